@@ -1,0 +1,207 @@
+"""Generate golden fixtures by IMPORTING the reference (build container only).
+
+Runs the reference's own ``calibration_step2`` (read-only import from
+/root/reference, CPU, ``.cuda()`` shimmed to identity -- SURVEY.md App. C) on
+small seeded layers and stores inputs + outputs as ``tests/golden/*.npz``.
+Nothing from the reference is copied: the fixtures are data (inputs, expected
+intervals, expected score tables).  The reference does not exist on the GPU
+box, so this script is never run there; the committed ``.npz`` files travel.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _install_shims():
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+class ArgmaxRecorder:
+    """Capture every score table the reference feeds to argmax (the search decisions)."""
+
+    def __init__(self):
+        self.tables = []
+        self._t_argmax = torch.Tensor.argmax
+        self._f_argmax = torch.argmax
+
+    def __enter__(self):
+        rec = self
+
+        def t_argmax(self_, *a, **k):
+            rec.tables.append(self_.detach().clone().numpy())
+            return rec._t_argmax(self_, *a, **k)
+
+        def f_argmax(inp, *a, **k):
+            rec.tables.append(inp.detach().clone().numpy())
+            return rec._f_argmax(inp, *a, **k)
+
+        torch.Tensor.argmax = t_argmax
+        torch.argmax = f_argmax
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.argmax = self._t_argmax
+        torch.argmax = self._f_argmax
+
+
+def _save(name, params, arrays, tables):
+    os.makedirs(OUT, exist_ok=True)
+    payload = {k: np.asarray(v) for k, v in arrays.items()}
+    for i, t in enumerate(tables):
+        payload[f"scores_{i:02d}"] = t
+    payload["params"] = np.array(json.dumps(params))
+    payload["n_scores"] = np.array(len(tables))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **payload)
+    print(f"wrote {name}.npz  ({len(tables)} score tables)")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# --------------------------------------------------------------------------- #
+def gen_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bias=True, **kw):
+    from quant_layers.linear import PTQSLBatchingQuantLinear, PostGeluPTQSLBatchingQuantLinear
+
+    g = torch.Generator().manual_seed(seed)
+    ic = shape_x[-1]
+    w = torch.randn(oc, ic, generator=g) * 0.05
+    # per-row-block magnitude spread so the n_V blocks get different intervals
+    w = w * torch.linspace(0.5, 2.0, oc).view(-1, 1)
+    b = torch.randn(oc, generator=g) * 0.1 if bias else None
+    x = torch.randn(*shape_x, generator=g)
+    if postgelu:
+        x = F.gelu(1.5 * x)
+    out = F.linear(x, w, b)
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    cls = PostGeluPTQSLBatchingQuantLinear if postgelu else PTQSLBatchingQuantLinear
+    m = cls(ic, oc, bias=bias, **kw)
+    m.weight.data = w.clone()
+    if bias:
+        m.bias.data = b.clone()
+    m.raw_input, m.raw_out, m.raw_grad = x.clone(), out.clone(), grad.clone()
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        m.calibration_step2()
+    m.mode = "quant_forward"
+    with torch.no_grad():
+        qf = m(x)
+    arrays = dict(weight=w.numpy(), x=x.numpy(), out=out.numpy(), grad=grad.numpy(),
+                  w_interval=m.w_interval.numpy(), a_interval=m.a_interval.numpy(),
+                  quant_forward=qf.numpy(),
+                  calib=np.array([m.calib_size, m.calib_batch_size, m.parallel_eq_n]))
+    if bias:
+        arrays["bias"] = b.numpy()
+    _save(name, dict(kind="linear", postgelu=postgelu, oc=oc, **kw), arrays, rec.tables)
+
+
+def gen_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, **kw):
+    from quant_layers.matmul import PTQSLBatchingQuantMatMul, SoSPTQSLBatchingQuantMatMul
+
+    g = torch.Generator().manual_seed(seed)
+    if sos:
+        A = torch.softmax(torch.randn(b, H, d1, d2, generator=g) * 3.0, dim=-1)
+    else:
+        A = torch.randn(b, H, d1, d2, generator=g) * torch.linspace(0.5, 2.0, H).view(1, H, 1, 1)
+    # B is handed over as a transposed view in the q.k^T case (utils/models.py:16)
+    Bm = (torch.randn(b, H, d3, d2, generator=g) * torch.linspace(2.0, 0.5, H).view(1, H, 1, 1)).transpose(-2, -1)
+    out = A @ Bm
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    cls = SoSPTQSLBatchingQuantMatMul if sos else PTQSLBatchingQuantMatMul
+    m = cls(**kw)
+    m.raw_input, m.raw_out, m.raw_grad = [A.clone(), Bm.clone()], out.clone(), grad.clone()
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        m.calibration_step2()
+    m.mode = "quant_forward"
+    with torch.no_grad():
+        qf = m(A, Bm)
+    arrays = dict(A=A.numpy(), B=Bm.contiguous().numpy(), out=out.numpy(), grad=grad.numpy(),
+                  A_interval=np.asarray(m.A_interval), B_interval=m.B_interval.numpy(),
+                  quant_forward=qf.numpy())
+    if sos:
+        arrays["split"] = np.asarray(m.split)
+    _save(name, dict(kind="matmul", sos=sos, **kw), arrays, rec.tables)
+
+
+def gen_conv(name, *, b, ic, hw, oc, k, stride, channelwise=True, grad_scale=1e-3, seed=0, **kw):
+    from quant_layers.conv import BatchingEasyQuantConv2d, ChannelwiseBatchingQuantConv2d
+
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(oc, ic, k, k, generator=g) * 0.05 * torch.linspace(0.5, 2.0, oc).view(-1, 1, 1, 1)
+    bias = torch.randn(oc, generator=g) * 0.1
+    x = torch.randn(b, ic, hw, hw, generator=g)
+    out = F.conv2d(x, w, bias, stride)
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    cls = ChannelwiseBatchingQuantConv2d if channelwise else BatchingEasyQuantConv2d
+    m = cls(ic, oc, k, stride, **kw)
+    m.weight.data = w.clone()
+    m.bias.data = bias.clone()
+    m.raw_input, m.raw_out, m.raw_grad = x.clone(), out.clone(), grad.clone()
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        m.calibration_step2()
+    m.mode = "quant_forward"
+    with torch.no_grad():
+        qf = m(x)
+    arrays = dict(weight=w.numpy(), bias=bias.numpy(), x=x.numpy(), out=out.numpy(), grad=grad.numpy(),
+                  w_interval=np.asarray(m.w_interval), a_interval=np.asarray(m.a_interval),
+                  quant_forward=qf.numpy())
+    _save(name, dict(kind="conv", channelwise=channelwise, stride=stride, **kw), arrays, rec.tables)
+
+
+PTQ4VIT = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3)
+BASEPTQ = dict(metric="cosine", eq_alpha=0.5, eq_beta=1.2, eq_n=100, search_round=1)
+
+
+def main():
+    _install_shims()
+    os.chdir(REF)
+    # ---- Linear (quant_layers/linear.py:349-642) ---------------------------------
+    gen_linear("linear_qkv_hessian_w8a8", shape_x=(4, 13, 48), oc=36, n_V=3, w_bit=8, a_bit=8, **PTQ4VIT)
+    gen_linear("linear_hessian_w6a6_tinygrad", shape_x=(4, 13, 48), oc=24, n_V=1, w_bit=6, a_bit=6,
+               grad_scale=1e-10, seed=1, **PTQ4VIT)
+    gen_linear("linear_cosine_w8a8", shape_x=(4, 13, 48), oc=36, n_V=3, w_bit=8, a_bit=8, seed=2, **BASEPTQ)
+    gen_linear("linear_head2d_hessian", shape_x=(8, 40), oc=10, n_V=1, w_bit=8, a_bit=8, seed=3, **PTQ4VIT)
+    gen_linear("linear_nobias_L2", shape_x=(3, 7, 32), oc=16, n_V=2, w_bit=8, a_bit=8, seed=4, bias=False,
+               metric="L2_norm", eq_alpha=0.3, eq_beta=1.3, eq_n=50, search_round=2)
+    gen_linear("linear_blocks_nH2_na2", shape_x=(3, 7, 32), oc=16, n_V=2, n_H=2, n_a=2, w_bit=8, a_bit=8, seed=5,
+               metric="hessian", eq_alpha=0.2, eq_beta=1.2, eq_n=40, search_round=2)
+    for i, met in enumerate(["L1_norm", "linear_weighted_L2_norm", "square_weighted_L2_norm"]):
+        gen_linear(f"linear_metric_{met}", shape_x=(3, 5, 32), oc=16, n_V=1, w_bit=8, a_bit=8, seed=6 + i,
+                   metric=met, eq_alpha=0.3, eq_beta=1.2, eq_n=30, search_round=1)
+    gen_linear("postgelu_hessian_w8a8", shape_x=(4, 13, 64), oc=24, postgelu=True, n_V=1, w_bit=8, a_bit=8,
+               seed=10, **PTQ4VIT)
+    gen_linear("postgelu_hessian_w6a6", shape_x=(4, 13, 64), oc=24, postgelu=True, n_V=1, w_bit=6, a_bit=6,
+               seed=11, **PTQ4VIT)
+    gen_linear("postgelu_cosine_w8a8", shape_x=(4, 13, 64), oc=24, postgelu=True, n_V=1, w_bit=8, a_bit=8,
+               seed=12, **BASEPTQ)
+    # ---- MatMul (quant_layers/matmul.py:390-644) ---------------------------------
+    gen_matmul("matmul_qk_hessian_w8a8", b=4, H=3, d1=13, d2=8, d3=13, A_bit=8, B_bit=8, seed=20, **PTQ4VIT)
+    gen_matmul("matmul_qk_cosine_w6a6", b=4, H=3, d1=13, d2=8, d3=13, A_bit=6, B_bit=6, seed=21, **BASEPTQ)
+    gen_matmul("matmul_sv_hessian_plain", b=4, H=3, d1=13, d2=13, d3=8, A_bit=8, B_bit=8, seed=22, **PTQ4VIT)
+    gen_matmul("matmul_sos_hessian_w8a8", b=4, H=3, d1=13, d2=13, d3=8, sos=True, A_bit=8, B_bit=8, seed=23, **PTQ4VIT)
+    gen_matmul("matmul_sos_hessian_w6a6", b=4, H=3, d1=13, d2=13, d3=8, sos=True, A_bit=6, B_bit=6, seed=24, **PTQ4VIT)
+    # ---- Conv2d (quant_layers/conv.py:279-614) -----------------------------------
+    gen_conv("conv_channelwise_hessian", b=4, ic=3, hw=32, oc=12, k=8, stride=8, w_bit=8, a_bit=32, seed=30, **PTQ4VIT)
+    gen_conv("conv_channelwise_cosine", b=4, ic=3, hw=32, oc=12, k=8, stride=8, w_bit=8, a_bit=32, seed=31, **BASEPTQ)
+    gen_conv("conv_layerwise_cosine", b=4, ic=3, hw=32, oc=12, k=8, stride=8, channelwise=False, w_bit=8, a_bit=32,
+             seed=32, **BASEPTQ)
+    # NB: the layer-wise class cannot search activations (conv.py:420 indexes a 4-D tensor with dim 4 ->
+    # IndexError), so it is only usable with a_bit=32, as both shipped configs do (configs/BasePTQ.py:50).
+    gen_conv("conv_layerwise_hessian_w6", b=4, ic=3, hw=32, oc=12, k=8, stride=8, channelwise=False, w_bit=6, a_bit=32,
+             seed=33, **PTQ4VIT)
+    gen_conv("conv_channelwise_hessian_a8_overlap", b=3, ic=3, hw=20, oc=8, k=5, stride=3, w_bit=8, a_bit=8, seed=34,
+             metric="hessian", eq_alpha=0.3, eq_beta=1.2, eq_n=30, search_round=2)
+
+
+if __name__ == "__main__":
+    main()
