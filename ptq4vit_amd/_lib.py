@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI in include/ptq4vit_hip.h (libptq4vit_hip.so, built in-tree).
+
+The library is the product: if it cannot be loaded this module raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptq4vit_hip.so")
+
+METRICS = {
+    "L1_norm": 0,
+    "L2_norm": 1,
+    "linear_weighted_L2_norm": 2,
+    "square_weighted_L2_norm": 3,
+    "hessian": 4,
+    "cosine": 5,
+}
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "tokens", "in_features", "out_features", "n_V", "n_H", "n_a", "w_bit", "a_bit", "metric",
+        "eq_n", "search_round", "twin_postgelu", "init_layerwise", "has_bias", "reserved")]
+
+
+class MatMulDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("batch", "heads", "M", "K", "N")] + [("_pad0", C.c_int32)] +
+                [("a_stride", C.c_int64 * 4), ("b_stride", C.c_int64 * 4)] +
+                [(n, C.c_int32) for n in ("A_bit", "B_bit", "metric", "eq_n", "search_round", "sos",
+                                          "init_layerwise", "reserved")])
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "in_channels", "height", "width", "out_channels", "kernel_h", "kernel_w", "stride_h", "stride_w",
+        "pad_h", "pad_w", "dil_h", "dil_w", "w_bit", "a_bit", "metric", "eq_n", "search_round", "channelwise",
+        "init_layerwise", "has_bias", "reserved")]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("sweep_i8_ms", C.c_double), ("sweep_i8_launches", C.c_int64), ("sweep_i8_macs", C.c_double),
+                ("sweep_f32_ms", C.c_double), ("sweep_f32_launches", C.c_int64), ("sweep_f32_macs", C.c_double)]
+
+
+EXPORTS = [
+    "p4v_version", "p4v_last_error",
+    "p4v_linear_workspace_bytes", "p4v_linear_calibrate",
+    "p4v_matmul_workspace_bytes", "p4v_matmul_calibrate",
+    "p4v_conv_workspace_bytes", "p4v_conv_calibrate",
+    "p4v_quantize_i8", "p4v_fake_quant",
+    "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
+]
+
+_lib = None
+
+
+def load():
+    """Load libptq4vit_hip.so (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"ptq4vit_amd: HIP extension {LIB_PATH} is missing -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the calibration path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.p4v_version.restype = C.c_int
+    lib.p4v_last_error.restype = C.c_char_p
+    lib.p4v_linear_workspace_bytes.restype = C.c_size_t
+    lib.p4v_linear_workspace_bytes.argtypes = [C.POINTER(LinearDesc)]
+    lib.p4v_linear_calibrate.restype = C.c_int
+    lib.p4v_linear_calibrate.argtypes = [C.POINTER(LinearDesc), fp, fp, fp, fp, fp, fp, fp, fp, fp, ip, vp, C.c_size_t, vp]
+    lib.p4v_matmul_workspace_bytes.restype = C.c_size_t
+    lib.p4v_matmul_workspace_bytes.argtypes = [C.POINTER(MatMulDesc)]
+    lib.p4v_matmul_calibrate.restype = C.c_int
+    lib.p4v_matmul_calibrate.argtypes = [C.POINTER(MatMulDesc), fp, fp, fp, fp, fp, fp, fp, fp, fp, ip, vp, C.c_size_t, vp]
+    lib.p4v_conv_workspace_bytes.restype = C.c_size_t
+    lib.p4v_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
+    lib.p4v_conv_calibrate.restype = C.c_int
+    lib.p4v_conv_calibrate.argtypes = [C.POINTER(ConvDesc), fp, fp, fp, fp, fp, fp, fp, fp, fp, ip, vp, C.c_size_t, vp]
+    lib.p4v_quantize_i8.restype = C.c_int
+    lib.p4v_quantize_i8.argtypes = [fp, C.c_int64, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
+    lib.p4v_fake_quant.restype = C.c_int
+    lib.p4v_fake_quant.argtypes = [fp, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, fp, vp]
+    lib.p4v_stats_enable.restype = C.c_int
+    lib.p4v_stats_enable.argtypes = [C.c_int]
+    lib.p4v_stats_reset.restype = C.c_int
+    lib.p4v_stats_get.restype = C.c_int
+    lib.p4v_stats_get.argtypes = [C.POINTER(KernelStats)]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().p4v_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,890 @@
+// Host side of the C ABI declared in include/ptq4vit_hip.h.
+//
+// Each *_calibrate entry point enqueues the complete calibration_step2() of one module on the
+// caller's stream: interval initialisation, candidate tables, and for every search round the
+// pack -> sweep -> finish -> select kernel chain for both operands.  Intervals live in device
+// memory from start to end, so there is no host round trip inside a module (the reference moves
+// x/out/grad host<->device on every search call, quant_layers/linear.py:461-464).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/ptq4vit_hip.h"
+#include "p4v_kernels.h"
+
+using namespace p4v;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(P4V_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define CHK(expr)              \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Bump allocator over the caller's workspace.  With base == nullptr it only counts (dry run):
+// *_workspace_bytes() runs the same planning code as *_calibrate().
+struct Arena {
+    char* base;
+    size_t cap, off, peak;
+    bool dry;
+    Arena(void* b, size_t c) : base((char*)b), cap(c), off(0), peak(0), dry(b == nullptr) {}
+    template <typename T> T* get(size_t n) {
+        off = (size_t)rup((long)off, 256);
+        T* p = dry ? nullptr : (T*)(base + off);
+        off += n * sizeof(T);
+        if (off > peak) peak = off;
+        return p;
+    }
+    bool ok() const { return dry || off <= cap; }
+};
+
+// ---- optional per-launch timing of the sweep kernels (bench.py roofline) -----------------------
+struct StatRec { hipEvent_t a, b; int kind; double macs; };
+std::mutex g_stat_mu;
+bool g_stat_on = false;
+std::vector<StatRec> g_stat_recs;
+p4v_kernel_stats g_stats = {};
+
+struct Ctx {
+    hipStream_t st;
+    Arena ws;
+    bool dry;
+};
+
+void metric_epi(int metric, int* epi, int* wt_mode) {
+    switch (metric) {
+        case P4V_METRIC_L1_NORM: *epi = EPI_ABS; *wt_mode = 0; break;
+        case P4V_METRIC_L2_NORM: *epi = EPI_SQ; *wt_mode = 0; break;
+        case P4V_METRIC_LINEAR_WEIGHTED_L2: *epi = EPI_W_SQ; *wt_mode = 3; break;
+        case P4V_METRIC_SQUARE_WEIGHTED_L2: *epi = EPI_SQ_W; *wt_mode = 2; break;
+        case P4V_METRIC_HESSIAN: *epi = EPI_SQ_W; *wt_mode = 1; break;
+        default: *epi = EPI_COS; *wt_mode = 0; break;
+    }
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+int launch_absmax(Ctx& c, const float* src, const long (&st)[4], int D0, int D1, int R, int C, int nV, int nH,
+                  int crb_r, int crb_c, int signed_max, unsigned* out) {
+    if (c.dry) return 0;
+    HIPCHK(hipMemsetAsync(out, 0, sizeof(unsigned) * (size_t)D1 * nV * nH, c.st));  // 0 < enc(x) for every float x
+    AbsMaxParams p{src, st[0], st[1], st[2], st[3], D0, D1, R, C, nV, nH, crb_r, crb_c, 0, signed_max, out};
+    p.row_tile = std::max(1, std::min(crb_r, std::max(1, 8192 / std::max(1, std::min(crb_c, C)))));
+    const int tiles_per_v = cdiv(crb_r, p.row_tile);
+    dim3 grid(tiles_per_v * nV * nH, D1, D0);
+    hipLaunchKernelGGL(k_absmax, grid, dim3(256), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_interval(Ctx& c, const unsigned* enc, int n, float denom, int broadcast, float* interval) {
+    if (c.dry) return 0;
+    hipLaunchKernelGGL(k_interval_from_max, dim3(cdiv(n, 64)), dim3(64), 0, c.st, enc, n, denom, broadcast, interval);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_cands(Ctx& c, const float* mult, const float* interval, int ncand, int nblk, float* cands) {
+    if (c.dry) return 0;
+    hipLaunchKernelGGL(k_make_cands, dim3(cdiv((long)ncand * nblk, 256)), dim3(256), 0, c.st, mult, interval, ncand, nblk, cands);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_scale(Ctx& c, ScaleParams p) {
+    if (c.dry) return 0;
+    hipLaunchKernelGGL(k_scale_table, dim3(cdiv((long)p.C * p.nblk, 256)), dim3(256), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
+    if (c.dry) return 0;
+    const long total = (long)p.Z * p.Rp * (p.Kp / 16);
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 256L * 64);
+    hipLaunchKernelGGL(k_pack<T>, dim3(blocks), dim3(256), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams& p, int epi) {
+    const size_t lds = 2 * (TWIN ? 3 : 2) * SW_TILE_BYTES;
+    dim3 grid(p.mtiles * p.ntiles, p.Z), block(512);
+    switch (epi) {
+        case EPI_SQ_W: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ_W>), grid, block, lds, c.st, p); break;
+        case EPI_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ>), grid, block, lds, c.st, p); break;
+        case EPI_ABS: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_ABS>), grid, block, lds, c.st, p); break;
+        case EPI_W_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_W_SQ>), grid, block, lds, c.st, p); break;
+        default: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_COS>), grid, block, lds, c.st, p); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi) {
+    if (c.dry) return 0;
+    bool timed;
+    StatRec rec{};
+    {
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        timed = g_stat_on;
+    }
+    if (timed) {
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        rec.kind = i8 ? 0 : 1;
+        const double kelems = (double)p.ldk / (i8 ? 1 : 4);
+        rec.macs = (double)p.mtiles * SW_BM * (double)p.ntiles * SW_BN * kelems * p.Z * (p.c1 - p.c0) * (twin ? 2 : 1);
+        HIPCHK(hipEventRecord(rec.a, c.st));
+    }
+    int r;
+    if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi) : launch_sweep_epi<int8_t, false>(c, p, epi);
+    else r = twin ? launch_sweep_epi<float, true>(c, p, epi) : launch_sweep_epi<float, false>(c, p, epi);
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        g_stat_recs.push_back(rec);
+    }
+    return r;
+}
+
+int launch_finish(Ctx& c, const FinishParams& p) {
+    if (c.dry) return 0;
+    hipLaunchKernelGGL(k_finish, dim3(p.C, p.nj), dim3(256), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_finish_cos(Ctx& c, const FinishCosParams& p) {
+    if (c.dry) return 0;
+    const int gy = p.j_mode == 3 ? cdiv(p.S, 256) : p.nj;
+    hipLaunchKernelGGL(k_finish_cos, dim3(p.C, gy), dim3(256), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_select(Ctx& c, const SelectParams& p) {
+    if (c.dry) return 0;
+    hipLaunchKernelGGL(k_select, dim3(cdiv(p.nj, 64)), dim3(64), 0, c.st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- one search pass -------------------------------------------------------------------------------
+// A "pass" evaluates eq_n candidates of ONE operand against a fixed counterpart and selects the best
+// candidate per score block.  The GEMM is D[rows][cols] = rowop . colop^T; in the plain orientation rows
+// are samples (activations / matmul A) and columns are output features (weights / matmul B); the cosine
+// metric runs swapped so that the feature axis it reduces over lies on the MFMA rows.
+struct Operand {
+    PackParams pk;        // src/strides/sizes/scales/mode filled by the caller (dst, C, Rp, Kp set by run_pass)
+    bool expanded;        // true: one plane per candidate
+    bool present;
+};
+
+struct Pass {
+    bool i8, twin;
+    int epi, wt_mode;
+    Operand row, row2, col;   // row2 = twin second plane (always on the row side)
+    int Z;                    // batched GEMMs (matmul batch*heads, V blocks of the swapped cosine sweep)
+    long row_zs_shared, col_zs_shared;  // 1 = operand shared across z (stride 0)
+    int Mrows, Ncols, K;      // valid sizes of the GEMM
+    int eq_n;
+    // scales
+    ScaleParams s1, s2;       // s.S filled by run_pass; nblk = s_cs
+    bool use_s1;
+    int sb_mode, sb_div, s_cs;
+    // epilogue operands
+    const float* bias; int bias_axis; long bias_zs;
+    const float* O; const float* G;
+    long o_zs, o_bs, o_ms, o_nbs, o_ns; int o_inner, o_ninner;
+    // finish
+    int j_mode, j_div, nj; double norm;
+    int cos_ZB, cos_ZV, cos_j_mode, cos_j_div;   // cosine finish geometry
+    // select
+    const float* cands; int cand_cs, cand_js, cand_off;
+    float* interval; int out_js, out_off;
+    float* aux_out; float aux_div;
+    float* scores_out; int scores_out_ld;
+    int32_t* best_out;
+};
+
+static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
+
+int run_pass(Ctx& c, Pass& ps) {
+    const int esz = ps.i8 ? 1 : 4;
+    const int Kp = (int)rup(ps.K, 64 / esz);          // 64-byte k-tiles
+    const int Mp = (int)rup(ps.Mrows, SW_BM), Np = (int)rup(ps.Ncols, SW_BN);
+    const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
+    const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
+    const long col_plane1 = ps.col_zs_shared ? (long)Np * Kp * esz : col_plane;
+    const long exp_plane = ps.row.expanded ? row_plane1 : col_plane1;
+    int chunk = (int)std::max<long>(1, std::min<long>(ps.eq_n, PLANE_BUDGET / std::max<long>(1, exp_plane)));
+
+    const size_t mark = c.ws.off;
+    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk : 1));
+    char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
+    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk : 1));
+    const int MT = Mp / 64;
+    const bool cosm = ps.epi == EPI_COS;
+    const long p_zs = (long)MT * Np * (cosm ? 3 : 1);
+    const long p_cs = p_zs * ps.Z;
+    float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
+    float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
+    float* S2 = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
+    float* scores = c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+
+    if (ps.use_s1) {
+        ps.s1.S = S1; ps.s1.C = ps.eq_n; ps.s1.nblk = ps.s_cs;
+        CHK(launch_scale(c, ps.s1));
+        if (ps.twin) { ps.s2.S = S2; ps.s2.C = ps.eq_n; ps.s2.nblk = ps.s_cs; CHK(launch_scale(c, ps.s2)); }
+    }
+    auto pack = [&](Operand& op, char* buf, int Rp, bool shared, int c0, int nc) -> int {
+        PackParams pk = op.pk;
+        pk.Rp = Rp; pk.Kp = Kp; pk.dst = buf;
+        pk.Z = shared ? 1 : ps.Z;
+        pk.C = op.expanded ? nc : 1;
+        if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
+        return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
+    };
+    // fixed planes once
+    if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
+    if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));
+    if (!ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, 0, 1));
+
+    for (int c0 = 0; c0 < ps.eq_n; c0 += chunk) {
+        const int nc = std::min(chunk, ps.eq_n - c0);
+        if (ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
+        if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
+        if (ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
+        SweepParams sp{};
+        // plane pointers are biased so that the kernel can index them with the absolute candidate id
+        sp.a_cs = ps.row.expanded ? row_plane1 : 0;
+        sp.A = rowbuf - (long)c0 * sp.a_cs;
+        sp.a_zs = ps.row_zs_shared ? 0 : (long)Mp * Kp * esz;
+        if (ps.twin) {
+            sp.a2_cs = ps.row2.expanded ? row_plane1 : 0;
+            sp.A2 = row2buf - (long)c0 * sp.a2_cs;
+            sp.a2_zs = sp.a_zs;
+        }
+        sp.b_cs = ps.col.expanded ? col_plane1 : 0;
+        sp.B = colbuf - (long)c0 * sp.b_cs;
+        sp.b_zs = ps.col_zs_shared ? 0 : (long)Np * Kp * esz;
+        sp.ldk = Kp * esz; sp.ktiles = sp.ldk / SW_BKB;
+        sp.S1 = S1; sp.S2 = S2; sp.s_cs = ps.s_cs; sp.sb_mode = ps.sb_mode; sp.sb_div = std::max(1, ps.sb_div);
+        sp.bias = ps.bias; sp.bias_axis = ps.bias_axis; sp.bias_zs = ps.bias_zs;
+        sp.O = ps.O; sp.Wt = ps.G; sp.wt_mode = ps.wt_mode;
+        sp.o_zs = ps.o_zs; sp.o_bs = ps.o_bs; sp.o_ms = ps.o_ms; sp.o_nbs = ps.o_nbs; sp.o_ns = ps.o_ns;
+        sp.o_inner = ps.o_inner > 0 ? ps.o_inner : INT_MAX;
+        sp.o_ninner = ps.o_ninner > 0 ? ps.o_ninner : INT_MAX;
+        sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc;
+        sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = Np;
+        sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
+        CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi));
+    }
+    if (!cosm) {
+        FinishParams fp{part, p_cs, p_zs, Np, MT, ps.Z, ps.Ncols, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores};
+        CHK(launch_finish(c, fp));
+    } else {
+        // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
+        FinishCosParams fp{part, p_cs, p_zs, Np, MT, ps.cos_ZB, ps.cos_ZV, ps.Ncols, ps.eq_n,
+                           ps.cos_j_mode, std::max(1, ps.cos_j_div), ps.nj, ps.norm, scores};
+        CHK(launch_finish_cos(c, fp));
+    }
+    SelectParams sl{scores, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, ps.interval, ps.out_js,
+                    ps.out_off, ps.aux_out, ps.aux_div, ps.scores_out, ps.scores_out_ld, ps.best_out};
+    CHK(launch_select(c, sl));
+    c.ws.off = mark;   // scratch of this pass is reusable by the next one (same stream => ordered)
+    return 0;
+}
+
+PackParams pack2d(const float* src, long rows, long cols, long ld) {
+    PackParams p{};
+    p.src = src; p.s_z = 0; p.s_r = ld; p.s_k = 1; p.Z = 1; p.R = (int)rows; p.K = (int)cols;
+    p.mode = PACK_SYM; p.nblk_r = 1; p.nblk_k = 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear
+// ------------------------------------------------------------------------------------------------
+int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, const float* X, const float* O,
+                const float* G, const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out,
+                Ctx& c) {
+    const int M = d->batch * d->tokens, K = d->in_features, N = d->out_features;
+    const int nV = d->n_V, nH = d->n_H, nA = d->n_a;
+    if (M <= 0 || K <= 0 || N <= 0 || nV <= 0 || nH <= 0 || nA <= 0 || d->eq_n <= 0)
+        return fail(P4V_ERR_INVALID, "linear: non-positive dimension");
+    if (N % nV || K % nH || K % nA) return fail(P4V_ERR_UNSUPPORTED, "linear: n_V/n_H/n_a must divide the layer (reference ignores remainders, linear.py:118)");
+    if (d->w_bit > 8 || d->a_bit > 8 || d->w_bit < 2 || d->a_bit < 2) return fail(P4V_ERR_UNSUPPORTED, "linear: bit widths 2..8 supported");
+    const int crb_rows = N / nV, crb_cols = K / nH, crb_acts = K / nA;
+    const int wq = 1 << (d->w_bit - 1), aq = 1 << (d->a_bit - 1);
+    const float a_neg = (float)(0.16997124254703522 / aq);   // linear.py:574
+    int epi, wt_mode;
+    metric_epi(d->metric, &epi, &wt_mode);
+    const bool cosm = epi == EPI_COS;
+    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "linear: hessian metric needs raw_grad (linear.py:418)");
+    const bool general = (nH > 1 || nA > 1 || (d->reserved & 1) || (cosm && d->twin_postgelu));
+    const bool i8 = !general;
+    const bool twin = d->twin_postgelu && i8;
+    if (cosm && (nH > 1 || nA > 1)) return fail(P4V_ERR_UNSUPPORTED, "linear: cosine with n_H>1 / n_a>1 is not implemented on the GPU");
+    const int ncand = d->eq_n + 1;
+
+    // ---- interval initialisation (linear.py:380-397 / 576-599) ---------------------------------------
+    unsigned* enc_w = c.ws.get<unsigned>((size_t)nV * nH);
+    unsigned* enc_a = c.ws.get<unsigned>((size_t)nA);
+    float* w_cands = c.ws.get<float>((size_t)ncand * nV * nH);
+    float* a_cands = c.ws.get<float>((size_t)ncand * nA);
+    float* w_mix = c.ws.get<float>((size_t)ncand * nV * nH);   // general path: candidates of block column h only
+    float* a_mix = c.ws.get<float>((size_t)ncand * nA);
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
+    {
+        const long stw[4] = {0, 0, K, 1};
+        CHK(launch_absmax(c, W, stw, 1, 1, N, K, nV, nH, crb_rows, crb_cols, 0, enc_w));
+        CHK(launch_interval(c, enc_w, nV * nH, (float)(wq - 0.5), d->init_layerwise, w_iv));
+        CHK(launch_absmax(c, X, stw, 1, 1, M, K, 1, nA, M, crb_acts, d->twin_postgelu ? 1 : 0, enc_a));
+        CHK(launch_interval(c, enc_a, nA, (float)(aq - 0.5), d->init_layerwise, a_iv));
+        CHK(launch_cands(c, mult, w_iv, ncand, nV * nH, w_cands));
+        CHK(launch_cands(c, mult, a_iv, ncand, nA, a_cands));
+    }
+
+    auto x_operand = [&](bool expanded, const float* scales, int sc_cs) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        op.pk = pack2d(X, M, K, K);
+        op.pk.scales = scales; op.pk.sc_cs = sc_cs;
+        op.pk.lo = -aq; op.pk.hi = aq - 1;
+        if (nA > 1) { op.pk.blk_mode = 1; op.pk.blk_div = INT_MAX; op.pk.nblk_r = 1; op.pk.nblk_k = nA; op.pk.blk_div2 = crb_acts; }
+        if (d->twin_postgelu) {
+            if (i8) { op.pk.lo = 0; }
+            else { op.pk.mode = PACK_TWIN_SIM; op.pk.lo = -aq; op.pk.neg_scale = a_neg; }
+        }
+        return op;
+    };
+    auto xneg_operand = [&]() {
+        Operand op{};
+        op.present = true; op.expanded = false;
+        op.pk = pack2d(X, M, K, K);
+        op.pk.scales = nullptr; op.pk.neg_scale = a_neg; op.pk.lo = -aq; op.pk.hi = 0;
+        return op;
+    };
+    auto w_operand = [&](bool expanded, const float* scales, int sc_cs, bool by_vblock) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        if (by_vblock) {   // swapped cosine sweep: one GEMM per V block
+            op.pk = pack2d(W, crb_rows, K, K);
+            op.pk.s_z = (long)crb_rows * K;
+            op.pk.blk_mode = 2; op.pk.blk_div = nV;
+            if (nH > 1) return op;  // unreachable: general path is not swapped per block
+        } else {
+            op.pk = pack2d(W, N, K, K);
+            op.pk.blk_mode = 1; op.pk.blk_div = crb_rows; op.pk.nblk_r = nV; op.pk.nblk_k = nH;
+            op.pk.blk_div2 = nH > 1 ? crb_cols : 0;
+        }
+        op.pk.scales = scales; op.pk.sc_cs = sc_cs;
+        op.pk.lo = -wq; op.pk.hi = wq - 1;
+        return op;
+    };
+
+    for (int round = 0; round < d->search_round; ++round) {
+        // ================= weight search (linear.py:455-495) =================
+        for (int h = 0; h < nH; ++h) {
+            Pass ps{};
+            ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
+            const float* wc = w_cands;
+            int wc_cs = nV * nH;
+            if (general && nH > 1) {
+                // candidates replace column block h only, the others keep the current interval (linear.py:468-469)
+                if (!c.dry) {
+                    ScaleParams mp{};  // w_mix[c][j] = (j % nH == h) ? w_cands[c][j] : w_iv[j] -- done with two launches
+                    mp.x = w_iv; mp.x_cs = 0; mp.x_js = 1; mp.y = nullptr; mp.y_const = 1.0f; mp.C = ncand; mp.nblk = nV * nH; mp.S = w_mix;
+                    CHK(launch_scale(c, mp));
+                    for (int v = 0; v < nV; ++v)
+                        HIPCHK(hipMemcpy2DAsync(w_mix + v * nH + h, sizeof(float) * nV * nH, w_cands + v * nH + h,
+                                                sizeof(float) * nV * nH, sizeof(float), ncand, hipMemcpyDeviceToDevice, c.st));
+                }
+                wc = w_mix;
+            }
+            ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
+            ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
+            ps.scores_out = scores_out ? scores_out + ((long)(round * 2 + 0) * d->eq_n) * nV : nullptr;
+            ps.scores_out_ld = nV;
+            ps.best_out = best_out ? best_out + (long)(round * 2 + 0) * nV : nullptr;
+            if (scores_out && nH > 1 && h > 0) ps.scores_out = nullptr;  // table of the first column block only
+            if (!cosm) {
+                ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
+                ps.row = x_operand(false, a_iv, 0);
+                if (twin) ps.row2 = xneg_operand();
+                ps.col = w_operand(true, wc, wc_cs, false);
+                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 1; ps.sb_div = crb_rows;
+                ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+                ps.s2 = ScaleParams{nullptr, 0, 0, a_neg, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+                ps.bias = bias; ps.bias_axis = 0; ps.bias_zs = 0;
+                ps.O = O; ps.G = G; ps.o_zs = 0; ps.o_bs = 0; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
+                ps.j_mode = 1; ps.j_div = crb_rows;
+                ps.norm = 1.0 / ((double)d->tokens * crb_rows);
+            } else {
+                // swapped: rows = features of V block z, cols = samples
+                ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
+                ps.row = w_operand(true, wc, wc_cs, true);
+                ps.col = x_operand(false, a_iv, 0);
+                ps.col_zs_shared = 1;
+                ps.use_s1 = true; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
+                ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+                ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
+                ps.O = O; ps.G = nullptr; ps.o_zs = crb_rows; ps.o_bs = 0; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
+                ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 1;
+                ps.norm = 1.0 / (double)d->tokens;
+            }
+            CHK(run_pass(c, ps));
+        }
+        // ================= activation search (linear.py:497-533 / 609-642) =================
+        for (int a = 0; a < nA; ++a) {
+            Pass ps{};
+            ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
+            const float* ac = a_cands;
+            if (general && nA > 1) {
+                if (!c.dry) {
+                    ScaleParams mp{};
+                    mp.x = a_iv; mp.x_cs = 0; mp.x_js = 1; mp.y = nullptr; mp.y_const = 1.0f; mp.C = ncand; mp.nblk = nA; mp.S = a_mix;
+                    CHK(launch_scale(c, mp));
+                    HIPCHK(hipMemcpy2DAsync(a_mix + a, sizeof(float) * nA, a_cands + a, sizeof(float) * nA, sizeof(float), ncand,
+                                            hipMemcpyDeviceToDevice, c.st));
+                }
+                ac = a_mix;
+            }
+            ps.nj = 1; ps.cands = a_cands; ps.cand_cs = nA; ps.cand_js = 0; ps.cand_off = a;
+            ps.interval = a_iv; ps.out_js = 0; ps.out_off = a;
+            ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)(round * 2 + 1) * d->eq_n) * nV : nullptr;
+            ps.scores_out_ld = nV;
+            ps.best_out = (best_out && a == 0) ? best_out + (long)(round * 2 + 1) * nV : nullptr;
+            if (!cosm) {
+                ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
+                ps.row = x_operand(true, ac, nA);
+                if (twin) ps.row2 = xneg_operand();
+                ps.col = w_operand(false, w_iv, 0, false);
+                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 1; ps.sb_div = crb_rows;
+                ps.s1 = ScaleParams{a_cands, 1, 0, 0.f, w_iv, 0, 1, 0.f, 0, 0, nullptr};
+                ps.s2 = ScaleParams{nullptr, 0, 0, a_neg, w_iv, 0, 1, 0.f, 0, 0, nullptr};
+                ps.bias = bias; ps.bias_axis = 0;
+                ps.O = O; ps.G = G; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
+                ps.j_mode = 0;
+                ps.norm = 1.0 / ((double)d->tokens * N);
+            } else {
+                ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
+                ps.row = w_operand(false, w_iv, 0, true);
+                ps.col = x_operand(true, ac, nA);
+                ps.col_zs_shared = 1;
+                ps.use_s1 = true; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
+                ps.s1 = ScaleParams{a_cands, 1, 0, 0.f, w_iv, 0, 1, 0.f, 0, 0, nullptr};
+                ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
+                ps.O = O; ps.o_zs = crb_rows; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
+                ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 0;
+                ps.norm = 1.0 / (double)d->tokens;
+            }
+            CHK(run_pass(c, ps));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MatMul
+// ------------------------------------------------------------------------------------------------
+int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const float* O, const float* G,
+                const float* mult, float* A_iv, float* B_iv, float* split, float* scores_out, int32_t* best_out, Ctx& c) {
+    const int H = d->heads, Z = d->batch * d->heads, M = d->M, K = d->K, N = d->N;
+    if (Z <= 0 || M <= 0 || K <= 0 || N <= 0 || d->eq_n <= 0) return fail(P4V_ERR_INVALID, "matmul: non-positive dimension");
+    if (d->A_bit > 8 || d->B_bit > 8) return fail(P4V_ERR_UNSUPPORTED, "matmul: bit widths <= 8 supported");
+    const int Aq = 1 << (d->A_bit - 1), Bq = 1 << (d->B_bit - 1);
+    int epi, wt_mode;
+    metric_epi(d->metric, &epi, &wt_mode);
+    const bool cosm = epi == EPI_COS;
+    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
+    if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
+    const int ncand = d->eq_n + 1;
+    const int NSPLIT = 20;  // matmul.py:636
+
+    unsigned* enc_A = c.ws.get<unsigned>(H);
+    unsigned* enc_B = c.ws.get<unsigned>(H);
+    float* A_cands = c.ws.get<float>((size_t)ncand * H);
+    float* B_cands = c.ws.get<float>((size_t)ncand * H);
+    float* split_cands = c.ws.get<float>(NSPLIT);
+    float* A_headwise = c.ws.get<float>(H);   // sos: the inherited head-wise A interval is computed then overwritten (matmul.py:419-440)
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
+    {
+        const long sa[4] = {d->a_stride[0], d->a_stride[1], d->a_stride[2], d->a_stride[3]};
+        const long sb[4] = {d->b_stride[0], d->b_stride[1], d->b_stride[2], d->b_stride[3]};
+        float* a_dst = d->sos ? A_headwise : A_iv;
+        CHK(launch_absmax(c, A, sa, d->batch, H, M, K, 1, 1, M, K, 0, enc_A));
+        CHK(launch_interval(c, enc_A, H, (float)(Aq - 0.5), d->init_layerwise, a_dst));
+        CHK(launch_absmax(c, B, sb, d->batch, H, K, N, 1, 1, K, N, 0, enc_B));
+        CHK(launch_interval(c, enc_B, H, (float)(Bq - 0.5), d->init_layerwise, B_iv));
+        if (!d->sos) CHK(launch_cands(c, mult, A_iv, ncand, H, A_cands));
+        CHK(launch_cands(c, mult, B_iv, ncand, H, B_cands));
+        if (d->sos && !c.dry) {
+            float sc[NSPLIT];
+            for (int i = 0; i < NSPLIT; ++i) sc[i] = (float)std::ldexp(1.0, -i);  // 2**(-i), exact in fp32
+            HIPCHK(hipMemcpyAsync(split_cands, sc, sizeof sc, hipMemcpyHostToDevice, c.st));
+            HIPCHK(hipStreamSynchronize(c.st));  // sc lives on this stack frame
+        }
+    }
+    // logical [Z][rows][K] views: A rows = m, B rows = n (B given as [K][N])
+    auto A_operand = [&](bool expanded, const float* scales, int sc_cs, int mode) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        op.pk = PackParams{};
+        op.pk.src = A; op.pk.s_z = d->a_stride[1]; op.pk.s_r = d->a_stride[2]; op.pk.s_k = d->a_stride[3];
+        op.pk.s_z2 = d->a_stride[0]; op.pk.zdiv = H;
+        op.pk.Z = Z; op.pk.R = M; op.pk.K = K; op.pk.nblk_r = 1; op.pk.nblk_k = 1;
+        op.pk.mode = mode; op.pk.scales = scales; op.pk.sc_cs = sc_cs;
+        op.pk.blk_mode = (mode == PACK_SYM) ? 2 : 0; op.pk.blk_div = H;
+        op.pk.lo = -Aq; op.pk.hi = Aq - 1; op.pk.qm1 = (float)(Aq - 1);
+        return op;
+    };
+    auto B_operand = [&](bool expanded, const float* scales, int sc_cs, int mode) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        op.pk = PackParams{};
+        op.pk.src = B; op.pk.s_z = d->b_stride[1]; op.pk.s_r = d->b_stride[3]; op.pk.s_k = d->b_stride[2];
+        op.pk.s_z2 = d->b_stride[0]; op.pk.zdiv = H;
+        op.pk.Z = Z; op.pk.R = N; op.pk.K = K; op.pk.nblk_r = 1; op.pk.nblk_k = 1;
+        op.pk.mode = mode; op.pk.scales = scales; op.pk.sc_cs = sc_cs;
+        op.pk.blk_mode = (mode == PACK_SYM) ? 2 : 0; op.pk.blk_div = H;
+        op.pk.lo = -Bq; op.pk.hi = Bq - 1;
+        return op;
+    };
+    auto common = [&](Pass& ps) {
+        ps.Z = Z; ps.K = K;
+        ps.O = O; ps.G = G; ps.wt_mode = wt_mode; ps.epi = epi;
+        ps.o_inner = INT_MAX;
+        if (!cosm) { ps.Mrows = M; ps.Ncols = N; ps.o_zs = (long)M * N; ps.o_ms = N; ps.o_ns = 1; }
+        else { ps.Mrows = N; ps.Ncols = M; ps.o_zs = (long)M * N; ps.o_ms = 1; ps.o_ns = N; ps.G = nullptr;
+               ps.cos_ZB = Z; ps.cos_ZV = 1; }
+    };
+
+    for (int round = 0; round < d->search_round; ++round) {
+        float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * H : nullptr;
+        int32_t* bo = best_out ? best_out + (long)(round * 2) * H : nullptr;
+        if (!d->sos) {
+            // ---- A search, B fixed at its current head-wise interval (matmul.py:483-522) ----
+            Pass ps{};
+            common(ps);
+            ps.i8 = true; ps.twin = false; ps.eq_n = d->eq_n;
+            Operand a = A_operand(true, A_cands, H, PACK_SYM), b = B_operand(false, B_iv, 0, PACK_SYM);
+            if (!cosm) { ps.row = a; ps.col = b; } else { ps.row = b; ps.col = a; }
+            ps.use_s1 = true; ps.s_cs = H; ps.sb_mode = 2; ps.sb_div = H;
+            ps.s1 = ScaleParams{A_cands, H, 1, 0.f, B_iv, 0, 1, 0.f, 0, 0, nullptr};
+            ps.j_mode = 2; ps.j_div = H; ps.nj = H; ps.cos_j_mode = 2; ps.cos_j_div = H;
+            ps.norm = cosm ? 1.0 / (double)M : 1.0 / ((double)M * N);
+            ps.cands = A_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = A_iv; ps.out_js = 1;
+            ps.scores_out = so; ps.scores_out_ld = H; ps.best_out = bo;
+            CHK(run_pass(c, ps));
+        } else {
+            // ---- split search against the UNQUANTISED B (matmul.py:600-631): fp32 operands ----
+            Pass ps{};
+            common(ps);
+            ps.i8 = false; ps.twin = false; ps.eq_n = NSPLIT;
+            Operand a = A_operand(true, split_cands, 1, PACK_SOS_SIM), b = B_operand(false, nullptr, 0, PACK_RAW);
+            if (!cosm) { ps.row = a; ps.col = b; } else { ps.row = b; ps.col = a; }
+            ps.use_s1 = false; ps.s_cs = 1; ps.sb_mode = 0;
+            ps.j_mode = 0; ps.nj = 1; ps.cos_j_mode = 0;
+            ps.norm = cosm ? 1.0 / ((double)H * M) : 1.0 / ((double)H * M * N);
+            ps.cands = split_cands; ps.cand_cs = 1; ps.cand_js = 0; ps.interval = split; ps.out_js = 0;
+            ps.aux_out = A_iv; ps.aux_div = (float)(Aq - 1);   // A_interval = split/(qmax-1) (matmul.py:629)
+            ps.scores_out = (d->eq_n >= NSPLIT) ? so : nullptr; ps.scores_out_ld = H; ps.best_out = bo;
+            CHK(run_pass(c, ps));
+        }
+        {
+            // ---- B search, A fixed (matmul.py:524-563); with sos, A is the two-range twin (matmul.py:595-598) ----
+            Pass ps{};
+            common(ps);
+            ps.eq_n = d->eq_n;
+            const bool twin_rows = d->sos && !cosm;
+            ps.i8 = !(d->sos && cosm);   // cosine + sos: fp32 operands (the twin sits on the column side when swapped)
+            ps.twin = twin_rows;
+            Operand b = B_operand(true, B_cands, H, PACK_SYM);
+            Operand a = d->sos ? A_operand(false, split, 0, ps.i8 ? PACK_SOS_HI : PACK_SOS_SIM) : A_operand(false, A_iv, 0, PACK_SYM);
+            if (!cosm) { ps.row = a; ps.col = b; if (twin_rows) ps.row2 = A_operand(false, split, 0, PACK_SOS_LO); }
+            else { ps.row = b; ps.col = a; }
+            ps.use_s1 = ps.i8; ps.s_cs = H; ps.sb_mode = 2; ps.sb_div = H;
+            if (!d->sos) ps.s1 = ScaleParams{A_iv, 0, 1, 0.f, B_cands, H, 1, 0.f, 0, 0, nullptr};
+            else {
+                // high range: k_hi/(q-1) ; low range: k_lo * (split/(q-1)) = k_lo * A_interval
+                ps.s1 = ScaleParams{nullptr, 0, 0, 1.0f / (float)(Aq - 1), B_cands, H, 1, 0.f, 0, 0, nullptr};
+                ps.s2 = ScaleParams{A_iv, 0, 0, 0.f, B_cands, H, 1, 0.f, 0, 0, nullptr};
+            }
+            ps.j_mode = 2; ps.j_div = H; ps.nj = H; ps.cos_j_mode = 2; ps.cos_j_div = H;
+            ps.norm = cosm ? 1.0 / (double)M : 1.0 / ((double)M * N);
+            ps.cands = B_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = B_iv; ps.out_js = 1;
+            ps.scores_out = so ? so + (long)d->eq_n * H : nullptr; ps.scores_out_ld = H;
+            ps.best_out = bo ? bo + H : nullptr;
+            CHK(run_pass(c, ps));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv2d (patch embedding): fp32 operands (the input stays unquantised with a_bit >= 32, conv.py:544)
+// ------------------------------------------------------------------------------------------------
+int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const float* X, const float* O, const float* G,
+              const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out, Ctx& c) {
+    const int b = d->batch, ic = d->in_channels, H = d->height, Wd = d->width, oc = d->out_channels;
+    const int kh = d->kernel_h, kw = d->kernel_w;
+    const int fh = (H + 2 * d->pad_h - d->dil_h * (kh - 1) - 1) / d->stride_h + 1;
+    const int fw = (Wd + 2 * d->pad_w - d->dil_w * (kw - 1) - 1) / d->stride_w + 1;
+    if (b <= 0 || ic <= 0 || oc <= 0 || fh <= 0 || fw <= 0 || d->eq_n <= 0) return fail(P4V_ERR_INVALID, "conv: bad geometry");
+    if (d->w_bit > 8) return fail(P4V_ERR_UNSUPPORTED, "conv: w_bit <= 8 supported");
+    const int L = fh * fw, K = ic * kh * kw, M = b * L;
+    const int wq = 1 << (d->w_bit - 1);
+    const bool aquant = d->a_bit < 32;
+    const int aq = aquant ? (1 << (d->a_bit - 1)) : 0;
+    if (aquant && !d->channelwise) return fail(P4V_ERR_UNSUPPORTED, "conv: the layer-wise class cannot search activations (reference conv.py:420 raises IndexError); use a_bit=32");
+    int epi, wt_mode;
+    metric_epi(d->metric, &epi, &wt_mode);
+    const bool cosm = epi == EPI_COS;
+    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "conv: hessian metric needs raw_grad");
+    if (cosm && aquant) return fail(P4V_ERR_UNSUPPORTED, "conv: cosine does not support the activation search (reference conv.py:505-506)");
+    const int nw = d->channelwise ? oc : 1;
+    const int ncand = d->eq_n + 1;
+
+    unsigned* enc_w = c.ws.get<unsigned>(nw);
+    unsigned* enc_a = c.ws.get<unsigned>(1);
+    float* w_cands = c.ws.get<float>((size_t)ncand * nw);
+    float* a_cands = c.ws.get<float>(ncand);
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
+    {
+        const long stw[4] = {0, 0, K, 1};
+        CHK(launch_absmax(c, W, stw, 1, 1, oc, K, nw, 1, d->channelwise ? 1 : oc, K, 0, enc_w));
+        CHK(launch_interval(c, enc_w, nw, (float)(wq - 0.5), d->init_layerwise, w_iv));
+        const long stx[4] = {0, 0, (long)ic * H * Wd, 1};
+        CHK(launch_absmax(c, X, stx, 1, 1, b, ic * H * Wd, 1, 1, b, ic * H * Wd, 0, enc_a));
+        CHK(launch_interval(c, enc_a, 1, aquant ? (float)(aq - 0.5) : (float)(std::ldexp(1.0, d->a_bit - 1) - 0.5), 0, a_iv));
+        CHK(launch_cands(c, mult, w_iv, ncand, nw, w_cands));
+        CHK(launch_cands(c, mult, a_iv, ncand, 1, a_cands));
+    }
+    // x as im2col rows.  per_image: Z = batch, rows = pixels of one image (channel-wise cosine reduces over pixels)
+    auto x_operand = [&](bool expanded, const float* scales, int sc_cs, bool per_image) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        op.pk = PackParams{};
+        op.pk.src = X; op.pk.conv = 1; op.pk.ic = ic; op.pk.H = H; op.pk.W = Wd; op.pk.kh = kh; op.pk.kw = kw;
+        op.pk.sh = d->stride_h; op.pk.sw = d->stride_w; op.pk.ph = d->pad_h; op.pk.pw = d->pad_w; op.pk.dh = d->dil_h; op.pk.dw = d->dil_w;
+        op.pk.fw = fw; op.pk.L = L;
+        op.pk.Z = per_image ? b : 1; op.pk.s_z = per_image ? (long)ic * H * Wd : 0;
+        op.pk.R = per_image ? L : M; op.pk.K = K; op.pk.nblk_r = 1; op.pk.nblk_k = 1;
+        op.pk.mode = aquant ? PACK_SYM : PACK_RAW; op.pk.scales = aquant ? scales : nullptr; op.pk.sc_cs = sc_cs;
+        op.pk.lo = -aq; op.pk.hi = aq - 1;
+        return op;
+    };
+    auto w_operand = [&](bool expanded, const float* scales, int sc_cs) {
+        Operand op{};
+        op.present = true; op.expanded = expanded;
+        op.pk = pack2d(W, oc, K, K);
+        op.pk.scales = scales; op.pk.sc_cs = sc_cs;
+        op.pk.blk_mode = d->channelwise ? 1 : 0; op.pk.blk_div = 1; op.pk.nblk_r = nw; op.pk.nblk_k = 1;
+        op.pk.lo = -wq; op.pk.hi = wq - 1;
+        return op;
+    };
+    auto setup = [&](Pass& ps, bool w_search) {
+        ps.i8 = false; ps.twin = false; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
+        ps.use_s1 = false; ps.s_cs = 1; ps.sb_mode = 0;
+        ps.O = O; ps.G = G; ps.bias = bias;
+        Operand xo = x_operand(!w_search, a_cands, 1, cosm && d->channelwise);
+        Operand wo = w_operand(w_search, w_search ? w_cands : w_iv, w_search ? nw : 0);
+        if (!cosm) {
+            // rows = (image, pixel), cols = oc;  out[b][oc][l]
+            ps.Z = 1; ps.Mrows = M; ps.Ncols = oc; ps.row = xo; ps.col = wo;
+            ps.o_inner = L; ps.o_bs = (long)oc * L; ps.o_ms = 1; ps.o_ns = L; ps.bias_axis = 0;
+        } else if (d->channelwise) {
+            // cosine over the pixels of one image per (image, oc) (conv.py:504-508): rows = pixels, z = image
+            ps.Z = b; ps.Mrows = L; ps.Ncols = oc; ps.row = xo; ps.col = wo; ps.col_zs_shared = 1;
+            ps.o_zs = (long)oc * L; ps.o_inner = INT_MAX; ps.o_ms = 1; ps.o_ns = L; ps.bias_axis = 0; ps.G = nullptr;
+            ps.cos_ZB = b; ps.cos_ZV = 1;
+        } else {
+            // cosine over oc per pixel (conv.py:387): swapped, rows = oc, cols = (image, pixel)
+            ps.Z = 1; ps.Mrows = oc; ps.Ncols = M; ps.row = wo; ps.col = xo;
+            // element (row=oc, col=m): idx = (m / L)*oc*L + (m % L) + oc_idx*L  -> column index drives the image split
+            ps.o_inner = INT_MAX; ps.o_ms = L; ps.o_ninner = L; ps.o_nbs = (long)oc * L; ps.o_ns = 1;
+            ps.bias_axis = 1; ps.G = nullptr;
+            ps.cos_ZB = 1; ps.cos_ZV = 1;
+        }
+    };
+
+    for (int round = 0; round < d->search_round; ++round) {
+        float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * nw : nullptr;
+        int32_t* bo = best_out ? best_out + (long)(round * 2) * nw : nullptr;
+        {   // ---- weight search (conv.py:526-557 / 365-396) ----
+            Pass ps{};
+            setup(ps, true);
+            ps.nj = nw;
+            if (!cosm) { ps.j_mode = d->channelwise ? 3 : 0; ps.norm = d->channelwise ? 1.0 / (double)L : 1.0 / ((double)L * oc); }
+            else if (d->channelwise) { ps.cos_j_mode = 3; ps.norm = 1.0; }
+            else { ps.cos_j_mode = 0; ps.norm = 1.0 / (double)L; }
+            ps.cands = w_cands; ps.cand_cs = nw; ps.cand_js = 1; ps.interval = w_iv; ps.out_js = 1;
+            ps.scores_out = so; ps.scores_out_ld = nw; ps.best_out = bo;
+            CHK(run_pass(c, ps));
+        }
+        if (aquant) {  // ---- activation search (conv.py:559-589), channel-wise class only ----
+            Pass ps{};
+            setup(ps, false);
+            ps.nj = 1; ps.j_mode = 0; ps.norm = 1.0 / ((double)L * oc);
+            ps.cands = a_cands; ps.cand_cs = 1; ps.cand_js = 0; ps.interval = a_iv; ps.out_js = 0;
+            ps.scores_out = so ? so + (long)d->eq_n * nw : nullptr; ps.scores_out_ld = nw;
+            ps.best_out = bo ? bo + nw : nullptr;
+            CHK(run_pass(c, ps));
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int p4v_version(void) { return P4V_VERSION; }
+const char* p4v_last_error(void) { return g_err.c_str(); }
+
+size_t p4v_linear_workspace_bytes(const p4v_linear_desc* desc) {
+    if (!desc) return 0;
+    Ctx c{nullptr, Arena(nullptr, 0), true};   // dry run of the planner: counts, launches nothing
+    if (linear_impl(desc, nullptr, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, nullptr, nullptr, c) != 0) return 0;
+    return c.ws.peak + 4096;
+}
+
+int p4v_linear_calibrate(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                         const float* d_out, const float* d_grad, const float* d_mult, float* d_w_interval,
+                         float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (!desc || !d_weight || !d_x || !d_out || !d_mult || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "linear: null pointer");
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "linear: has_bias set but d_bias is NULL");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return linear_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, d_mult, d_w_interval,
+                       d_a_interval, d_scores, d_best, c);
+}
+
+size_t p4v_matmul_workspace_bytes(const p4v_matmul_desc* desc) {
+    if (!desc) return 0;
+    Ctx c{nullptr, Arena(nullptr, 0), true};
+    float dummy = 0;
+    if (matmul_impl(desc, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, c) != 0) return 0;
+    return c.ws.peak + 4096;
+}
+
+int p4v_matmul_calibrate(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                         const float* d_grad, const float* d_mult, float* d_A_interval, float* d_B_interval, float* d_split,
+                         float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_A || !d_B || !d_out || !d_mult || !d_A_interval || !d_B_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "matmul: null pointer");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return matmul_impl(desc, d_A, d_B, d_out, d_grad, d_mult, d_A_interval, d_B_interval, d_split, d_scores, d_best, c);
+}
+
+size_t p4v_conv_workspace_bytes(const p4v_conv_desc* desc) {
+    if (!desc) return 0;
+    Ctx c{nullptr, Arena(nullptr, 0), true};
+    if (conv_impl(desc, nullptr, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, nullptr, nullptr, c) != 0) return 0;
+    return c.ws.peak + 4096;
+}
+
+int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                       const float* d_out, const float* d_grad, const float* d_mult, float* d_w_interval, float* d_a_interval,
+                       float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_out || !d_mult || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "conv: null pointer");
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "conv: has_bias set but d_bias is NULL");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return conv_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, d_mult, d_w_interval, d_a_interval,
+                     d_scores, d_best, c);
+}
+
+int p4v_quantize_i8(const float* d_x, int64_t rows, int64_t cols, int64_t cols_padded, const float* d_scales,
+                    int64_t rows_per_scale, int32_t lo, int32_t hi, int8_t* d_q, void* stream) {
+    if (!d_x || !d_scales || !d_q || rows <= 0 || cols <= 0 || cols_padded % 64 || cols_padded < cols || rows_per_scale <= 0)
+        return fail(P4V_ERR_INVALID, "quantize_i8: bad argument");
+    Ctx c{(hipStream_t)stream, Arena(nullptr, 0), false};
+    PackParams p = pack2d(d_x, rows, cols, cols);
+    p.Rp = (int)rows; p.Kp = (int)cols_padded; p.dst = d_q; p.C = 1;
+    p.scales = d_scales; p.sc_cs = 0; p.blk_mode = 1; p.blk_div = (int)rows_per_scale;
+    p.nblk_r = cdiv(rows, rows_per_scale); p.nblk_k = 1; p.lo = lo; p.hi = hi;
+    return launch_pack<int8_t>(c, p);
+}
+
+int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_scales, int64_t rows_per_scale,
+                   int32_t lo, int32_t hi, float* d_y, void* stream) {
+    if (!d_x || !d_scales || !d_y || rows <= 0 || cols <= 0 || rows_per_scale <= 0)
+        return fail(P4V_ERR_INVALID, "fake_quant: bad argument");
+    const long n = rows * cols;
+    hipLaunchKernelGGL(k_fake_quant_rows, dim3((unsigned)std::min<long>(cdiv(n, 256), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, (long)rows, (long)cols, d_scales, (long)rows_per_scale, (float)lo, (float)hi, d_y);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int p4v_stats_enable(int enable) {
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    g_stat_on = enable != 0;
+    return 0;
+}
+
+static int stats_drain_locked() {
+    for (auto& r : g_stat_recs) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.kind == 0) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; }
+        else { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_stat_recs.clear();
+    return 0;
+}
+
+int p4v_stats_reset(void) {
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    int r = stats_drain_locked();
+    g_stats = p4v_kernel_stats{};
+    return r;
+}
+
+int p4v_stats_get(p4v_kernel_stats* out) {
+    if (!out) return fail(P4V_ERR_INVALID, "stats_get: null");
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    int r = stats_drain_locked();
+    *out = g_stats;
+    return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,617 @@
+// Device kernels of the PTQ4ViT calibration engine for gfx950 (CDNA4, wave64).
+//
+// Pipeline of one search pass (reference quant_layers/linear.py:455-533 and siblings):
+//   k_pack      fake-quantise an operand to int8 grid indices (or fp32 values), once per
+//               candidate for the searched operand, once for the fixed one       [HBM-bound]
+//   k_sweep     candidate-sweep GEMM on MFMA (i8->i32 or f32) with the similarity
+//               metric fused into the epilogue -> per-column partial sums        [MFMA-bound]
+//   k_finish    deterministic fixed-order reduction of the partials -> score[c][block]
+//   k_select    argmax over candidates (first max, NaN counts as max) + gather of the interval
+//
+// No atomics on floating-point data anywhere: results are run-to-run and 1-vs-N-GPU identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace p4v {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// block abs-max (reference linear.py:385,395; matmul.py:435-436; conv.py:487,494)
+// ------------------------------------------------------------------------------------------
+// Monotonic float <-> uint encoding so that an integer atomicMax implements an exact
+// (order-independent, hence deterministic) floating-point max.
+__device__ __forceinline__ unsigned enc_ordered(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned e) {
+    unsigned b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(b);
+}
+
+struct AbsMaxParams {
+    const float* src;
+    long s0, s1, s2, s3;      // element strides of the 4-D view [D0][D1][R][C]
+    int D0, D1, R, C;
+    int nV, nH, crb_r, crb_c; // row / column blocking of (R, C); D1 indexes the group (head)
+    int row_tile;             // rows handled by one workgroup
+    int signed_max;           // 1: plain max (post-GELU, linear.py:597), 0: abs max
+    unsigned* out;            // [D1][nV][nH] ordered-encoded running max
+};
+
+__global__ __launch_bounds__(256) void k_absmax(AbsMaxParams p) {
+    // grid.x = tiles-per-v * nV * nH, grid.y = D1, grid.z = D0
+    const int tiles_per_v = (p.crb_r + p.row_tile - 1) / p.row_tile;
+    int bx = blockIdx.x;
+    const int h = bx % p.nH; bx /= p.nH;
+    const int v = bx % p.nV; bx /= p.nV;
+    const int rt = bx;
+    const int r0 = v * p.crb_r + rt * p.row_tile;
+    const int r1 = min(min(r0 + p.row_tile, (v + 1) * p.crb_r), p.R);
+    const int c0 = h * p.crb_c;
+    const int c1 = min(c0 + p.crb_c, p.C);
+    const int w = c1 - c0;
+    const float* base = p.src + (long)blockIdx.z * p.s0 + (long)blockIdx.y * p.s1;
+    float m = -INFINITY;
+    if (w > 0 && r1 > r0) {
+        const int n = (r1 - r0) * w;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int r = r0 + i / w, c = c0 + i % w;
+            float x = base[(long)r * p.s2 + (long)c * p.s3];
+            m = fmaxf(m, p.signed_max ? x : fabsf(x));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > -INFINITY) atomicMax(p.out + ((long)blockIdx.y * p.nV + v) * p.nH + h, enc_ordered(m));
+    }
+}
+
+// interval[j] = max[j] / (qmax - 0.5)   (linear.py:385); `broadcast`: init_layerwise (linear.py:383)
+__global__ void k_interval_from_max(const unsigned* enc, int n, float denom, int broadcast, float* interval) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float m;
+    if (broadcast) {
+        m = -INFINITY;
+        for (int i = 0; i < n; ++i) m = fmaxf(m, dec_ordered(enc[i]));
+    } else {
+        m = dec_ordered(enc[j]);
+    }
+    interval[j] = m / denom;
+}
+
+// cands[c][j] = mult[c] * interval[j]  (fp32 multiply, linear.py:544-545)
+__global__ void k_make_cands(const float* mult, const float* interval, int ncand, int nblk, float* cands) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand * nblk) return;
+    cands[i] = mult[i / nblk] * interval[i % nblk];
+}
+
+// S[c][j] = X(c,j) * Y(c,j); each factor is a device array (with candidate / block strides) or a constant.
+struct ScaleParams {
+    const float* x; int x_cs, x_js; float x_const;
+    const float* y; int y_cs, y_js; float y_const;
+    int C, nblk;
+    float* S;
+};
+__global__ void k_scale_table(ScaleParams p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.C * p.nblk) return;
+    const int c = i / p.nblk, j = i % p.nblk;
+    const float x = p.x ? p.x[c * p.x_cs + j * p.x_js] : p.x_const;
+    const float y = p.y ? p.y[c * p.y_cs + j * p.y_js] : p.y_const;
+    p.S[i] = x * y;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pack: fake quantisation of one operand into a K-contiguous, zero-padded plane
+// ------------------------------------------------------------------------------------------
+enum PackMode {
+    PACK_RAW = 0,     // copy (fp32 only)
+    PACK_SYM = 1,     // clamp(rint(x/s), lo, hi)                      linear.py:167
+    PACK_SOS_HI = 2,  // clamp(rint(clamp(x,split,1)*(q-1)), 0, q-1)   matmul.py:596
+    PACK_SOS_LO = 3,  // clamp(rint(clamp(x,0,split)/(split/(q-1))), 0, q-1)   matmul.py:597
+    PACK_SOS_SIM = 4, // fp32 only: hi/(q-1) + lo*(split/(q-1))        matmul.py:613-615
+    PACK_TWIN_SIM = 5 // fp32 only: pos*s + neg*s_neg                  linear.py:605-607
+};
+
+struct PackParams {
+    const float* src;
+    long s_z, s_r, s_k;   // element strides of the logical [Z][R][K] view
+    long s_z2; int zdiv;  // two-level batch: offset = (z / zdiv) * s_z2 + (z % zdiv) * s_z  (zdiv <= 0: single level)
+    int Z, R, K;
+    int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp]
+    void* dst;
+    int C;
+    const float* scales;  // scales[c*sc_cs + blk]; for SOS modes: split candidates / the split
+    int sc_cs;
+    int blk_mode, blk_div, blk_div2; // 0: blk=0; 1: blk = min(r/blk_div, nblk_r-1)*nblk_k + k/blk_div2 (k part only if blk_div2); 2: blk = z % blk_div
+    int nblk_r, nblk_k;
+    int mode, lo, hi;
+    float qm1;            // q-1 for SOS modes
+    float neg_scale;      // twin: fixed negative-range interval
+    // optional im2col gather (conv): logical r = (b, oy, ox), k = (ci, ki, kj)
+    int conv, ic, H, W, kh, kw, sh, sw, ph, pw, dh, dw, fw, L;
+};
+
+__device__ __forceinline__ float pack_value(const PackParams& p, float x, float s) {
+    switch (p.mode) {
+        case PACK_SYM: return fminf(fmaxf(rintf(x / s), (float)p.lo), (float)p.hi);
+        case PACK_SOS_HI: return fminf(fmaxf(rintf(fminf(fmaxf(x, s), 1.0f) * p.qm1), 0.0f), p.qm1);
+        case PACK_SOS_LO: {
+            const float a_int = s / p.qm1;
+            return fminf(fmaxf(rintf(fminf(fmaxf(x, 0.0f), s) / a_int), 0.0f), p.qm1);
+        }
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float pack_value_f32(const PackParams& p, float x, float s) {
+    switch (p.mode) {
+        case PACK_RAW: return x;
+        case PACK_SYM: return fminf(fmaxf(rintf(x / s), (float)p.lo), (float)p.hi) * s;
+        case PACK_SOS_SIM: {
+            const float a_int = s / p.qm1;
+            const float hi = fminf(fmaxf(rintf(fminf(fmaxf(x, s), 1.0f) * p.qm1), 0.0f), p.qm1) / p.qm1;
+            const float lo = fminf(fmaxf(rintf(fminf(fmaxf(x, 0.0f), s) / a_int), 0.0f), p.qm1) * a_int;
+            return hi + lo;
+        }
+        case PACK_TWIN_SIM: {
+            const float pos = fminf(fmaxf(rintf(x / s), 0.0f), (float)p.hi) * s;
+            const float neg = fminf(fmaxf(rintf(x / p.neg_scale), (float)p.lo), 0.0f) * p.neg_scale;
+            return pos + neg;
+        }
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float pack_load(const PackParams& p, const float* zbase, int r, int k) {
+    if (r >= p.R || k >= p.K) return 0.0f;
+    if (!p.conv) return zbase[(long)r * p.s_r + (long)k * p.s_k];
+    const int b = r / p.L, l = r % p.L;   // zbase already points at image z (flat layout: Z = 1, b = r / L)
+    const int oy = l / p.fw, ox = l % p.fw;
+    const int kk = p.kh * p.kw;
+    const int ci = k / kk, ki = (k % kk) / p.kw, kj = k % p.kw;
+    const int y = oy * p.sh - p.ph + ki * p.dh, x = ox * p.sw - p.pw + kj * p.dw;
+    if (y < 0 || y >= p.H || x < 0 || x >= p.W) return 0.0f;
+    return zbase[(((long)b * p.ic + ci) * p.H + y) * p.W + x];
+}
+
+__device__ __forceinline__ int pack_blk(const PackParams& p, int z, int r, int k) {
+    if (p.blk_mode == 1) {
+        int b = min(r / p.blk_div, p.nblk_r - 1);
+        if (p.blk_div2) b = b * p.nblk_k + min(k / p.blk_div2, p.nblk_k - 1);
+        return b;
+    }
+    if (p.blk_mode == 2) return z % p.blk_div;
+    return 0;
+}
+
+// One thread owns 16 consecutive k of one (z, r) and loops over the candidates, so the source is
+// read once per pass and every store is a full 16-byte (int8) / 64-byte (fp32) run.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(PackParams p) {
+    const long kchunks = p.Kp / 16;
+    const long total = (long)p.Z * p.Rp * kchunks;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kc = (int)(i % kchunks);
+        const int r = (int)((i / kchunks) % p.Rp);
+        const int z = (int)(i / (kchunks * p.Rp));
+        const float* zbase = p.zdiv > 0 ? p.src + (long)(z / p.zdiv) * p.s_z2 + (long)(z % p.zdiv) * p.s_z
+                                        : p.src + (long)z * p.s_z;
+        float x[16];
+        int blk[16];
+        const bool per_k_blk = (p.blk_mode == 1 && p.blk_div2);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            x[e] = pack_load(p, zbase, r, kc * 16 + e);
+            blk[e] = per_k_blk ? pack_blk(p, z, r, min(kc * 16 + e, p.K - 1)) : 0;
+        }
+        const int blk0 = pack_blk(p, z, r, 0);
+        const bool live = (r < p.R);
+        for (int c = 0; c < p.C; ++c) {
+            const long o = (((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16;
+            if constexpr (sizeof(T) == 1) {
+                const float s = p.scales ? p.scales[c * p.sc_cs + blk0] : p.neg_scale;
+                int w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int acc = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = kc * 16 + q * 4 + e;
+                        float v = (live && kk < p.K) ? pack_value(p, x[q * 4 + e], s) : 0.0f;
+                        acc |= ((int)v & 0xff) << (8 * e);
+                    }
+                    w[q] = acc;
+                }
+                *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + o) = v4i{w[0], w[1], w[2], w[3]};
+            } else {
+                float* d = reinterpret_cast<float*>(p.dst) + o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = kc * 16 + q * 4 + e;
+                        const float s = p.scales ? p.scales[c * p.sc_cs + (per_k_blk ? blk[q * 4 + e] : blk0)] : 1.0f;
+                        v[e] = (live && kk < p.K) ? pack_value_f32(p, x[q * 4 + e], s) : 0.0f;
+                    }
+                    *reinterpret_cast<v4f*>(d + q * 4) = v;
+                }
+            }
+        }
+    }
+}
+
+// Plain 2-D helpers behind p4v_quantize_i8 / p4v_fake_quant (quant_forward building blocks).
+__global__ void k_fake_quant_rows(const float* x, long rows, long cols, const float* scales, long rows_per_scale,
+                                  float lo, float hi, float* y) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float s = scales[(i / cols) / rows_per_scale];
+        y[i] = fminf(fmaxf(rintf(x[i] / s), lo), hi) * s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep: the candidate-sweep GEMM with the similarity metric fused into the epilogue
+// ------------------------------------------------------------------------------------------
+enum EpiMode {
+    EPI_SQ_W = 0,  // (w*d)^2     hessian (w = raw_grad), square_weighted_L2 (w = raw_out)
+    EPI_SQ = 1,    // d^2         L2_norm
+    EPI_ABS = 2,   // |d|         L1_norm
+    EPI_W_SQ = 3,  // w*d^2       linear_weighted_L2 (w = |raw_out|)
+    EPI_COS = 4    // cosine: per-row dot / norm partials (rows of the MFMA tile = features)
+};
+
+struct SweepParams {
+    const void* A;  long a_cs, a_zs;   // byte strides between candidates / batch entries (0 = shared)
+    const void* A2; long a2_cs, a2_zs; // twin second plane (post-GELU negative range / SoS low range)
+    const void* B;  long b_cs, b_zs;
+    int ldk;                           // bytes per operand row (Kp * sizeof(T)), multiple of 64
+    int ktiles;                        // ldk / 64
+    const float* S1; const float* S2;  // [C][nsb] combined scale of plane 1 / 2 (NULL -> 1)
+    int s_cs;                          // nsb (scales per candidate)
+    int sb_mode, sb_div;               // 0: sb = 0; 1: sb = n / sb_div; 2: sb = z % sb_div
+    const float* bias;                 // per-column (n) bias, or per-row (m) when bias_axis = 1; NULL = none
+    int bias_axis; long bias_zs;       // bias element offset per z (V-block batches of the swapped cosine sweep)
+    const float* O;                    // raw_out
+    const float* Wt;                   // metric weight source (raw_grad) or NULL
+    int wt_mode;                       // 0: none, 1: Wt[idx] (hessian), 2: raw_out, 3: |raw_out|
+    // element index = z*o_zs + (m / o_inner)*o_bs + (m % o_inner)*o_ms + (n / o_ninner)*o_nbs + (n % o_ninner)*o_ns
+    long o_zs, o_bs, o_ms, o_nbs, o_ns;
+    int o_inner, o_ninner;
+    int M, N, Z;
+    int c0, c1;                        // candidate range of this launch
+    float* part;                       // [C][Z][MT][Np] per-column partial sums (MT = Mp/64 row slabs)
+    long p_cs, p_zs;                   // element strides of `part`
+    int Np;
+    int mtiles, ntiles;
+};
+
+static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
+static constexpr int SW_TILE_BYTES = SW_BM * SW_ROW;
+
+// XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (block b -> XCD b%8);
+// give each XCD a contiguous run of tiles so that neighbouring tiles (sharing an operand panel of the
+// same candidate) hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename T, bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = TWIN ? 3 : 2;                 // planes per stage: A, (A2), B
+    constexpr int STAGE = NPL * SW_TILE_BYTES;
+    constexpr bool IS_I8 = (sizeof(T) == 1);
+    typedef typename std::conditional<IS_I8, v16i, v16f>::type acc_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;            // 2 x 4 waves, each 64 rows x 32 cols
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int mt = t % p.mtiles, nt = t / p.mtiles;   // m fastest: tiles sharing a B (weight) panel are adjacent
+    const int z = blockIdx.y;
+    const int m0 = mt * SW_BM, n0 = nt * SW_BN;
+
+    // ---- candidate-invariant epilogue operands, kept in registers for the whole sweep -------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float u[2][16], w[2][16];
+    const int n = n0 + wc * 32 + l31;
+    const bool ncol_ok = n < p.N;
+    const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
+    const float bias_n = (biasz && ncol_ok && p.bias_axis == 0) ? biasz[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float ov = 0.0f, wv = 0.0f;
+            if (ncol_ok && m < p.M) {
+                const long idx = (long)z * p.o_zs + (long)(m / p.o_inner) * p.o_bs + (long)(m % p.o_inner) * p.o_ms +
+                                 (long)(n / p.o_ninner) * p.o_nbs + (long)(n % p.o_ninner) * p.o_ns;
+                const float o = p.O[idx];
+                ov = o - bias_n;
+                wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+                // cosine keeps the raw output and carries the bias (0 on padding rows) in w
+                if (EPI == EPI_COS) { ov = o; wv = biasz ? (p.bias_axis ? biasz[m] : bias_n) : 0.0f; }
+            }
+            u[i][r] = ov;
+            w[i][r] = wv;
+        }
+    const int sb = p.sb_mode == 1 ? min(n / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0;
+
+    // ---- global -> LDS staging: one 16-byte piece per thread per plane per k-tile ---------------------
+    const int ld_row = tid >> 2, ld_col = (tid & 3) * 16;
+    const char* gA = (const char*)p.A + (long)z * p.a_zs + (long)(m0 + ld_row) * p.ldk + ld_col;
+    const char* gA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)(m0 + ld_row) * p.ldk + ld_col : nullptr;
+    const char* gB = (const char*)p.B + (long)z * p.b_zs + (long)(n0 + ld_row) * p.ldk + ld_col;
+    const int lds_st = ld_row * SW_ROW + ld_col;
+
+    const int ncand = p.c1 - p.c0;
+    const int total = ncand * p.ktiles;
+    v4i ra, ra2, rb;
+    auto gload = [&](int it) {
+        const int c = p.c0 + it / p.ktiles, kt = it % p.ktiles;
+        ra = *reinterpret_cast<const v4i*>(gA + (long)c * p.a_cs + kt * SW_BKB);
+        if (TWIN) ra2 = *reinterpret_cast<const v4i*>(gA2 + (long)c * p.a2_cs + kt * SW_BKB);
+        rb = *reinterpret_cast<const v4i*>(gB + (long)c * p.b_cs + kt * SW_BKB);
+    };
+    auto lstore = [&](int stage) {
+        char* s = smem + stage * STAGE + lds_st;
+        *reinterpret_cast<v4i*>(s) = ra;
+        if (TWIN) *reinterpret_cast<v4i*>(s + SW_TILE_BYTES) = ra2;
+        *reinterpret_cast<v4i*>(s + (NPL - 1) * SW_TILE_BYTES) = rb;
+    };
+
+    acc_t acc[2], acc2[2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][r] = 0; if (TWIN) acc2[i][r] = 0; }
+    };
+    zero_acc();
+
+    // fragment base offsets inside a stage
+    const int fa = (wr * 64 + l31) * SW_ROW;       // + i*32*SW_ROW
+    const int fb = (NPL - 1) * SW_TILE_BYTES + (wc * 32 + l31) * SW_ROW;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int it = 0; it < total; ++it) {
+        const int stage = it & 1;
+        if (it + 1 < total) gload(it + 1);
+        const char* s = smem + stage * STAGE;
+        if constexpr (IS_I8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {          // two 32-deep K steps per 64-byte row
+                const int off = h * 32 + g * 16;
+                const v4i b = *reinterpret_cast<const v4i*>(s + fb + off);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const v4i a = *reinterpret_cast<const v4i*>(s + fa + i * 32 * SW_ROW + off);
+                    acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[i], 0, 0, 0);
+                    if (TWIN) {
+                        const v4i a2 = *reinterpret_cast<const v4i*>(s + SW_TILE_BYTES + fa + i * 32 * SW_ROW + off);
+                        acc2[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b, acc2[i], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // 16 floats of K per row; lane group g owns floats [8g, 8g+8): 8 MFMA 32x32x2 steps.
+            const int off = g * 32;
+            const v4f b0 = *reinterpret_cast<const v4f*>(s + fb + off);
+            const v4f b1 = *reinterpret_cast<const v4f*>(s + fb + off + 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const v4f a0 = *reinterpret_cast<const v4f*>(s + fa + i * 32 * SW_ROW + off);
+                const v4f a1 = *reinterpret_cast<const v4f*>(s + fa + i * 32 * SW_ROW + off + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[i], 0, 0, 0);
+                if (TWIN) {
+                    const v4f c0 = *reinterpret_cast<const v4f*>(s + SW_TILE_BYTES + fa + i * 32 * SW_ROW + off);
+                    const v4f c1 = *reinterpret_cast<const v4f*>(s + SW_TILE_BYTES + fa + i * 32 * SW_ROW + off + 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[e], b0[e], acc2[i], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[e], b1[e], acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < total) lstore(stage ^ 1);
+        __syncthreads();
+
+        if ((it + 1) % p.ktiles == 0) {
+            // ---- fused similarity epilogue for candidate c ------------------------------------------
+            const int c = p.c0 + it / p.ktiles;
+            const float s1 = p.S1 ? p.S1[c * p.s_cs + sb] : 1.0f;
+            const float s2 = (TWIN && p.S2) ? p.S2[c * p.s_cs + sb] : 1.0f;
+            if constexpr (EPI != EPI_COS) {
+                float colsum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o_sim = (float)acc[i][r] * s1;
+                        if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                        const float d = u[i][r] - o_sim;
+                        if (EPI == EPI_SQ_W) { const float tt = w[i][r] * d; colsum = fmaf(tt, tt, colsum); }
+                        else if (EPI == EPI_SQ) colsum = fmaf(d, d, colsum);
+                        else if (EPI == EPI_ABS) colsum += fabsf(d);
+                        else colsum = fmaf(w[i][r] * d, d, colsum);
+                    }
+                colsum += __shfl_xor(colsum, 32);
+                if (g == 0)
+                    p.part[(long)c * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + wr) * p.Np + n0 + wc * 32 + l31] = colsum;
+            } else {
+                // cosine: the MFMA rows are the feature axis the cosine reduces over, the columns are
+                // samples.  Per sample: partial dot(o, o_sim), |o_sim|^2, |o|^2 over this wave's 64 features.
+                float dot = 0.0f, nn = 0.0f, oo = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o_sim = fmaf((float)acc[i][r], s1, w[i][r]);
+                        if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                        dot = fmaf(u[i][r], o_sim, dot);
+                        nn = fmaf(o_sim, o_sim, nn);
+                        oo = fmaf(u[i][r], u[i][r], oo);
+                    }
+                dot += __shfl_xor(dot, 32);
+                nn += __shfl_xor(nn, 32);
+                oo += __shfl_xor(oo, 32);
+                if (g == 0) {
+                    float* q = p.part + (long)c * p.p_cs + (long)z * p.p_zs + ((long)(mt * 2 + wr) * p.Np + n0 + wc * 32 + l31) * 3;
+                    q[0] = dot; q[1] = nn; q[2] = oo;
+                }
+            }
+            zero_acc();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finish / k_select
+// ------------------------------------------------------------------------------------------
+struct FinishParams {
+    const float* part; long p_cs, p_zs; int Np, MT, Z, N, C;
+    int j_mode, j_div;     // 0: one block; 1: j = n / j_div; 2: j = z % j_div; 3: j = n
+    int nj;
+    double norm;           // score = -norm * sum
+    float* scores;         // [C][nj]
+};
+
+// One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
+// fixed-shape tree: the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void k_finish(FinishParams p) {
+    const int c = blockIdx.x, j = blockIdx.y;
+    int nlo = 0, nhi = p.N, zstep = 1, zlo = 0;
+    if (p.j_mode == 1) { nlo = j * p.j_div; nhi = min(p.N, nlo + p.j_div); if (j == p.nj - 1) nhi = p.N; }
+    else if (p.j_mode == 3) { nlo = j; nhi = j + 1; }
+    else if (p.j_mode == 2) { zlo = j; zstep = p.j_div; }
+    const int wn = nhi - nlo;
+    const int nz = (p.Z - zlo + zstep - 1) / zstep;
+    const long total = (long)nz * p.MT * wn;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int nn = (int)(i % wn);
+        const int mt = (int)((i / wn) % p.MT);
+        const int zz = zlo + (int)(i / ((long)wn * p.MT)) * zstep;
+        s += (double)p.part[(long)c * p.p_cs + (long)zz * p.p_zs + (long)mt * p.Np + nlo + nn];
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(-p.norm * red[0]);
+}
+
+// Cosine finish.  `part` holds triples (dot, |sim|^2, |raw|^2) laid out [C][ZB][ZV][FS][Sp][3]:
+// ZB real batch entries, ZV feature blocks swept as separate GEMMs, FS 64-feature slabs, Sp padded samples.
+// cos(sample) = dot / (max(|raw|,eps) * max(|sim|,eps)) over the features of the score block
+// (torch cosine_similarity, linear.py:406-407), then the mean/sum over samples (linear.py:483-487).
+struct FinishCosParams {
+    const float* part; long p_cs, p_zs; int Sp, FS, ZB, ZV, S, C;
+    int j_mode, j_div;     // 0: one block, all zv; 1: j = zv; 2: j = zb % j_div; 3: j = sample (sum over zb)
+    int nj;
+    double norm;
+    float* scores;
+};
+__device__ __forceinline__ float cos_item(const FinishCosParams& p, int c, int zb, int zv0, int zv1, int smp) {
+    float dot = 0.f, nn = 0.f, oo = 0.f;
+    for (int zv = zv0; zv < zv1; ++zv)
+        for (int f = 0; f < p.FS; ++f) {
+            const float* q = p.part + (long)c * p.p_cs + (long)(zb * p.ZV + zv) * p.p_zs + ((long)f * p.Sp + smp) * 3;
+            dot += q[0]; nn += q[1]; oo += q[2];
+        }
+    const float na = fmaxf(sqrtf(oo), 1e-8f), nb = fmaxf(sqrtf(nn), 1e-8f);
+    return dot / (na * nb);
+}
+__global__ __launch_bounds__(256) void k_finish_cos(FinishCosParams p) {
+    const int c = blockIdx.x, j = blockIdx.y;
+    double acc = 0.0;
+    if (p.j_mode == 3) {
+        // one workgroup per (candidate, chunk of 256 samples): thread = sample, serial over zb
+        const int smp = j * 256 + threadIdx.x;
+        if (smp < p.S) {
+            for (int zb = 0; zb < p.ZB; ++zb) acc += (double)cos_item(p, c, zb, 0, p.ZV, smp);
+            p.scores[(long)c * p.nj + smp] = (float)(p.norm * acc);
+        }
+        return;
+    }
+    int zv0 = 0, zv1 = p.ZV, zlo = 0, zstep = 1;
+    if (p.j_mode == 1) { zv0 = j; zv1 = j + 1; }
+    if (p.j_mode == 2) { zlo = j; zstep = p.j_div; }
+    const int nz = (p.ZB - zlo + zstep - 1) / zstep;
+    const long total = (long)nz * p.S;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int smp = (int)(i % p.S);
+        const int zb = zlo + (int)(i / p.S) * zstep;
+        acc += (double)cos_item(p, c, zb, zv0, zv1, smp);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(p.norm * red[0]);
+}
+
+// argmax over candidates per block (torch.argmax semantics: first maximum, NaN is the maximum) and
+// gather of the winning candidate interval (linear.py:493-494).
+struct SelectParams {
+    const float* scores; int C, nj;
+    const float* cands; int cand_cs, cand_js, cand_off;  // cands[best*cand_cs + j*cand_js + cand_off]
+    float* interval; int out_js, out_off;
+    float* aux_out; float aux_div;                        // optional: aux_out[0] = selected / aux_div (SoS A_interval)
+    float* scores_out;  // optional copy [C][scores_out_ld]
+    int scores_out_ld;
+    int32_t* best_out;  // optional [nj]
+};
+__global__ void k_select(SelectParams p) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.nj) return;
+    int best = 0;
+    float bv = p.scores[j];
+    bool bnan = bv != bv;
+    if (p.scores_out) p.scores_out[j] = bv;
+    for (int c = 1; c < p.C; ++c) {
+        const float v = p.scores[(long)c * p.nj + j];
+        if (p.scores_out) p.scores_out[(long)c * p.scores_out_ld + j] = v;
+        if (!bnan && (v != v || v > bv)) { best = c; bv = v; bnan = v != v; }
+    }
+    const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
+    p.interval[(long)j * p.out_js + p.out_off] = sel;
+    if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
+    if (p.best_out) p.best_out[j] = best;
+}
+
+}  // namespace p4v

@@ -1,0 +1,203 @@
+"""GPU parity: the HIP calibration engine (through the C ABI) vs the golden vectors of the reference
+and vs the numpy oracle on seeded inputs.  Run on the MI355X box with `pytest -m gpu`.
+
+Bar (floating point path): score tables within SCORE_RTOL of the reference's; the selected candidate equal
+to the reference's argmax or a near-tie by the reference's own scores; intervals then
+bit-identical to the reference's, or one candidate-grid step away at a near-tie.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (assert_argmax_tie_aware, assert_scores_close, golden_names, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ptq4vit_amd import engine
+    return engine
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cmp_tables(pairs, name):
+    """pairs: list of (got_scores[C, nblk], got_best[nblk], ref_table)."""
+    flips = 0
+    for i, (got, best, ref) in enumerate(pairs):
+        ref2 = ref.reshape(ref.shape[0], -1)
+        got = got[: ref2.shape[0], : ref2.shape[1]]
+        assert_scores_close(got, ref2, what=f"{name}[{i}]")
+        flips += assert_argmax_tie_aware(best[: ref2.shape[1]], ref2, what=f"{name}[{i}]")
+        # the engine's own argmax must follow its own table (first max)
+        np.testing.assert_array_equal(best[: ref2.shape[1]], np.argmax(got, axis=0), err_msg=f"{name}[{i}] select")
+    return flips
+
+
+def run_linear(eng, g, force_f32=False):
+    p = dict(g["params"])
+    p.pop("kind"); p.pop("oc")
+    postgelu = p.pop("postgelu")
+    w_iv, a_iv, scores, best = eng.linear_calibrate(
+        weight=_t(g["weight"]), bias=_t(g["bias"]) if "bias" in g else None, x=_t(g["x"]), out=_t(g["out"]),
+        grad=_t(g["grad"]), postgelu=postgelu, want_scores=True, force_f32=force_f32,
+        n_H=p.pop("n_H", 1), n_a=p.pop("n_a", 1), **p)
+    torch.cuda.synchronize()
+    return w_iv.cpu().numpy(), a_iv.cpu().numpy(), scores.cpu().numpy(), best.cpu().numpy()
+
+
+@pytest.mark.parametrize("force_f32", [False, True], ids=["i8", "f32"])
+@pytest.mark.parametrize("name", golden_names("linear_") + golden_names("postgelu_"))
+def test_linear_vs_reference_golden(eng, name, force_f32):
+    g = load_golden(name)
+    p = g["params"]
+    nH, nA, R = p.get("n_H", 1), p.get("n_a", 1), p["search_round"]
+    w_iv, a_iv, scores, best = run_linear(eng, g, force_f32)
+    per_round = nH + nA
+    pairs = []
+    for r in range(R):
+        pairs.append((scores[r, 0], best[r, 0], g["scores"][r * per_round + 0]))
+        pairs.append((scores[r, 1][:, :1], best[r, 1][:1], g["scores"][r * per_round + nH]))
+    flips = _cmp_tables(pairs, name)
+    if flips == 0 and nH == 1 and nA == 1:
+        np.testing.assert_array_equal(w_iv, g["w_interval"].reshape(-1))
+        np.testing.assert_array_equal(a_iv, g["a_interval"].reshape(-1))
+    else:
+        np.testing.assert_allclose(w_iv, g["w_interval"].reshape(-1), rtol=0.05)
+        np.testing.assert_allclose(a_iv, g["a_interval"].reshape(-1), rtol=0.05)
+
+
+@pytest.mark.parametrize("name", golden_names("matmul_"))
+def test_matmul_vs_reference_golden(eng, name):
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    sos = p.pop("sos")
+    R = p["search_round"]
+    A_iv, B_iv, split, scores, best = eng.matmul_calibrate(
+        A=_t(g["A"]), B=_t(g["B"]), out=_t(g["out"]), grad=_t(g["grad"]), sos=sos, want_scores=True, **p)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    pairs = []
+    for r in range(R):
+        ta, tb = g["scores"][2 * r], g["scores"][2 * r + 1]
+        if sos:
+            pairs.append((scores[r, 0][:20, :1], best[r, 0][:1], ta))
+        else:
+            pairs.append((scores[r, 0], best[r, 0], ta))
+        pairs.append((scores[r, 1], best[r, 1], tb))
+    flips = _cmp_tables(pairs, name)
+    if flips == 0:
+        np.testing.assert_array_equal(B_iv.cpu().numpy(), g["B_interval"].reshape(-1))
+        np.testing.assert_array_equal(A_iv.cpu().numpy(), np.asarray(g["A_interval"]).reshape(-1))
+        if sos:
+            assert float(split.cpu()) == float(g["split"])
+
+
+@pytest.mark.parametrize("name", golden_names("conv_"))
+def test_conv_vs_reference_golden(eng, name):
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    st = p.pop("stride")
+    cw = p.pop("channelwise")
+    R = p["search_round"]
+    w_iv, a_iv, scores, best = eng.conv_calibrate(
+        weight=_t(g["weight"]), bias=_t(g["bias"]), x=_t(g["x"]), out=_t(g["out"]), grad=_t(g["grad"]),
+        stride=(st, st), padding=(0, 0), dilation=(1, 1), channelwise=cw, want_scores=True, **p)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    aq = p["a_bit"] < 32
+    per_round = 2 if aq else 1
+    pairs = []
+    for r in range(R):
+        pairs.append((scores[r, 0], best[r, 0], g["scores"][r * per_round]))
+        if aq:
+            pairs.append((scores[r, 1][:, :1], best[r, 1][:1], g["scores"][r * per_round + 1]))
+    flips = _cmp_tables(pairs, name)
+    if flips == 0:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), np.asarray(g["w_interval"]).reshape(-1))
+        if aq:
+            np.testing.assert_array_equal(a_iv.cpu().numpy(), np.asarray(g["a_interval"]).reshape(-1))
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded multi-tile shapes vs the oracle (ragged M/N/K, several row/column tiles, n_V = 3)
+# ------------------------------------------------------------------------------------------------
+def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((N, K)) * 0.05 * np.linspace(0.5, 2.0, N)[:, None]).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    x = rng.standard_normal((b, T, K)).astype(np.float32)
+    if postgelu:
+        x = torch.nn.functional.gelu(torch.from_numpy(1.5 * x)).numpy()
+    out = (x.reshape(-1, K) @ w.T + bias).reshape(b, T, N).astype(np.float32)
+    grad = (rng.standard_normal(out.shape) * gscale).astype(np.float32)
+    return w, bias, x, out, grad
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
+    dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=6, a_bit=6, metric="hessian", postgelu=False),
+    dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),
+    dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True),
+    dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="cosine", postgelu=False),
+    dict(b=3, T=50, K=96, N=160, n_V=2, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
+], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-nV{c['n_V']}")
+def test_linear_multitile_vs_oracle(eng, cfg):
+    from oracle.ptq4vit_oracle import LinearOracle
+    cfg = dict(cfg)
+    b, T, K, N, postgelu = (cfg.pop(k) for k in ("b", "T", "K", "N", "postgelu"))
+    w, bias, x, out, grad = _mk_linear(7, b, T, K, N, postgelu)
+    hp = dict(eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    o = LinearOracle(w, bias, postgelu=postgelu, **cfg, **hp)
+    o.calibration_step2(x, out, grad)
+    w_iv, a_iv, scores, best = eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad),
+                                                    postgelu=postgelu, n_H=1, n_a=1, want_scores=True, **cfg, **hp)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    pairs = []
+    for r in range(2):
+        pairs.append((scores[r, 0], best[r, 0], o.trace[2 * r][1]))
+        pairs.append((scores[r, 1][:, :1], best[r, 1][:1], o.trace[2 * r + 1][1]))
+    flips = _cmp_tables(pairs, "multitile")
+    if flips == 0:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), o.w_interval.reshape(-1))
+        np.testing.assert_array_equal(a_iv.cpu().numpy(), o.a_interval.reshape(-1))
+
+
+def test_quantize_i8_bit_exact(eng):
+    """Integer planes are bit-exact: clamp(rint(x/s)) with IEEE division and round-half-even."""
+    from oracle.ptq4vit_oracle import quant_int
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((257, 199)).astype(np.float32) * 3
+    # plant exact half-way cases: x = (k + 0.5) * s
+    s = np.array([0.0371, 0.011, 0.5], dtype=np.float32)
+    x[0, :100] = (np.arange(100, dtype=np.float32) - 50 + 0.5) * s[0]
+    q = eng.quantize_i8(_t(x), _t(s), 100, -128, 127).cpu().numpy()
+    ref = quant_int(x, np.repeat(s, 100)[:257, None], -128, 127)
+    np.testing.assert_array_equal(q, ref)
+    q6 = eng.quantize_i8(_t(x), _t(s), 100, -32, 31).cpu().numpy()
+    np.testing.assert_array_equal(q6, quant_int(x, np.repeat(s, 100)[:257, None], -32, 31))
+
+
+def test_determinism_and_f32_cross_check(eng):
+    """Run-to-run bit-identical results; the int8 MFMA path and the fp32 MFMA path pick the same candidates."""
+    w, bias, x, out, grad = _mk_linear(11, 8, 197, 192, 576, gscale=1e-10)
+    hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, n_V=3, n_H=1, n_a=1)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), want_scores=True)
+    r1 = eng.linear_calibrate(**args, **hp)
+    r2 = eng.linear_calibrate(**args, **hp)
+    r3 = eng.linear_calibrate(**args, **hp, force_f32=True)
+    torch.cuda.synchronize()
+    for a, b in zip(r1, r2):
+        assert torch.equal(a, b)
+    s1, s3 = r1[2].cpu().numpy(), r3[2].cpu().numpy()
+    assert_scores_close(s1, s3, rtol=5e-4, what="i8 vs f32 path")
+    for r in range(3):
+        assert_argmax_tie_aware(r1[3][r, 0].cpu().numpy(), s3[r, 0], what="w")
+        assert_argmax_tie_aware(r1[3][r, 1][:1].cpu().numpy(), s3[r, 1][:, :1], what="a")
