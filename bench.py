@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Benchmark of the PTQ4ViT calibration hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+A *step* is one full ``HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4)
+.batching_quant_calib()`` -- the region the reference times (example/test_all.py:31-34) -- on a ViT-B/224 with
+seeded random weights and 32 seeded synthetic images that are resident in HBM before the clock starts.
+value = wrapped modules calibrated per second, whole job (74 modules per step, sharded over the ranks for N > 1).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class SyntheticLoader:
+    """Calib-loader contract of the reference (utils/datasets.py:88-94): ONE batch of `num` images, `.batch_size`."""
+
+    def __init__(self, images):
+        self.images = images
+        self.batch_size = images.shape[0]
+
+    def __iter__(self):
+        yield self.images, torch.zeros(self.images.shape[0], dtype=torch.long)
+
+
+def search_macs(wrapped, calib, tokens, heads, head_dim, eq_n=100, rounds=3):
+    """Algorithmic MACs of the reference's candidate-sweep GEMMs for one calibration."""
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
+    lin = mm = conv = 0.0
+    for name, m in wrapped.items():
+        if isinstance(m, MinMaxQuantLinear):
+            rows = calib * (1 if name == "head" else tokens)
+            lin += rounds * 2 * eq_n * rows * m.in_features * m.out_features
+        elif isinstance(m, MinMaxQuantConv2d):
+            k = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+            conv += rounds * eq_n * calib * (tokens - 1) * k * m.out_channels
+        else:
+            sos = type(m).__name__.startswith("SoS")
+            per = calib * heads * tokens * tokens * head_dim
+            mm += rounds * ((20 + eq_n) if sos else 2 * eq_n) * per
+    return lin, mm, conv
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The numpy oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample:
+    one search round of the ViT-B `proj` layer (32x197x768 -> 768, hessian, eq_n=100), then scaled by
+    algorithmic MACs to the 74-module / 3-round workload."""
+    from oracle.ptq4vit_oracle import LinearOracle
+    rng = np.random.default_rng(0)
+    M, K, N = 32 * 197, 768, 768
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    b = np.zeros(N, np.float32)
+    x = rng.standard_normal((32, 197, K)).astype(np.float32)
+    out = (x.reshape(-1, K) @ w.T + b).reshape(32, 197, N)
+    grad = (rng.standard_normal(out.shape) * 1e-3).astype(np.float32)
+    o = LinearOracle(w, b, w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=1, n_V=1, chunk=20)
+    t = time.time()
+    o.calibration_step2(x, out, grad)
+    dt = time.time() - t
+    return dt, 2.0 * 100 * M * K * N  # seconds, MACs of the sample (w + a search)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="vit_base_patch16_224")
+    ap.add_argument("--calib", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ptq4vit_amd import engine
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+
+    net = models.get_net(args.model, seed=0, device=dev)
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    img = net.patch_embed.proj.kernel_size[0] * int(round((net.pos_embed.shape[1] - 1) ** 0.5))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    images = torch.randn(args.calib, 3, img, img, generator=g).to(dev)
+    loader = SyntheticLoader(images)
+    tokens = net.pos_embed.shape[1]
+    heads = net.blocks[0].attn.num_heads
+    head_dim = net.blocks[0].attn.qkv.in_features // heads
+
+    def one_step():
+        for m in wrapped.values():
+            m.mode = "raw"
+        cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4)
+        cal.batching_quant_calib()
+        return cal
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    import io
+    import contextlib
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    with quiet:
+        for _ in range(args.warmup):
+            one_step()
+        sync()
+        t0 = time.time()
+        cals = [one_step() for _ in range(args.steps)]
+        sync()
+        elapsed = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_mod = len(wrapped)
+    value = n_mod * args.steps / elapsed
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # live HIP-event timing of the dominant kernel (k_sweep<int8>) over one more, untimed-for-value step
+        engine.stats_reset()
+        engine.stats_enable(True)
+        with quiet:
+            one_step() if world == 1 else None
+        torch.cuda.synchronize()
+        st = engine.stats_get()
+        engine.stats_enable(False)
+        if st["sweep_i8_launches"] > 0:
+            lin, mm, conv = search_macs(wrapped, args.calib, tokens, heads, head_dim)
+            algo_ops = 2.0 * (lin + mm)            # ops of the reference GEMMs that run on the int8 sweep
+            issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
+            secs = st["sweep_i8_ms"] * 1e-3
+            peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
+            roof = {"bound": "mfma", "kernel": "k_sweep<int8>", "achieved": algo_ops / secs / 1e12, "peak": peak,
+                    "unit": "TOP/s", "frac": algo_ops / secs / 1e12 / peak, "traffic": None,
+                    "issued": issued_ops / secs / 1e12, "launches": st["sweep_i8_launches"],
+                    "avg_launch_ms": st["sweep_i8_ms"] / st["sweep_i8_launches"],
+                    "f32_sweep_ms": st["sweep_f32_ms"], "f32_sweep_tflops": (2.0 * st["sweep_f32_macs"] / (st["sweep_f32_ms"] * 1e-3) / 1e12) if st["sweep_f32_ms"] else None}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dt, sample_macs = cpu_baseline()
+        lin, mm, conv = search_macs(wrapped, args.calib, tokens, heads, head_dim)
+        est_total = dt * (lin + mm + conv) / sample_macs
+        cpu = {"value": n_mod / est_total, "unit": "layers/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"numpy oracle, ViT-B proj layer 32x197x768->768, 1 search round: {dt:.1f} s; scaled by algorithmic MACs to 74 modules x 3 rounds (search only, no capture)"}
+
+    if rank == 0:
+        t = cals[-1].timings
+        line = {
+            "metric": "calibration throughput (wrapped modules calibrated per second), ViT-B/224 W8A8, 32 calibration images",
+            "value": value, "unit": "layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "calibration_wall_clock_s": elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
+            "data": "synthetic (seeded N(0,1) images, trunc-normal weights)",
+            "config": {"workload": f"{args.model} PTQ4ViT W8A8, {args.calib} calibration images, {n_mod} wrapped modules, "
+                                   "HessianQuantCalibrator.batching_quant_calib (capture + search)",
+                       "global_batch": args.calib, "parallelism": f"layers sharded over {world} GPU(s)"},
+            "breakdown": {"capture_s": t["capture_s"], "search_s": t["search_s"]},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,9 @@ def load():
             f"ptq4vit_amd: HIP extension {LIB_PATH} is missing -- build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the calibration path.")
+    # torch ships its own libamdhip64 (same soname as /opt/rocm's).  Import torch FIRST so that this library
+    # binds to the HIP runtime torch already initialised: two runtimes in one process cannot both own the GPU.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p
     lib.p4v_version.restype = C.c_int

@@ -438,7 +438,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             ps.scores_out = scores_out ? scores_out + ((long)(round * 2 + 0) * d->eq_n) * nV : nullptr;
             ps.scores_out_ld = nV;
             ps.best_out = best_out ? best_out + (long)(round * 2 + 0) * nV : nullptr;
-            if (scores_out && nH > 1 && h > 0) ps.scores_out = nullptr;  // table of the first column block only
+            if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
             if (!cosm) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
                 ps.row = x_operand(false, a_iv, 0);
@@ -457,7 +457,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.row = w_operand(true, wc, wc_cs, true);
                 ps.col = x_operand(false, a_iv, 0);
                 ps.col_zs_shared = 1;
-                ps.use_s1 = true; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
+                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
                 ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
                 ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
                 ps.O = O; ps.G = nullptr; ps.o_zs = crb_rows; ps.o_bs = 0; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
@@ -503,7 +503,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.row = w_operand(false, w_iv, 0, true);
                 ps.col = x_operand(true, ac, nA);
                 ps.col_zs_shared = 1;
-                ps.use_s1 = true; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
+                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
                 ps.s1 = ScaleParams{a_cands, 1, 0, 0.f, w_iv, 0, 1, 0.f, 0, 0, nullptr};
                 ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
                 ps.O = O; ps.o_zs = crb_rows; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
@@ -719,7 +719,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
         ps.i8 = false; ps.twin = false; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
         ps.use_s1 = false; ps.s_cs = 1; ps.sb_mode = 0;
         ps.O = O; ps.G = G; ps.bias = bias;
-        Operand xo = x_operand(!w_search, a_cands, 1, cosm && d->channelwise);
+        Operand xo = x_operand(!w_search, w_search ? a_iv : a_cands, w_search ? 0 : 1, cosm && d->channelwise);
         Operand wo = w_operand(w_search, w_search ? w_cands : w_iv, w_search ? nw : 0);
         if (!cosm) {
             // rows = (image, pixel), cols = oc;  out[b][oc][l]

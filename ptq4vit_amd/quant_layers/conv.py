@@ -1,0 +1,168 @@
+"""Quantised Conv2d modules (patch embedding) -- API mirror of the reference's quant_layers/conv.py.
+
+Hot classes (reference conv.py:279-614): ChannelwiseBatchingQuantConv2d (PTQ4ViT config, one interval per
+output channel) and BatchingEasyQuantConv2d (BasePTQ config, one interval per layer).
+``calibration_step2()`` calls ``p4v_conv_calibrate`` (include/ptq4vit_hip.h).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine
+from ._common import calib_parameters, dispatch, fake_quant
+
+
+class MinMaxQuantConv2d(nn.Conv2d):
+    """Reference conv.py:9-89."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, dilation=1,
+                 groups: int = 1, bias: bool = True, padding_mode: str = "zeros", mode="raw", w_bit=8, a_bit=8,
+                 bias_bit=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+        assert bias_bit is None, "No support bias bit now"
+        self.n_calibration_steps = 2
+        self.mode = mode
+        self.w_bit, self.a_bit, self.bias_bit = w_bit, a_bit, bias_bit
+        self.w_interval = None
+        self.a_interval = None
+        self.bias_interval = None
+        self.raw_input = None
+        self.raw_out = None
+        self.metric = None
+        self.next_nodes = []
+        self.w_qmax = 2 ** (w_bit - 1)
+        self.a_qmax = 2 ** (a_bit - 1)
+
+    def forward(self, x):
+        return dispatch(self, x)
+
+    def _conv(self, x, w, b):
+        return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+
+    def raw_forward(self, x):
+        return self._conv(x, self.weight, self.bias)
+
+    def quant_weight_bias(self):
+        return fake_quant(self.weight, self.w_interval, -self.w_qmax, self.w_qmax - 1), self.bias
+
+    def quant_input(self, x):
+        return fake_quant(x, self.a_interval, -self.a_qmax, self.a_qmax - 1)
+
+    def quant_forward(self, x):
+        assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        w_sim, bias_sim = self.quant_weight_bias()
+        return self._conv(self.quant_input(x), w_sim, bias_sim)
+
+    def calibration_step1(self, x):
+        out = self.raw_forward(x)
+        self.raw_input, self.raw_out = x.detach(), out.detach()
+        return out
+
+    def calibration_step2(self, x):
+        self.w_interval = (self.weight.data.abs().max() / (self.w_qmax - 0.5)).detach()
+        self.a_interval = (x.abs().max() / (self.a_qmax - 0.5)).detach()
+        self.calibrated = True
+        return self.quant_forward(x)
+
+
+class PTQSLQuantConv2d(MinMaxQuantConv2d):
+    """Constructor surface of reference conv.py:126-277 (base of the two batching classes).  Its own
+    sub-layerwise search is not selected by any shipped config and is not implemented."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, dilation=1,
+                 groups: int = 1, bias: bool = True, padding_mode: str = "zeros", mode="raw", w_bit=8, a_bit=8,
+                 bias_bit=None, metric="L2_norm", search_round=1, eq_alpha=0.1, eq_beta=2, eq_n=100,
+                 parallel_eq_n=10, n_V=1, n_H=1, init_layerwise=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                         groups=groups, bias=bias, padding_mode=padding_mode, mode=mode, w_bit=w_bit, a_bit=a_bit,
+                         bias_bit=bias_bit)
+        self.metric = metric
+        self.search_round = search_round
+        self.eq_alpha, self.eq_beta, self.eq_n = eq_alpha, eq_beta, eq_n
+        self.parallel_eq_n = parallel_eq_n
+        self.n_H, self.n_V = n_H, n_V
+        self.init_layerwise = init_layerwise
+        self.raw_grad = None
+
+    def calibration_step2(self, x):
+        raise NotImplementedError("PTQSLQuantConv2d's own search is unused by the shipped configs; "
+                                  "use ChannelwiseBatchingQuantConv2d / BatchingEasyQuantConv2d")
+
+
+class _BatchingConv(PTQSLQuantConv2d):
+    _channelwise = True
+
+    def _initialize_calib_parameters(self):
+        """Reference conv.py:467-480 (15 GiB budget); attribute parity only."""
+        self.calib_size = int(self.raw_input.shape[0])
+        numel = 2 * (self.raw_input.numel() + self.raw_out.numel())
+        self.calib_batch_size, self.parallel_eq_n, self.calib_need_batching = calib_parameters(numel, self.calib_size, 15)
+
+    def quant_weight_bias(self):
+        return fake_quant(self.weight, self.w_interval, -self.w_qmax, self.w_qmax - 1), self.bias
+
+    def quant_forward(self, x):
+        assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        w_sim, bias_sim = self.quant_weight_bias()
+        x_sim = self.quant_input(x) if self.a_bit < 32 else x
+        return self._conv(x_sim, w_sim, bias_sim)
+
+    def calibration_step2(self):
+        """p4v_conv_calibrate: replaces conv.py:591-603 / :429-441."""
+        if self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("ptq4vit_amd: grouped / non-zero-padded convolutions are not implemented on the GPU")
+        if self.metric == "hessian":
+            assert self.raw_grad is not None, "raw_grad is None in _get_similarity!"
+        self._initialize_calib_parameters()
+        w_iv, a_iv, _, _ = engine.conv_calibrate(
+            weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=self.raw_input,
+            out=self.raw_out, grad=self.raw_grad if self.metric == "hessian" else None, stride=self.stride,
+            padding=self.padding, dilation=self.dilation, w_bit=self.w_bit, a_bit=self.a_bit, metric=self.metric,
+            eq_alpha=self.eq_alpha, eq_beta=self.eq_beta, eq_n=self.eq_n, search_round=self.search_round,
+            channelwise=self._channelwise, init_layerwise=self.init_layerwise)
+        self.w_interval = w_iv.view(-1, 1, 1, 1) if self._channelwise else w_iv.reshape(1, 1, 1, 1)
+        self.a_interval = a_iv if self.a_bit >= 32 else a_iv.reshape(())
+        self.calibrated = True
+        del self.raw_input, self.raw_out, self.raw_grad
+
+
+class BatchingEasyQuantConv2d(_BatchingConv):
+    """Reference conv.py:279-441: layer-wise EasyQuant (BasePTQ config)."""
+
+    _channelwise = False
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_V = 1
+        self.n_H = 1
+
+
+class ChannelwiseBatchingQuantConv2d(_BatchingConv):
+    """Reference conv.py:444-614: one weight interval per output channel (PTQ4ViT config)."""
+
+    _channelwise = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_V = self.out_channels
+        self.n_H = 1
+
+
+class QuantileQuantConv2d(MinMaxQuantConv2d):
+    """Reference conv.py:91-124 (quantile instead of max for the min-max init; unused by the shipped configs)."""
+
+    def __init__(self, *args, w_quantile=0.9999, a_quantile=0.9999, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.w_quantile, self.a_quantile = w_quantile, a_quantile
+
+    def _quantile(self, tensor, quantile):
+        if tensor.numel() >= 16777216:
+            n = tensor.numel() // 16777216
+            return torch.quantile(tensor.view(-1)[: 16777216 * n].view(n, 16777216), quantile, 1).mean()
+        return torch.quantile(tensor, quantile)
+
+    def calibration_step2(self, x):
+        self.w_interval = (self._quantile(self.weight.data.abs(), self.w_quantile) / (self.w_qmax - 0.5)).detach()
+        self.a_interval = (self._quantile(x.abs(), self.a_quantile) / (self.a_qmax - 0.5)).detach()
+        self.calibrated = True
+        return self.quant_forward(x)

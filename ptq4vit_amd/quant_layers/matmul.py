@@ -1,0 +1,190 @@
+"""Quantised MatMul modules (q.k^T and attn.v) -- API mirror of the reference's quant_layers/matmul.py.
+
+Hot classes (reference matmul.py:390-644): PTQSLBatchingQuantMatMul (head-wise intervals) and
+SoSPTQSLBatchingQuantMatMul (split-of-softmax twin on A).  ``calibration_step2()`` calls
+``p4v_matmul_calibrate`` (include/ptq4vit_hip.h).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import engine
+from ._common import dispatch, fake_quant
+
+
+class MinMaxQuantMatMul(nn.Module):
+    """Reference matmul.py:8-60."""
+
+    def __init__(self, A_bit=8, B_bit=8, mode="raw"):
+        super().__init__()
+        self.A_bit, self.B_bit = A_bit, B_bit
+        self.A_interval = None
+        self.B_interval = None
+        self.A_qmax = 2 ** (A_bit - 1)
+        self.B_qmax = 2 ** (B_bit - 1)
+        self.mode = mode
+        self.raw_input = None
+        self.raw_out = None
+
+    def forward(self, A, B):
+        return dispatch(self, A, B)
+
+    def raw_forward(self, A, B):
+        return A @ B
+
+    def quant_input(self, x, interval, qmax):
+        return fake_quant(x, interval, -qmax, qmax - 1)
+
+    def quant_forward(self, A, B):
+        assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        return self.quant_input(A, self.A_interval, self.A_qmax) @ self.quant_input(B, self.B_interval, self.B_qmax)
+
+    def calibration_step1(self, A, B):
+        self.raw_input = A.detach(), B.detach()
+        out = A @ B
+        self.raw_out = out.detach()
+        return out
+
+    def calibration_step2(self, A, B):
+        self.A_interval = (A.data.abs().max() / (self.A_qmax - 0.5)).detach()
+        self.B_interval = (B.data.abs().max() / (self.B_qmax - 0.5)).detach()
+        self.calibrated = True
+        return self.quant_forward(A, B)
+
+
+class PTQSLQuantMatMul(MinMaxQuantMatMul):
+    """Reference matmul.py:62-282: operands viewed as (n_G, n_V, n_H) blocks with zero padding;
+    interval shape (1, n_G, 1, n_V, 1, n_H, 1)."""
+
+    _sos = False
+
+    def __init__(self, A_bit=8, B_bit=8, mode="raw", metric="L2_norm", search_round=1, eq_alpha=0.1, eq_beta=2,
+                 eq_n=100, parallel_eq_n=10, n_G_A=1, n_V_A=1, n_H_A=1, n_G_B=1, n_V_B=1, n_H_B=1,
+                 init_layerwise=False):
+        super().__init__(A_bit=A_bit, B_bit=B_bit, mode=mode)
+        self.metric = metric
+        self.search_round = search_round
+        self.eq_alpha, self.eq_beta, self.eq_n = eq_alpha, eq_beta, eq_n
+        self.parallel_eq_n = parallel_eq_n
+        self.n_G_A, self.n_V_A, self.n_H_A = n_G_A, n_V_A, n_H_A
+        self.n_G_B, self.n_V_B, self.n_H_B = n_G_B, n_V_B, n_H_B
+        for s in "AB":
+            for what in ("crb_groups", "crb_rows", "crb_cols", "pad_groups", "pad_rows", "pad_cols"):
+                setattr(self, f"{what}_{s}", None)
+        self.raw_grad = None
+        self.init_layerwise = init_layerwise
+
+    def _get_padding_parameters(self, A, B):
+        """Reference matmul.py:109-122."""
+        for s, X in (("A", A), ("B", B)):
+            n = [getattr(self, f"n_{k}_{s}") for k in "GVH"]
+            crb = [(X.shape[i + 1] + n[i] - 1) // n[i] for i in range(3)]
+            for name, c, ni, dim in zip(("groups", "rows", "cols"), crb, n, X.shape[1:]):
+                setattr(self, f"crb_{name}_{s}", c)
+                setattr(self, f"pad_{name}_{s}", c * ni - dim)
+
+    def _quant_blocked(self, x, s, interval, qmax):
+        """Reference matmul.py:124-138."""
+        pg, pr, pc = (getattr(self, f"pad_{k}_{s}") for k in ("groups", "rows", "cols"))
+        nG, nV, nH = (getattr(self, f"n_{k}_{s}") for k in "GVH")
+        cg, cr, cc = (getattr(self, f"crb_{k}_{s}") for k in ("groups", "rows", "cols"))
+        xp = F.pad(x, [0, pc, 0, pr, 0, pg]).view(-1, nG, cg, nV, cr, nH, cc)
+        xq = fake_quant(xp, interval, -qmax, qmax - 1).view(-1, nG * cg, nV * cr, nH * cc)
+        return xq[:, : xq.shape[1] - pg, : xq.shape[2] - pr, : xq.shape[3] - pc]
+
+    def quant_input_A(self, x):
+        return self._quant_blocked(x, "A", self.A_interval, self.A_qmax)
+
+    def quant_input_B(self, x):
+        return self._quant_blocked(x, "B", self.B_interval, self.B_qmax)
+
+    def quant_forward(self, A, B):
+        assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        return self.quant_input_A(A) @ self.quant_input_B(B)
+
+    # ---- the GPU search --------------------------------------------------------------------------
+    def _search_on_gpu(self, A, B, raw_out, raw_grad):
+        """p4v_matmul_calibrate: replaces matmul.py:565-576 / :633-644.  The engine searches one interval per
+        head (the Batching classes force n_G = heads, matmul.py:411-417) with n_V = n_H = 1."""
+        if self.metric == "hessian":
+            assert raw_grad is not None, "No raw_grad in PTQSLBatchingQuantMatMul!"
+        if (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) != (1, 1, 1, 1):
+            raise NotImplementedError("ptq4vit_amd: MatMul row/column sub-blocks (n_V, n_H > 1) are not implemented on the GPU")
+        H = A.shape[1]
+        self.n_G_A, self.n_G_B = H, H   # head-wise (matmul.py:415-416; also overrides the SoS constructor's n_G_A = 1)
+        self._get_padding_parameters(A, B)
+        A_iv, B_iv, split, _, _ = engine.matmul_calibrate(
+            A=A, B=B, out=raw_out, grad=raw_grad if self.metric == "hessian" else None, A_bit=self.A_bit,
+            B_bit=self.B_bit, metric=self.metric, eq_alpha=self.eq_alpha, eq_beta=self.eq_beta, eq_n=self.eq_n,
+            search_round=self.search_round, sos=self._sos, init_layerwise=self.init_layerwise)
+        self.B_interval = B_iv.view(1, H, 1, 1, 1, 1, 1)
+        if self._sos:
+            self.split = split.reshape(())
+            self.A_interval = A_iv.reshape(())
+        else:
+            self.A_interval = A_iv.view(1, H, 1, 1, 1, 1, 1)
+
+    def calibration_step2(self, A, B):
+        self._search_on_gpu(A, B, self.raw_out, self.raw_grad)
+        self.calibrated = True
+        del self.raw_input, self.raw_out, self.raw_grad
+        dev = self.B_interval.device
+        return self.quant_forward(A.to(dev), B.to(dev))
+
+
+class SoSPTQSLQuantMatMul(PTQSLQuantMatMul):
+    """Reference matmul.py:284-388: split-of-softmax twin quantiser on the score matrix A."""
+
+    _sos = True
+
+    def __init__(self, *args, split=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_G_A = self.n_V_A = self.n_H_A = 1
+        self.A_qmax = 2 ** (self.A_bit - 1)
+        self.split = split
+        if split is not None:
+            self.A_interval = self.split / (self.A_qmax - 1)
+
+    def quant_input_A(self, x):
+        q1 = self.A_qmax - 1
+        x_high = torch.clamp(torch.round(x.clamp(self.split, 1) * q1), 0, q1) / q1
+        x_low = torch.clamp(torch.round(x.clamp(0, self.split) / self.A_interval), 0, q1) * self.A_interval
+        return x_high + x_low
+
+
+class PTQSLBatchingQuantMatMul(PTQSLQuantMatMul):
+    """Reference matmul.py:390-576."""
+
+    def _initialize_calib_parameters(self):
+        from ._common import calib_parameters
+        self.calib_size = int(self.raw_input[0].shape[0])
+        numel = self.raw_input[0].numel() + self.raw_input[1].numel() + 2 * self.raw_out.numel()
+        self.calib_batch_size, self.parallel_eq_n, self.calib_need_batching = calib_parameters(numel, self.calib_size)
+
+    def calibration_step2(self):
+        self._initialize_calib_parameters()
+        self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
+        self.calibrated = True
+        del self.raw_input, self.raw_out, self.raw_grad
+
+
+class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
+    """Reference matmul.py:578-644."""
+
+    _sos = True
+
+    def __init__(self, *args, split=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_G_A = self.n_V_A = self.n_H_A = 1
+        self.A_qmax = 2 ** (self.A_bit - 1)
+        self.split = split
+        if split is not None:
+            self.A_interval = self.split / (self.A_qmax - 1)
+
+    quant_input_A = SoSPTQSLQuantMatMul.quant_input_A
+
+    def calibration_step2(self):
+        # the reference keeps raw_input / raw_out / raw_grad alive on this class (matmul.py:633-644 has no `del`)
+        self._initialize_calib_parameters()
+        self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
+        self.calibrated = True

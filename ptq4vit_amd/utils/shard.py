@@ -1,0 +1,128 @@
+"""Layer sharding over the GPUs of one node + the final interval exchange.
+
+With ``sequential=False`` every module's step 2 depends only on its own cached tensors, so modules are
+independent units: longest-processing-time assignment by search FLOPs, no data-path collective, and ONE
+all-gather of a fixed-layout fp32 interval vector at the end (a few KB: latency-bound, so xGMI bandwidth
+does not matter).  The reference has no collective communication at all; this is the
+multi-GPU design BASELINE.json asks for.
+"""
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+def rank_world():
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def module_cost(module):
+    """Relative search time of one module.  Linears: MACs per token of one candidate GEMM (K*N).  The patch
+    embedding runs fp32-operand MFMA (~1/16 of the int8 rate).  Attention matmuls are small and epilogue-bound;
+    their cost is set from the measured ViT-B breakdown (profiles/): about a proj-sized linear."""
+    w = getattr(module, "weight", None)
+    if w is None:
+        return 0.6e6
+    if w.dim() == 4:
+        return float(w.numel()) * 4.0
+    return float(w.numel())
+
+
+def assign_modules(wrapped_modules, world, costs=None):
+    """LPT: heaviest module first onto the currently lightest rank.  Deterministic -> identical on every rank."""
+    names = list(wrapped_modules)
+    if costs is None:
+        costs = {n: module_cost(wrapped_modules[n]) for n in names}
+    order = sorted(names, key=lambda n: (-costs[n], names.index(n)))
+    load = [0.0] * world
+    owner = {}
+    for n in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        owner[n] = r
+        load[r] += costs[n]
+    return owner
+
+
+INTERVAL_ATTRS = ("w_interval", "a_interval", "A_interval", "B_interval", "split")
+
+
+def _pack(module):
+    vals, meta = [], []
+    for a in INTERVAL_ATTRS:
+        v = getattr(module, a, None)
+        if v is None:
+            continue
+        if isinstance(v, (list, tuple)):  # non-batching post-GELU class keeps [tensor, float]
+            v = v[0]
+        t = torch.as_tensor(v, dtype=torch.float32).detach().reshape(-1)
+        vals.append(t)
+        meta.append((a, tuple(torch.as_tensor(v).shape)))
+    return vals, meta
+
+
+def exchange_intervals(wrapped_modules, owner):
+    """All ranks end up with every module's calibrated intervals.  Two tiny collectives: the per-module slot
+    sizes (all_reduce MAX) so that the layout is fixed, then one all_gather of the interval vector."""
+    rank, world = rank_world()
+    names = list(wrapped_modules)
+    dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
+    # slot sizes: 5 attrs x up to 4 dims per module, encoded as ints (0 = absent)
+    shape_tab = torch.zeros(len(names), len(INTERVAL_ATTRS), 5, dtype=torch.int64, device=dev)
+    packed = {}
+    for i, n in enumerate(names):
+        if owner[n] != rank:
+            continue
+        vals, meta = _pack(wrapped_modules[n])
+        packed[n] = vals
+        for (a, shp) in meta:
+            j = INTERVAL_ATTRS.index(a)
+            shape_tab[i, j, 0] = 1 + len(shp)
+            for k, s in enumerate(shp[:4]):
+                shape_tab[i, j, 1 + k] = s
+    dist.all_reduce(shape_tab, op=dist.ReduceOp.MAX)
+    shape_tab = shape_tab.cpu()
+    offsets, total = {}, 0
+    for i, n in enumerate(names):
+        for j, a in enumerate(INTERVAL_ATTRS):
+            nd = int(shape_tab[i, j, 0])
+            if nd == 0:
+                continue
+            shp = tuple(int(s) for s in shape_tab[i, j, 1:nd])
+            numel = 1
+            for s in shp:
+                numel *= s
+            offsets[(n, a)] = (total, numel, shp)
+            total += numel
+    vec = torch.zeros(total, dtype=torch.float32, device=dev)
+    for n, vals in packed.items():
+        k = 0
+        for a in INTERVAL_ATTRS:
+            if (n, a) in offsets and getattr(wrapped_modules[n], a, None) is not None:
+                off, numel, _ = offsets[(n, a)]
+                vec[off:off + numel] = vals[k].to(dev)
+                k += 1
+    gathered = torch.empty(world, total, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(gathered, vec)
+    for n in names:
+        r = owner[n]
+        if r == rank:
+            continue
+        m = wrapped_modules[n]
+        mdev = next((p.device for p in m.parameters()), dev) if hasattr(m, "parameters") else dev
+        for a in INTERVAL_ATTRS:
+            if (n, a) not in offsets:
+                continue
+            off, numel, shp = offsets[(n, a)]
+            setattr(m, a, gathered[r, off:off + numel].reshape(shp).to(mdev).clone())
+        m.calibrated = True
+        for cache in ("raw_input", "raw_out", "raw_grad"):
+            if hasattr(m, cache) and not type(m).__name__.startswith("SoS"):
+                try:
+                    delattr(m, cache)
+                except AttributeError:
+                    pass
+    return total
