@@ -166,8 +166,8 @@ class HessianQuantCalibrator(QuantCalibrator):
         for n in names:
             m = self.wrapped_modules[n]
             m.raw_input = m.raw_out = None
-            if hasattr(m, "raw_grad"):
-                m.raw_grad = None
+            if hasattr(m, "metric"):
+                m.raw_grad = None   # step 2 deletes the caches (reference linear.py:554): re-create for re-calibration
             hooks += _register(m, with_grad and hasattr(m, "metric"))
         for inp, _ in self.calib_loader:
             total = inp.shape[0]
