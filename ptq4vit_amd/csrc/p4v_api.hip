@@ -73,6 +73,7 @@ std::mutex g_stat_mu;
 bool g_stat_on = false;
 std::vector<StatRec> g_stat_recs;
 p4v_kernel_stats g_stats = {};
+bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
 
 struct Ctx {
     hipStream_t st;
@@ -149,7 +150,31 @@ template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams&
     return 0;
 }
 
-int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi) {
+template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)SW2_NS * (TWIN ? 3 : 2) * SW2_TILE + (size_t)per * 8 * sizeof(float) * (TWIN ? 3 : 2);
+    dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
+#define P4V_LAUNCH2(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false; /* benign race: the attribute is idempotent */                           \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep2<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep2<TWIN, E>), grid, block, lds, c.st, p);                                    \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH2(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH2(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH2(EPI_ABS); break;
+        default: P4V_LAUNCH2(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH2
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
     bool timed;
     StatRec rec{};
@@ -166,7 +191,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi) {
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
-    if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi) : launch_sweep_epi<int8_t, false>(c, p, epi);
+    if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
+    else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi) : launch_sweep_epi<int8_t, false>(c, p, epi);
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi) : launch_sweep_epi<float, false>(c, p, epi);
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
@@ -254,7 +280,12 @@ int run_pass(Ctx& c, Pass& ps) {
     char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk : 1));
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
-    const long p_zs = (long)MT * Np * (cosm ? 3 : 1);
+    // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
+    const bool fast = ps.i8 && !cosm && !(g_force_v1) &&
+                      (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
+                      (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
+    const int NpP = fast ? Np / 32 : Np;          // columns of the partial-sum table
+    const long p_zs = (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
@@ -306,12 +337,18 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.o_inner = ps.o_inner > 0 ? ps.o_inner : INT_MAX;
         sp.o_ninner = ps.o_ninner > 0 ? ps.o_ninner : INT_MAX;
         sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc;
-        sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = Np;
+        sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = NpP;
         sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
-        CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi));
+        int cgroups = 1;
+        if (fast) {
+            const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
+            cgroups = (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs));
+        }
+        CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
     if (!cosm) {
-        FinishParams fp{part, p_cs, p_zs, Np, MT, ps.Z, ps.Ncols, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores};
+        FinishParams fp{part, p_cs, p_zs, NpP, MT, ps.Z, fast ? cdiv(ps.Ncols, 32) : ps.Ncols, ps.eq_n, ps.j_mode,
+                        std::max(1, fast && ps.j_mode == 1 ? cdiv(ps.j_div, 32) : ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));
     } else {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
@@ -854,7 +891,8 @@ int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_
 
 int p4v_stats_enable(int enable) {
     std::lock_guard<std::mutex> lk(g_stat_mu);
-    g_stat_on = enable != 0;
+    g_stat_on = (enable & 1) != 0;
+    g_force_v1 = (enable & 2) != 0;   // bit 1: A/B switch, generic sweep kernel only
     return 0;
 }
 

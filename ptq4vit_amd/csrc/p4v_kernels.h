@@ -494,6 +494,177 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sweep2: the fast int8 candidate sweep (linear layers and attention matmuls, element-wise metrics)
+// ------------------------------------------------------------------------------------------
+// Same contract as k_sweep<int8_t,...> but built for the MI355X memory system:
+//   * operand k-tiles (128 rows x 64 B) stream HBM/L2 -> LDS with direct-to-LDS loads
+//     (global_load_lds_dwordx4: no VGPR staging), SW2_NS tiles deep, waited with counted vmcnt, so
+//     the L2/HBM latency of tile t+3 hides under the MFMAs of tile t; the loop runs flat over
+//     (candidate, k-tile) so the pipeline never drains between candidates;
+//   * the LDS image is lane-linear (a requirement of LDS-DMA), so the 16-byte chunks of a row are
+//     XOR-swizzled on the SOURCE address and on the ds_read_b128 address (conflict-free reads);
+//   * every wave's 32 columns lie inside one scale / score block (checked by the host), so scales are
+//     scalar loads (lgkmcnt, never vmcnt) and the per-candidate result is ONE float per wave, kept in LDS
+//     and written once at the end: no vector-memory traffic besides the operand stream inside the loop.
+static constexpr int SW2_NS = 4;
+static constexpr int SW2_TILE = 128 * 64;   // bytes of one operand k-tile
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = TWIN ? 3 : 2;
+    constexpr int STAGE = NPL * SW2_TILE;
+    // tail of the LDS image: per-(candidate, wave) results and the scale tables (ONE __shared__ object: a
+    // second one makes hipcc drain vmcnt(0) before every ds_read of an LDS-DMA pipeline)
+    float* res = reinterpret_cast<float*>(smem + SW2_NS * STAGE);   // [per][8 waves]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 5, l31 = lane & 31;
+
+    // tile order: workgroups that share the tile of the candidate-EXPANDED operand are adjacent (same XCD L2)
+    const int nwg = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    int mt, nt;
+    if (p.a_cs != 0) { nt = t % p.ntiles; mt = t / p.ntiles; } else { mt = t % p.mtiles; nt = t / p.mtiles; }
+    const int z = blockIdx.y;
+    const int m0 = mt * SW_BM, n0 = nt * SW_BN;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+
+    // ---- candidate-invariant epilogue operands (identical to k_sweep) -----------------------------
+    float u[2][16], w[2][16];
+    const int n = n0 + wc * 32 + l31;
+    const bool ncol_ok = n < p.N;
+    const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
+    const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float ov = 0.0f, wv = 0.0f;
+            if (ncol_ok && m < p.M) {
+                const long idx = (long)z * p.o_zs + (long)(m / p.o_inner) * p.o_bs + (long)(m % p.o_inner) * p.o_ms +
+                                 (long)(n / p.o_ninner) * p.o_nbs + (long)(n % p.o_ninner) * p.o_ns;
+                const float o = p.O[idx];
+                ov = o - bias_n;
+                wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+            }
+            u[i][r] = ov;
+            w[i][r] = wv;
+        }
+    // wave-uniform scale block of this wave's 32 columns (host guarantees they share one block)
+    const int nw0 = n0 + wc * 32;
+    const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
+    // scales of this wave's block for every candidate of this workgroup -> LDS (ordinary loads must not appear
+    // inside the LDS-DMA loop: hipcc would wait vmcnt(0) for them and drain the prefetch ring)
+    float* s1tab = res + per * 8;
+    float* s2tab = s1tab + per * 8;
+    for (int i = lane; i < c_hi - c_lo; i += 64) {
+        s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+        if (TWIN) s2tab[i * 8 + wid] = p.S2 ? p.S2[(c_lo + i) * p.s_cs + sb] : 1.0f;
+    }
+
+    // ---- LDS-DMA addressing: wave `wid` fills rows [16*wid, 16*wid+16) of every plane ------------------
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);          // logical 16-B chunk landing in physical slot lane&3
+    const char* gA = (const char*)p.A + (long)z * p.a_zs + (long)(m0 + ld_row) * p.ldk + ld_chunk * 16;
+    const char* gA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)(m0 + ld_row) * p.ldk + ld_chunk * 16 : nullptr;
+    const char* gB = (const char*)p.B + (long)z * p.b_zs + (long)(n0 + ld_row) * p.ldk + ld_chunk * 16;
+    const int lds_wave = wid * 1024;
+
+    const int ktiles = p.ktiles;
+    const int total = (c_hi - c_lo) * ktiles;
+    int ic = c_lo, ikt = 0;   // (candidate, k-tile) of the next tile to issue
+    auto issue = [&](int stage) {
+        char* s = smem + stage * STAGE + lds_wave;
+        glds16(gA + (long)ic * p.a_cs + ikt * SW_BKB, s);
+        if (TWIN) glds16(gA2 + (long)ic * p.a2_cs + ikt * SW_BKB, s + SW2_TILE);
+        glds16(gB + (long)ic * p.b_cs + ikt * SW_BKB, s + (NPL - 1) * SW2_TILE);
+        if (++ikt == ktiles) { ikt = 0; ++ic; }
+    };
+
+    v16i acc[2], acc2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0; if (TWIN) acc2[i][r] = 0; }
+
+    // swizzled fragment addresses: row R, logical chunk c -> physical chunk c ^ ((R>>2)&3)
+    const int ra0 = wr * 64 + l31, ra1 = ra0 + 32, rb = wc * 32 + l31;
+    const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sbz = (rb >> 2) & 3;
+
+    const int npre = min(SW2_NS - 1, total);
+    for (int i = 0; i < npre; ++i) issue(i);
+
+    int kt = 0, c = c_lo;
+    for (int it = 0; it < total; ++it) {
+        // tile `it` has landed once at most min(NS-2, tiles issued after it) load groups are outstanding
+        const int after = min(SW2_NS - 2, total - 1 - it);
+        if (after >= 2) wait_vmcnt<2 * NPL>(); else if (after == 1) wait_vmcnt<NPL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile `it` are in LDS; everyone is done reading stage (it-1)%NS
+        if (it + SW2_NS - 1 < total) issue((it + SW2_NS - 1) % SW2_NS);
+        const char* s = smem + (it % SW2_NS) * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cl = 2 * h + g;
+            const v4i b = *reinterpret_cast<const v4i*>(s + (NPL - 1) * SW2_TILE + rb * 64 + ((cl ^ sbz) << 4));
+            const v4i a0 = *reinterpret_cast<const v4i*>(s + ra0 * 64 + ((cl ^ sa0) << 4));
+            const v4i a1 = *reinterpret_cast<const v4i*>(s + ra1 * 64 + ((cl ^ sa1) << 4));
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc[1], 0, 0, 0);
+            if (TWIN) {
+                const v4i c0 = *reinterpret_cast<const v4i*>(s + SW2_TILE + ra0 * 64 + ((cl ^ sa0) << 4));
+                const v4i c1 = *reinterpret_cast<const v4i*>(s + SW2_TILE + ra1 * 64 + ((cl ^ sa1) << 4));
+                acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c0, b, acc2[0], 0, 0, 0);
+                acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c1, b, acc2[1], 0, 0, 0);
+            }
+        }
+        if (++kt == ktiles) {
+            // ---- fused similarity epilogue of candidate c: one float per wave -----------------------------
+            const float s1 = s1tab[(c - c_lo) * 8 + wid];
+            const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + wid] : 1.0f;
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float o_sim = (float)acc[i][r] * s1;
+                    if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                    const float d = u[i][r] - o_sim;
+                    if (EPI == EPI_SQ_W) { const float tt = w[i][r] * d; sum = fmaf(tt, tt, sum); }
+                    else if (EPI == EPI_SQ) sum = fmaf(d, d, sum);
+                    else if (EPI == EPI_ABS) sum += fabsf(d);
+                    else sum = fmaf(w[i][r] * d, d, sum);
+                    acc[i][r] = 0;
+                    if (TWIN) acc2[i][r] = 0;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);   // fixed butterfly: deterministic
+            if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
+            kt = 0;
+            ++c;
+        }
+    }
+    __syncthreads();
+    // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
+    for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
+        const int cc = c_lo + i / 8, wv = i % 8;
+        p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_finish / k_select
 // ------------------------------------------------------------------------------------------
 struct FinishParams {

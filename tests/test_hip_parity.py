@@ -142,12 +142,16 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
 
 @pytest.mark.parametrize("cfg", [
     dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
+    dict(b=5, T=61, K=200, N=384, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),   # fast sweep (32-aligned blocks)
+    dict(b=4, T=70, K=330, N=200, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),    # fast sweep, twin, ragged N
+    dict(b=4, T=70, K=330, N=256, n_V=2, w_bit=6, a_bit=6, metric="L1_norm", postgelu=False),
+    dict(b=4, T=70, K=330, N=256, n_V=2, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=False),
     dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=6, a_bit=6, metric="hessian", postgelu=False),
     dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),
     dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True),
     dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="cosine", postgelu=False),
     dict(b=3, T=50, K=96, N=160, n_V=2, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
-], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-nV{c['n_V']}")
+], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
     cfg = dict(cfg)
@@ -201,3 +205,20 @@ def test_determinism_and_f32_cross_check(eng):
     for r in range(3):
         assert_argmax_tie_aware(r1[3][r, 0].cpu().numpy(), s3[r, 0], what="w")
         assert_argmax_tie_aware(r1[3][r, 1][:1].cpu().numpy(), s3[r, 1][:, :1], what="a")
+
+
+def test_fast_sweep_matches_generic_sweep(eng):
+    """A/B: k_sweep2 (LDS-DMA ring, one float per wave) vs the generic k_sweep on the same launch sequence."""
+    w, bias, x, out, grad = _mk_linear(13, 6, 197, 384, 768, gscale=1e-3)
+    hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, n_V=3, n_H=1, n_a=1)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), want_scores=True)
+    fast = eng.linear_calibrate(**args, **hp)
+    eng.stats_enable(2)
+    try:
+        slow = eng.linear_calibrate(**args, **hp)
+    finally:
+        eng.stats_enable(0)
+    torch.cuda.synchronize()
+    assert_scores_close(fast[2].cpu().numpy(), slow[2].cpu().numpy(), rtol=1e-5, what="fast vs generic")
+    assert torch.equal(fast[3], slow[3])
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
