@@ -73,6 +73,7 @@ std::mutex g_stat_mu;
 bool g_stat_on = false;
 std::vector<StatRec> g_stat_recs;
 p4v_kernel_stats g_stats = {};
+int g_variant = 0;         // tuning A/B switches (bit 0: two k-tiles per barrier in k_sweep2)
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
 
 struct Ctx {
@@ -131,7 +132,7 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
     if (c.dry) return 0;
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
     const int blocks = (int)std::min<long>(cdiv(total, 256), 256L * 64);
-    hipLaunchKernelGGL(k_pack<T>, dim3(blocks), dim3(256), 0, c.st, p);
+    hipLaunchKernelGGL(k_pack<T>, dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -171,6 +172,50 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
     }
 #undef P4V_LAUNCH2
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep3(Ctx& c, const Sweep3Params& p, int epi, int cgroups, double algo_macs) {
+    if (c.dry) return 0;
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW3_NS * SW3_TT + (size_t)per * 8 * sizeof(float) * 2;
+    dim3 grid(p.stiles * p.ttiles, 1, cgroups), block(512);
+    bool timed;
+    StatRec rec{};
+    {
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        timed = g_stat_on;
+    }
+    if (timed) {
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        rec.kind = 0;
+        rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 256 * (double)p.ldk * (p.c1 - p.c0);
+        (void)algo_macs;
+        HIPCHK(hipEventRecord(rec.a, c.st));
+    }
+#define P4V_LAUNCH3(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep3<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep3<E>), grid, block, lds, c.st, p);                                          \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH3(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH3(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH3(EPI_ABS); break;
+        default: P4V_LAUNCH3(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH3
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        g_stat_recs.push_back(rec);
+    }
     return 0;
 }
 
@@ -267,7 +312,14 @@ static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane
 int run_pass(Ctx& c, Pass& ps) {
     const int esz = ps.i8 ? 1 : 4;
     const int Kp = (int)rup(ps.K, 64 / esz);          // 64-byte k-tiles
-    const int Mp = (int)rup(ps.Mrows, SW_BM), Np = (int)rup(ps.Ncols, SW_BN);
+    // stationary-operand sweep (k_sweep3): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
+    const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
+                          (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 64 == 0)));
+    const bool stat_ok = ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
+                         ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
+                         rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
+    const int PADR = stat_ok ? 256 : SW_BM;
+    const int Mp = (int)rup(ps.Mrows, PADR), Np = (int)rup(ps.Ncols, PADR);
     const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
     const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
     const long col_plane1 = ps.col_zs_shared ? (long)Np * Kp * esz : col_plane;
@@ -281,11 +333,14 @@ int run_pass(Ctx& c, Pass& ps) {
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
-    const bool fast = ps.i8 && !cosm && !(g_force_v1) &&
+    const bool fast = !stat_ok && ps.i8 && !cosm && !(g_force_v1) &&
                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
-    const int NpP = fast ? Np / 32 : Np;          // columns of the partial-sum table
-    const long p_zs = (long)MT * NpP * (cosm ? 3 : 1);
+    // k_sweep3 table: [slabs of 64 stationary rows][groups of 64 streaming rows]
+    const bool a_search = ps.row.expanded;          // stationary = weights (col operand), streaming = activations
+    const int s3_slabs = (a_search ? Np : Mp) / 64, s3_groups = (a_search ? Mp : Np) / 64;
+    const int NpP = stat_ok ? s3_groups : fast ? Np / 32 : Np;          // columns of the partial-sum table
+    const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
@@ -316,6 +371,26 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
+        if (stat_ok) {
+            Sweep3Params q{};
+            const long tplane = a_search ? row_plane1 : col_plane1;
+            q.S = a_search ? colbuf : rowbuf; q.s_zs = 0;
+            q.T = (a_search ? rowbuf : colbuf) - (long)c0 * tplane; q.t_cs = tplane; q.t_zs = 0;
+            q.ldk = Kp; q.ktiles = Kp / SW_BKB;
+            q.S1 = S1; q.s_cs = ps.s_cs; q.sb_on_t = a_search ? 0 : 1; q.sb_div = std::max(1, ps.sb_div);
+            q.bias = ps.bias; q.bias_on_t = a_search ? 0 : 1;
+            q.O = ps.O; q.Wt = ps.G; q.wt_mode = ps.wt_mode;
+            q.o_ss = a_search ? ps.o_ns : ps.o_ms; q.o_ts = a_search ? ps.o_ms : ps.o_ns;
+            q.SR = a_search ? ps.Ncols : ps.Mrows; q.TR = a_search ? ps.Mrows : ps.Ncols;
+            q.c0 = c0; q.c1 = c0 + nc;
+            q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
+            q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 256;
+            q.dbg = g_variant & 3;
+            const long wgs = (long)q.stiles * q.ttiles;
+            const int cgroups = (int)std::max<long>(1, std::min<long>(std::min(nc, 20), (1536 + wgs - 1) / wgs));
+            CHK(launch_sweep3(c, q, ps.epi, cgroups, 0.0));
+            continue;
+        }
         SweepParams sp{};
         // plane pointers are biased so that the kernel can index them with the absolute candidate id
         sp.a_cs = ps.row.expanded ? row_plane1 : 0;
@@ -339,6 +414,7 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc;
         sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = NpP;
         sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
+        sp.dbg = g_variant & 3;
         int cgroups = 1;
         if (fast) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
@@ -347,8 +423,11 @@ int run_pass(Ctx& c, Pass& ps) {
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
     if (!cosm) {
-        FinishParams fp{part, p_cs, p_zs, NpP, MT, ps.Z, fast ? cdiv(ps.Ncols, 32) : ps.Ncols, ps.eq_n, ps.j_mode,
-                        std::max(1, fast && ps.j_mode == 1 ? cdiv(ps.j_div, 32) : ps.j_div), ps.nj, ps.norm, scores};
+        const int gdiv = stat_ok ? 64 : 32;
+        // k_sweep3 activation search (j_mode 0) sums the whole table; its columns are sample groups
+        const int fin_cols = stat_ok ? (a_search ? s3_groups : cdiv(ps.Ncols, 64)) : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
+        FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
+                        std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));
     } else {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
@@ -893,6 +972,7 @@ int p4v_stats_enable(int enable) {
     std::lock_guard<std::mutex> lk(g_stat_mu);
     g_stat_on = (enable & 1) != 0;
     g_force_v1 = (enable & 2) != 0;   // bit 1: A/B switch, generic sweep kernel only
+    g_variant = (enable >> 2);        // bits 2..: kernel tuning variants
     return 0;
 }
 

@@ -198,12 +198,17 @@ __device__ __forceinline__ int pack_blk(const PackParams& p, int z, int r, int k
     return 0;
 }
 
-// One thread owns 16 consecutive k of one (z, r) and loops over the candidates, so the source is
-// read once per pass and every store is a full 16-byte (int8) / 64-byte (fp32) run.
+// One thread owns 16 consecutive k of one (z, r) for a group of PACK_CG candidates (blockIdx.y): the source
+// (L2 / Infinity-Cache resident: it is re-read once per candidate group) is loaded once per group, the scales
+// are loaded up front, and every plane is written as one contiguous stream of full 16-byte (int8) /
+// 64-byte (fp32) runs -- a pure streaming-write kernel.
+static constexpr int PACK_CG = 4;
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack(PackParams p) {
     const long kchunks = p.Kp / 16;
     const long total = (long)p.Z * p.Rp * kchunks;
+    const int cbeg = blockIdx.y * PACK_CG, cend = min(p.C, cbeg + PACK_CG);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int kc = (int)(i % kchunks);
         const int r = (int)((i / kchunks) % p.Rp);
@@ -220,10 +225,17 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         }
         const int blk0 = pack_blk(p, z, r, 0);
         const bool live = (r < p.R);
-        for (int c = 0; c < p.C; ++c) {
+        float sc[PACK_CG];
+#pragma unroll
+        for (int j = 0; j < PACK_CG; ++j)
+            sc[j] = (p.scales && cbeg + j < cend) ? p.scales[(cbeg + j) * p.sc_cs + blk0] : p.neg_scale;
+#pragma unroll
+        for (int j = 0; j < PACK_CG; ++j) {
+            const int c = cbeg + j;
+            if (c >= cend) break;
             const long o = (((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16;
             if constexpr (sizeof(T) == 1) {
-                const float s = p.scales ? p.scales[c * p.sc_cs + blk0] : p.neg_scale;
+                const float s = sc[j];
                 int w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kk = kc * 16 + q * 4 + e;
-                        const float s = p.scales ? p.scales[c * p.sc_cs + (per_k_blk ? blk[q * 4 + e] : blk0)] : 1.0f;
+                        const float s = !p.scales ? 1.0f : per_k_blk ? p.scales[c * p.sc_cs + blk[q * 4 + e]] : sc[j];
                         v[e] = (live && kk < p.K) ? pack_value_f32(p, x[q * 4 + e], s) : 0.0f;
                     }
                     *reinterpret_cast<v4f*>(d + q * 4) = v;
@@ -299,6 +311,7 @@ struct SweepParams {
     long p_cs, p_zs;                   // element strides of `part`
     int Np;
     int mtiles, ntiles;
+    int dbg;                           // tuning experiments only (0 in production): 1 = no operand loads, 2 = no MFMA
 };
 
 static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
@@ -517,7 +530,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool TWIN, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
+__global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = TWIN ? 3 : 2;
     constexpr int STAGE = NPL * SW2_TILE;
@@ -576,22 +589,27 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     }
 
     // ---- LDS-DMA addressing: wave `wid` fills rows [16*wid, 16*wid+16) of every plane ------------------
+    // global address = wave-uniform 64-bit cursor (SGPRs, advanced with scalar adds) + per-lane 32-bit offset
     const int ld_row = wid * 16 + (lane >> 2);
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);          // logical 16-B chunk landing in physical slot lane&3
-    const char* gA = (const char*)p.A + (long)z * p.a_zs + (long)(m0 + ld_row) * p.ldk + ld_chunk * 16;
-    const char* gA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)(m0 + ld_row) * p.ldk + ld_chunk * 16 : nullptr;
-    const char* gB = (const char*)p.B + (long)z * p.b_zs + (long)(n0 + ld_row) * p.ldk + ld_chunk * 16;
-    const int lds_wave = wid * 1024;
-
+    const unsigned voffA = (unsigned)(ld_row * p.ldk + ld_chunk * 16);
+    const char* curA = (const char*)p.A + (long)z * p.a_zs + (long)m0 * p.ldk + (long)c_lo * p.a_cs;
+    const char* curA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)m0 * p.ldk + (long)c_lo * p.a2_cs : nullptr;
+    const char* curB = (const char*)p.B + (long)z * p.b_zs + (long)n0 * p.ldk + (long)c_lo * p.b_cs;
     const int ktiles = p.ktiles;
+    const long wrapA = p.a_cs - (long)ktiles * SW_BKB, wrapA2 = TWIN ? p.a2_cs - (long)ktiles * SW_BKB : 0,
+               wrapB = p.b_cs - (long)ktiles * SW_BKB;   // cursor jump at the end of a candidate
+    const int lds_wave = wid * 1024;
     const int total = (c_hi - c_lo) * ktiles;
-    int ic = c_lo, ikt = 0;   // (candidate, k-tile) of the next tile to issue
+    int ikt = 0;   // k-tile of the next tile to issue
     auto issue = [&](int stage) {
         char* s = smem + stage * STAGE + lds_wave;
-        glds16(gA + (long)ic * p.a_cs + ikt * SW_BKB, s);
-        if (TWIN) glds16(gA2 + (long)ic * p.a2_cs + ikt * SW_BKB, s + SW2_TILE);
-        glds16(gB + (long)ic * p.b_cs + ikt * SW_BKB, s + (NPL - 1) * SW2_TILE);
-        if (++ikt == ktiles) { ikt = 0; ++ic; }
+        glds16(curA + voffA, s);
+        if (TWIN) glds16(curA2 + voffA, s + SW2_TILE);
+        glds16(curB + voffA, s + (NPL - 1) * SW2_TILE);
+        curA += SW_BKB; curB += SW_BKB;
+        if (TWIN) curA2 += SW_BKB;
+        if (++ikt == ktiles) { ikt = 0; curA += wrapA; curB += wrapB; if (TWIN) curA2 += wrapA2; }
     };
 
     v16i acc[2], acc2[2];
@@ -600,38 +618,58 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0; if (TWIN) acc2[i][r] = 0; }
 
-    // swizzled fragment addresses: row R, logical chunk c -> physical chunk c ^ ((R>>2)&3)
+    // swizzled fragment addresses (per lane, stage-independent): row R, logical chunk c -> physical chunk c ^ ((R>>2)&3)
     const int ra0 = wr * 64 + l31, ra1 = ra0 + 32, rb = wc * 32 + l31;
     const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sbz = (rb >> 2) & 3;
+    const char* fA0 = smem + ra0 * 64;            // + ((chunk ^ sa0) << 4)
+    const char* fA1 = smem + ra1 * 64;
+    const char* fB = smem + (NPL - 1) * SW2_TILE + rb * 64;
+    const int oa00 = (g ^ sa0) << 4, oa01 = ((2 + g) ^ sa0) << 4;
+    const int oa10 = (g ^ sa1) << 4, oa11 = ((2 + g) ^ sa1) << 4;
+    const int ob0 = (g ^ sbz) << 4, ob1 = ((2 + g) ^ sbz) << 4;
 
     const int npre = min(SW2_NS - 1, total);
     for (int i = 0; i < npre; ++i) issue(i);
 
     int kt = 0, c = c_lo;
-    for (int it = 0; it < total; ++it) {
-        // tile `it` has landed once at most min(NS-2, tiles issued after it) load groups are outstanding
-        const int after = min(SW2_NS - 2, total - 1 - it);
-        if (after >= 2) wait_vmcnt<2 * NPL>(); else if (after == 1) wait_vmcnt<NPL>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile `it` are in LDS; everyone is done reading stage (it-1)%NS
-        if (it + SW2_NS - 1 < total) issue((it + SW2_NS - 1) % SW2_NS);
-        const char* s = smem + (it % SW2_NS) * STAGE;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cl = 2 * h + g;
-            const v4i b = *reinterpret_cast<const v4i*>(s + (NPL - 1) * SW2_TILE + rb * 64 + ((cl ^ sbz) << 4));
-            const v4i a0 = *reinterpret_cast<const v4i*>(s + ra0 * 64 + ((cl ^ sa0) << 4));
-            const v4i a1 = *reinterpret_cast<const v4i*>(s + ra1 * 64 + ((cl ^ sa1) << 4));
-            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc[1], 0, 0, 0);
-            if (TWIN) {
-                const v4i c0 = *reinterpret_cast<const v4i*>(s + SW2_TILE + ra0 * 64 + ((cl ^ sa0) << 4));
-                const v4i c1 = *reinterpret_cast<const v4i*>(s + SW2_TILE + ra1 * 64 + ((cl ^ sa1) << 4));
-                acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c0, b, acc2[0], 0, 0, 0);
-                acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c1, b, acc2[1], 0, 0, 0);
-            }
+    // one k-tile with a COMPILE-TIME stage: every LDS address is a VGPR base + immediate offset
+    auto tile = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr int SO = ST * STAGE;
+        if (it + 2 < total) wait_vmcnt<2 * NPL>(); else if (it + 1 < total) wait_vmcnt<NPL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // tile `it` is in LDS for everyone; stage (it-1)%NS is free for everyone
+        if (it + SW2_NS - 1 < total && !(p.dbg & 1)) issue((ST + SW2_NS - 1) % SW2_NS);
+        if (p.dbg & 2) { if (++kt == ktiles) { kt = 0; ++c; } return; }
+        const v4i b0 = *reinterpret_cast<const v4i*>(fB + SO + ob0);
+        const v4i a00 = *reinterpret_cast<const v4i*>(fA0 + SO + oa00);
+        const v4i a10 = *reinterpret_cast<const v4i*>(fA1 + SO + oa10);
+        const v4i b1 = *reinterpret_cast<const v4i*>(fB + SO + ob1);
+        const v4i a01 = *reinterpret_cast<const v4i*>(fA0 + SO + oa01);
+        const v4i a11 = *reinterpret_cast<const v4i*>(fA1 + SO + oa11);
+        v4i c00, c10, c01, c11;
+        if (TWIN) {
+            c00 = *reinterpret_cast<const v4i*>(fA0 + SO + SW2_TILE + oa00);
+            c10 = *reinterpret_cast<const v4i*>(fA1 + SO + SW2_TILE + oa10);
+            c01 = *reinterpret_cast<const v4i*>(fA0 + SO + SW2_TILE + oa01);
+            c11 = *reinterpret_cast<const v4i*>(fA1 + SO + SW2_TILE + oa11);
         }
+        // keep the fragment reads ahead of the MFMAs (the scheduler otherwise re-serialises read->wait->mfma)
+        __builtin_amdgcn_sched_group_barrier(0x100, TWIN ? 10 : 6, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a00, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, b0, acc[1], 0, 0, 0);
+        if (TWIN) {
+            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c00, b0, acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c10, b0, acc2[1], 0, 0, 0);
+        }
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01, b1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
+        if (TWIN) {
+            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c01, b1, acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c11, b1, acc2[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, TWIN ? 8 : 4, 0);
         if (++kt == ktiles) {
-            // ---- fused similarity epilogue of candidate c: one float per wave -----------------------------
+            // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             const float s1 = s1tab[(c - c_lo) * 8 + wid];
             const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + wid] : 1.0f;
             float sum = 0.0f;
@@ -655,12 +693,202 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
             kt = 0;
             ++c;
         }
+    };
+    for (int it = 0; it < total; it += SW2_NS) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{});
+        if (it + 3 < total) tile(it + 3, std::integral_constant<int, 3>{});
     }
     __syncthreads();
     // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep3: int8 sweep with the candidate-INVARIANT operand stationary in LDS (Linear layers, K <= 768)
+// ------------------------------------------------------------------------------------------
+// The candidate-invariant operand (activations in the weight search, weights in the activation search) is
+// re-used by all ~100 candidates.  k_sweep2 re-streams its 128 x K tile from L2 for every candidate; here the
+// whole tile (K/64 k-tiles of 8 KB, <= 96 KB) is loaded into LDS ONCE per workgroup and only the
+// candidate-expanded operand streams through a 3-stage LDS-DMA ring.  Tile = 128 stationary rows x 256
+// streaming rows, 8 waves as 2 x 4, 64 x 64 per wave (2 x 2 MFMA 32x32x32): half the L2->LDS bytes per MAC and
+// two thirds of the LDS reads per MFMA of k_sweep2, at one workgroup (8 waves, ~240 VGPRs) per CU.
+// The MFMA rows are the stationary rows: in the activation search the output tile is therefore transposed
+// (rows = output features, columns = samples); the raw_out / raw_grad tile is gathered through strides.
+struct Sweep3Params {
+    const void* S; long s_zs;           // stationary plane [rows_p][ldk] (never candidate-expanded)
+    const void* T; long t_cs, t_zs;     // streaming plane  [C][rows_p][ldk]
+    int ldk, ktiles;
+    const float* S1;                    // [C][s_cs] combined scales
+    int s_cs, sb_on_t, sb_div;          // scale block = (stationary or streaming row) / sb_div
+    const float* bias; int bias_on_t;   // bias indexed by the streaming (1) or stationary (0) row
+    const float* O; const float* Wt; int wt_mode;
+    long o_ss, o_ts;                    // element index = srow * o_ss + trow * o_ts
+    int SR, TR;                         // valid stationary / streaming rows
+    int c0, c1;
+    float* part; long p_cs; int NG;     // part[c*p_cs + (st*2+wr)*NG + tt*4+wc]
+    int stiles, ttiles;
+    int dbg;
+};
+
+static constexpr int SW3_NS = 3;
+static constexpr int SW3_TT = 256 * 64;  // bytes of one streaming k-tile
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ktiles = p.ktiles;
+    char* ring = smem + ktiles * SW2_TILE;
+    float* res = reinterpret_cast<float*>(ring + SW3_NS * SW3_TT);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.stiles * p.ttiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
+    const int s0 = st * 128, t0 = tt * 256;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+
+    // ---- stationary operand: all k-tiles of this workgroup's 128 rows, once ------------------------------
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    {
+        const char* gS = (const char*)p.S + (long)(s0 + ld_row) * p.ldk + ld_chunk * 16;
+        for (int kt = 0; kt < ktiles; ++kt) glds16(gS + kt * SW_BKB, smem + kt * SW2_TILE + wid * 1024);
+    }
+    // ---- streaming operand cursor: wave `wid` fills rows [32*wid, 32*wid+32) of a stage (2 pieces) ---------
+    const unsigned voffT0 = (unsigned)((wid * 32 + (lane >> 2)) * p.ldk + (((lane & 3) ^ (((wid * 32 + (lane >> 2)) >> 2) & 3)) << 4));
+    const unsigned voffT1 = (unsigned)((wid * 32 + 16 + (lane >> 2)) * p.ldk + (((lane & 3) ^ (((wid * 32 + 16 + (lane >> 2)) >> 2) & 3)) << 4));
+    const char* curT = (const char*)p.T + (long)t0 * p.ldk + (long)c_lo * p.t_cs;
+    const long wrapT = p.t_cs - (long)ktiles * SW_BKB;
+    const int total = (c_hi - c_lo) * ktiles;
+    int ikt = 0;
+    auto issue = [&](int stage) {
+        char* sdst = ring + stage * SW3_TT + wid * 2048;
+        glds16(curT + voffT0, sdst);
+        glds16(curT + voffT1, sdst + 1024);
+        curT += SW_BKB;
+        if (++ikt == ktiles) { ikt = 0; curT += wrapT; }
+    };
+    const int npre = min(SW3_NS - 1, total);
+    for (int i = 0; i < npre; ++i) issue(i);
+
+    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 ------------------------------
+    // C/D layout: col = lane&31 (streaming row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (stationary row)
+    float u[2][2][16], w[2][2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tr = t0 + wc * 64 + j * 32 + l31;
+        const bool t_ok = tr < p.TR;
+        const float bias_t = (p.bias && p.bias_on_t && t_ok) ? p.bias[tr] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sr = s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float ov = 0.0f, wv = 0.0f;
+                if (t_ok && sr < p.SR) {
+                    const long idx = (long)sr * p.o_ss + (long)tr * p.o_ts;
+                    const float o = p.O[idx];
+                    const float b = p.bias ? (p.bias_on_t ? bias_t : p.bias[sr]) : 0.0f;
+                    ov = o - b;
+                    wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+                }
+                u[i][j][r] = ov;
+                w[i][j][r] = wv;
+            }
+    }
+    const int blk_row = p.sb_on_t ? (t0 + wc * 64) : (s0 + wr * 64);
+    const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
+    float* s1tab = res + per * 8;
+    for (int i = lane; i < c_hi - c_lo; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    // fragment addresses: stationary rows (runtime k-tile offset added per tile), streaming rows (immediate stage offsets)
+    const int rs0 = wr * 64 + l31, rs1 = rs0 + 32, rt0 = wc * 64 + l31, rt1 = rt0 + 32;
+    const int ss0 = (rs0 >> 2) & 3, ss1 = (rs1 >> 2) & 3, st0 = (rt0 >> 2) & 3, st1 = (rt1 >> 2) & 3;
+    const int aS00 = rs0 * 64 + ((g ^ ss0) << 4), aS01 = rs0 * 64 + (((2 + g) ^ ss0) << 4);
+    const int aS10 = rs1 * 64 + ((g ^ ss1) << 4), aS11 = rs1 * 64 + (((2 + g) ^ ss1) << 4);
+    const char* fT00 = ring + rt0 * 64 + ((g ^ st0) << 4);
+    const char* fT01 = ring + rt0 * 64 + (((2 + g) ^ st0) << 4);
+    const char* fT10 = ring + rt1 * 64 + ((g ^ st1) << 4);
+    const char* fT11 = ring + rt1 * 64 + (((2 + g) ^ st1) << 4);
+
+    int kt = 0, c = c_lo;
+    auto tile = [&](int it, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr int SO = ST * SW3_TT;
+        if (it + 1 < total) wait_vmcnt<2>(); else wait_vmcnt<0>();   // ring depth 3: one tile (2 pieces) may stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (it + SW3_NS - 1 < total && !(p.dbg & 1)) issue((ST + SW3_NS - 1) % SW3_NS);
+        if (p.dbg & 2) { if (++kt == ktiles) { kt = 0; ++c; } return; }
+        const char* sk = smem + kt * SW2_TILE;
+        const v4i s00 = *reinterpret_cast<const v4i*>(sk + aS00);
+        const v4i s10 = *reinterpret_cast<const v4i*>(sk + aS10);
+        const v4i t00 = *reinterpret_cast<const v4i*>(fT00 + SO);
+        const v4i t10 = *reinterpret_cast<const v4i*>(fT10 + SO);
+        const v4i s01 = *reinterpret_cast<const v4i*>(sk + aS01);
+        const v4i s11 = *reinterpret_cast<const v4i*>(sk + aS11);
+        const v4i t01 = *reinterpret_cast<const v4i*>(fT01 + SO);
+        const v4i t11 = *reinterpret_cast<const v4i*>(fT11 + SO);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t00, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t00, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t10, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t10, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s01, t01, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t01, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s01, t11, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t11, acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+        if (++kt == ktiles) {
+            const float s1 = s1tab[(c - c_lo) * 8 + wid];
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = u[i][j][r] - (float)acc[i][j][r] * s1;
+                        if (EPI == EPI_SQ_W) { const float tt2 = w[i][j][r] * d; sum = fmaf(tt2, tt2, sum); }
+                        else if (EPI == EPI_SQ) sum = fmaf(d, d, sum);
+                        else if (EPI == EPI_ABS) sum += fabsf(d);
+                        else sum = fmaf(w[i][j][r] * d, d, sum);
+                        acc[i][j][r] = 0;
+                    }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
+            kt = 0;
+            ++c;
+        }
+    };
+    for (int it = 0; it < total; it += SW3_NS) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{});
+    }
+    __syncthreads();
+    for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
+        const int cc = c_lo + i / 8, wv = i % 8;
+        p.part[(long)cc * p.p_cs + (long)(st * 2 + (wv >> 2)) * p.NG + tt * 4 + (wv & 3)] = res[i];
     }
 }
 

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one module's calibration on synthetic ViT-B shaped tensors (for rocprofv3 / tuning).
+
+    python tools/bench_layer.py --layer fc1 --rounds 1 --reps 3
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ptq4vit_amd import engine  # noqa: E402
+
+SHAPES = {  # name: (K, N, n_V, postgelu)
+    "qkv": (768, 2304, 3, False), "proj": (768, 768, 1, False), "fc1": (768, 3072, 1, False),
+    "fc2": (3072, 768, 1, True), "head": (768, 1000, 1, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layer", default="fc1")
+    ap.add_argument("--rounds", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=197)
+    ap.add_argument("--bits", type=int, default=8)
+    ap.add_argument("--variant", type=int, default=0, help="bits 1.. of p4v_stats_enable (kernel A/B switches)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
+    if a.variant:
+        engine.stats_enable(a.variant << 2)
+    if a.layer in SHAPES:
+        K, N, nV, gelu = SHAPES[a.layer]
+        x = torch.randn(a.batch, a.tokens, K, generator=g)
+        if gelu:
+            x = torch.nn.functional.gelu(1.5 * x)
+        w = torch.randn(N, K, generator=g) * 0.02
+        b = torch.randn(N, generator=g) * 0.02
+        x, w, b = x.to(dev), w.to(dev), b.to(dev)
+        out = torch.nn.functional.linear(x, w, b)
+        grad = (torch.randn(out.shape, generator=g) * 1e-3).to(dev)
+        run = lambda: engine.linear_calibrate(weight=w, bias=b, x=x, out=out, grad=grad, w_bit=a.bits, a_bit=a.bits,
+                                              n_V=nV, n_H=1, n_a=1, postgelu=gelu, **hp)
+        macs = 2.0 * 100 * a.rounds * a.batch * a.tokens * K * N
+    elif a.layer in ("qk", "sv"):
+        H, D, S = 12, 64, a.tokens
+        if a.layer == "qk":
+            A = torch.randn(a.batch, H, S, D, generator=g).to(dev)
+            B = torch.randn(a.batch, H, S, D, generator=g).to(dev).transpose(-2, -1)
+        else:
+            A = torch.softmax(torch.randn(a.batch, H, S, S, generator=g) * 2, -1).to(dev)
+            B = torch.randn(a.batch, H, S, D, generator=g).to(dev)
+        out = A @ B
+        grad = (torch.randn(out.shape, generator=g) * 1e-3).to(dev)
+        run = lambda: engine.matmul_calibrate(A=A, B=B, out=out, grad=grad, A_bit=a.bits, B_bit=a.bits,
+                                              sos=(a.layer == "sv"), **hp)
+        macs = (2.0 if a.layer == "qk" else 1.2) * 100 * a.rounds * a.batch * H * S * S * D
+    else:
+        raise SystemExit("unknown layer")
+    run()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(a.reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / a.reps
+    print(f"{a.layer}: {dt * 1e3:.2f} ms per calibration ({a.rounds} round(s)); {2 * macs / dt / 1e12:.1f} TOP/s algorithmic incl. pack/finish")
+
+
+if __name__ == "__main__":
+    main()
