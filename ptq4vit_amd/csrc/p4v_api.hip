@@ -346,8 +346,10 @@ int run_pass(Ctx& c, Pass& ps) {
     float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
     float* S2 = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
     float* scores = c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
+    float* zero_bias = (stat_ok && !ps.bias) ? c.ws.get<float>((size_t)std::max(Mp, Np)) : nullptr;
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
 
+    if (zero_bias && !c.dry) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
     if (ps.use_s1) {
         ps.s1.S = S1; ps.s1.C = ps.eq_n; ps.s1.nblk = ps.s_cs;
         CHK(launch_scale(c, ps.s1));
@@ -378,14 +380,14 @@ int run_pass(Ctx& c, Pass& ps) {
             q.T = (a_search ? rowbuf : colbuf) - (long)c0 * tplane; q.t_cs = tplane; q.t_zs = 0;
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.s_cs = ps.s_cs; q.sb_on_t = a_search ? 0 : 1; q.sb_div = std::max(1, ps.sb_div);
-            q.bias = ps.bias; q.bias_on_t = a_search ? 0 : 1;
-            q.O = ps.O; q.Wt = ps.G; q.wt_mode = ps.wt_mode;
+            q.bias = ps.bias ? ps.bias : zero_bias; q.bias_on_t = a_search ? 0 : 1;
+            q.O = ps.O; q.Wt = ps.G ? ps.G : ps.O; q.wt_mode = ps.wt_mode;
             q.o_ss = a_search ? ps.o_ns : ps.o_ms; q.o_ts = a_search ? ps.o_ms : ps.o_ns;
             q.SR = a_search ? ps.Ncols : ps.Mrows; q.TR = a_search ? ps.Mrows : ps.Ncols;
             q.c0 = c0; q.c1 = c0 + nc;
             q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
             q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 256;
-            q.dbg = g_variant & 3;
+            q.dbg = (g_variant & 3) | ((g_variant >> 3) << 2);
             const long wgs = (long)q.stiles * q.ttiles;
             const int cgroups = (int)std::max<long>(1, std::min<long>(std::min(nc, 20), (1536 + wgs - 1) / wgs));
             CHK(launch_sweep3(c, q, ps.epi, cgroups, 0.0));
@@ -407,7 +409,7 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.ldk = Kp * esz; sp.ktiles = sp.ldk / SW_BKB;
         sp.S1 = S1; sp.S2 = S2; sp.s_cs = ps.s_cs; sp.sb_mode = ps.sb_mode; sp.sb_div = std::max(1, ps.sb_div);
         sp.bias = ps.bias; sp.bias_axis = ps.bias_axis; sp.bias_zs = ps.bias_zs;
-        sp.O = ps.O; sp.Wt = ps.G; sp.wt_mode = ps.wt_mode;
+        sp.O = ps.O; sp.Wt = ps.G ? ps.G : ps.O; sp.wt_mode = ps.wt_mode;
         sp.o_zs = ps.o_zs; sp.o_bs = ps.o_bs; sp.o_ms = ps.o_ms; sp.o_nbs = ps.o_nbs; sp.o_ns = ps.o_ns;
         sp.o_inner = ps.o_inner > 0 ? ps.o_inner : INT_MAX;
         sp.o_ninner = ps.o_ninner > 0 ? ps.o_ninner : INT_MAX;

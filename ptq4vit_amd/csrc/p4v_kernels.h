@@ -20,6 +20,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
 // block abs-max (reference linear.py:385,395; matmul.py:435-436; conv.py:487,494)
@@ -198,6 +199,16 @@ __device__ __forceinline__ int pack_blk(const PackParams& p, int z, int r, int k
     return 0;
 }
 
+// Exact clamp(rint(x / s)) without a division per element: t = x * (1/s) differs from the correctly rounded
+// quotient by < 2 ulp, so rint(t) can only differ when t sits within 2^-12 of a half-integer (or would
+// saturate anyway).  Such elements are flagged and redone with the IEEE division (about 1 element in 2000).
+__device__ __forceinline__ float quant_fast(float x, float r, float lo, float hi, bool& redo) {
+    const float t = x * r;
+    const float n = rintf(t);
+    redo = (fabsf(t - n) > 0.49975586f) && (fabsf(t) < 256.0f);
+    return fminf(fmaxf(n, lo), hi);
+}
+
 // One thread owns 16 consecutive k of one (z, r) for a group of PACK_CG candidates (blockIdx.y): the source
 // (L2 / Infinity-Cache resident: it is re-read once per candidate group) is loaded once per group, the scales
 // are loaded up front, and every plane is written as one contiguous stream of full 16-byte (int8) /
@@ -237,16 +248,41 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
             if constexpr (sizeof(T) == 1) {
                 const float s = sc[j];
                 int w[4];
+                if (p.mode == PACK_SYM && live && kc * 16 + 16 <= p.K) {
+                    // hot path: symmetric grid, no padding inside this 16-element run
+                    const float rcp = 1.0f / s, flo = (float)p.lo, fhi = (float)p.hi;
+                    float qv[16];
+                    unsigned bad = (rcp < 3.0e38f) ? 0u : 0xffffu;   // 1/s overflowed: take the division for every element
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int acc = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kk = kc * 16 + q * 4 + e;
-                        float v = (live && kk < p.K) ? pack_value(p, x[q * 4 + e], s) : 0.0f;
-                        acc |= ((int)v & 0xff) << (8 * e);
+                    for (int e = 0; e < 16; ++e) {
+                        bool redo;
+                        qv[e] = quant_fast(x[e], rcp, flo, fhi, redo);
+                        bad |= redo ? (1u << e) : 0u;
                     }
-                    w[q] = acc;
+                    if (__any(bad != 0)) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (bad & (1u << e)) qv[e] = fminf(fmaxf(rintf(x[e] / s), flo), fhi);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int b0 = (int)qv[q * 4], b1 = (int)qv[q * 4 + 1], b2 = (int)qv[q * 4 + 2], b3 = (int)qv[q * 4 + 3];
+                        const unsigned lo16 = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u);
+                        const unsigned hi16 = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u);
+                        w[q] = (int)(lo16 | (hi16 << 16));
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int acc = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kk = kc * 16 + q * 4 + e;
+                            float v = (live && kk < p.K) ? pack_value(p, x[q * 4 + e], s) : 0.0f;
+                            acc |= ((int)v & 0xff) << (8 * e);
+                        }
+                        w[q] = acc;
+                    }
                 }
                 *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + o) = v4i{w[0], w[1], w[2], w[3]};
             } else {
@@ -352,24 +388,47 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const bool ncol_ok = n < p.N;
     const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
     const float bias_n = (biasz && ncol_ok && p.bias_axis == 0) ? biasz[n] : 0.0f;
+    {
+        // Phase 1: every load of the raw_out / weight tile issued back to back at clamped (always valid) addresses.
+        // (A load inside a per-element branch costs one dependent memory round trip per element.)
+        const int nc = min(n, p.N - 1);
+        const long ncol_off = (long)z * p.o_zs + (long)(nc / p.o_ninner) * p.o_nbs + (long)(nc % p.o_ninner) * p.o_ns;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            float ov = 0.0f, wv = 0.0f;
-            if (ncol_ok && m < p.M) {
-                const long idx = (long)z * p.o_zs + (long)(m / p.o_inner) * p.o_bs + (long)(m % p.o_inner) * p.o_ms +
-                                 (long)(n / p.o_ninner) * p.o_nbs + (long)(n % p.o_ninner) * p.o_ns;
-                const float o = p.O[idx];
-                ov = o - bias_n;
-                wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
-                // cosine keeps the raw output and carries the bias (0 on padding rows) in w
-                if (EPI == EPI_COS) { ov = o; wv = biasz ? (p.bias_axis ? biasz[m] : bias_n) : 0.0f; }
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.M - 1);
+                const long idx = ncol_off + (long)(mc / p.o_inner) * p.o_bs + (long)(mc % p.o_inner) * p.o_ms;
+                u[i][r] = p.O[idx];
+                w[i][r] = p.Wt[idx];   // host passes Wt = O when the metric has no weight tensor
             }
-            u[i][r] = ov;
-            w[i][r] = wv;
+        // Phase 2: pure ALU; the metric switch is hoisted out of the element loops
+        const int wm = EPI == EPI_COS ? 4 : p.wt_mode;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const bool ok = ncol_ok && m < p.M;
+                const float o = u[i][r], gw = w[i][r];
+                float ov = o - (EPI == EPI_COS ? 0.0f : bias_n), wv;
+                if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+                u[i][r] = ok ? ov : 0.0f;
+                w[i][r] = ok ? wv : 0.0f;
+            }
+        if (EPI == EPI_COS) {
+            // cosine keeps the raw output and carries the bias (0 on padding rows) in w
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const bool ok = ncol_ok && m < p.M;
+                    const float braw = (biasz && p.bias_axis) ? biasz[min(m, p.M - 1)] : bias_n;
+                    w[i][r] = (ok && biasz) ? braw : 0.0f;
+                }
         }
+    }
     const int sb = p.sb_mode == 1 ? min(n / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0;
 
     // ---- global -> LDS staging: one 16-byte piece per thread per plane per k-tile ---------------------
@@ -560,22 +619,35 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
     const bool ncol_ok = n < p.N;
     const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
     const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
+    {
+        // Phase 1: every load of the raw_out / weight tile issued back to back at clamped (always valid) addresses.
+        // (A load inside a per-element branch costs one dependent memory round trip per element.)
+        const int nc = min(n, p.N - 1);
+        const long ncol_off = (long)z * p.o_zs + (long)(nc / p.o_ninner) * p.o_nbs + (long)(nc % p.o_ninner) * p.o_ns;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            float ov = 0.0f, wv = 0.0f;
-            if (ncol_ok && m < p.M) {
-                const long idx = (long)z * p.o_zs + (long)(m / p.o_inner) * p.o_bs + (long)(m % p.o_inner) * p.o_ms +
-                                 (long)(n / p.o_ninner) * p.o_nbs + (long)(n % p.o_ninner) * p.o_ns;
-                const float o = p.O[idx];
-                ov = o - bias_n;
-                wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.M - 1);
+                const long idx = ncol_off + (long)(mc / p.o_inner) * p.o_bs + (long)(mc % p.o_inner) * p.o_ms;
+                u[i][r] = p.O[idx];
+                w[i][r] = p.Wt[idx];   // host passes Wt = O when the metric has no weight tensor
             }
-            u[i][r] = ov;
-            w[i][r] = wv;
-        }
+        // Phase 2: pure ALU; the metric switch is hoisted out of the element loops
+        const int wm = p.wt_mode;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const bool ok = ncol_ok && m < p.M;
+                const float o = u[i][r], gw = w[i][r];
+                float ov = o - bias_n, wv;
+                if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+                u[i][r] = ok ? ov : 0.0f;
+                w[i][r] = ok ? wv : 0.0f;
+            }
+    }
     // wave-uniform scale block of this wave's 32 columns (host guarantees they share one block)
     const int nw0 = n0 + wc * 32;
     const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
@@ -672,21 +744,24 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
             // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             const float s1 = s1tab[(c - c_lo) * 8 + wid];
             const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + wid] : 1.0f;
-            float sum = 0.0f;
+            v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float o_sim = (float)acc[i][r] * s1;
-                    if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
-                    const float d = u[i][r] - o_sim;
-                    if (EPI == EPI_SQ_W) { const float tt = w[i][r] * d; sum = fmaf(tt, tt, sum); }
-                    else if (EPI == EPI_SQ) sum = fmaf(d, d, sum);
-                    else if (EPI == EPI_ABS) sum += fabsf(d);
-                    else sum = fmaf(w[i][r] * d, d, sum);
-                    acc[i][r] = 0;
-                    if (TWIN) acc2[i][r] = 0;
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f a = {(float)acc[i][r], (float)acc[i][r + 1]};
+                    const v2f uu = {u[i][r], u[i][r + 1]};
+                    const v2f ww = {w[i][r], w[i][r + 1]};
+                    v2f d = uu - a * s1;
+                    if (TWIN) { const v2f a2 = {(float)acc2[i][r], (float)acc2[i][r + 1]}; d = d - a2 * s2; }
+                    if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                    else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                    else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                    else sum2 = (ww * d) * d + sum2;
+                    acc[i][r] = 0; acc[i][r + 1] = 0;
+                    if (TWIN) { acc2[i][r] = 0; acc2[i][r + 1] = 0; }
                 }
+            float sum = sum2.x + sum2.y;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);   // fixed butterfly: deterministic
             if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
@@ -785,26 +860,45 @@ __global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
     // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 ------------------------------
     // C/D layout: col = lane&31 (streaming row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (stationary row)
     float u[2][2][16], w[2][2][16];
+    // Phase 1: all raw_out / weight loads back to back at clamped addresses (no per-element branches)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int tr = t0 + wc * 64 + j * 32 + l31;
-        const bool t_ok = tr < p.TR;
-        const float bias_t = (p.bias && p.bias_on_t && t_ok) ? p.bias[tr] : 0.0f;
+        const long toff = (long)min(t0 + wc * 64 + j * 32 + l31, p.TR - 1) * p.o_ts;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int sr = s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                float ov = 0.0f, wv = 0.0f;
-                if (t_ok && sr < p.SR) {
-                    const long idx = (long)sr * p.o_ss + (long)tr * p.o_ts;
-                    const float o = p.O[idx];
-                    const float b = p.bias ? (p.bias_on_t ? bias_t : p.bias[sr]) : 0.0f;
-                    ov = o - b;
-                    wv = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
-                }
-                u[i][j][r] = ov;
-                w[i][j][r] = wv;
+                const long idx = toff + (long)min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1) * p.o_ss;
+                u[i][j][r] = p.O[idx];
+                w[i][j][r] = p.Wt[idx];
+            }
+    }
+    // bias per streaming row (weight search) or per stationary row (activation search); p.bias is never NULL
+    // (the host passes a zero vector for bias-free layers)
+    float bias_t[2], bias_s[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_t[j] = p.bias[p.bias_on_t ? min(t0 + wc * 64 + j * 32 + l31, p.TR - 1) : 0];
+    if (!p.bias_on_t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias_s[i][r] = p.bias[min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1)];
+    }
+    // Phase 2: pure ALU
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool t_ok = (t0 + wc * 64 + j * 32 + l31) < p.TR;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t_ok && (s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
+                const float o = u[i][j][r], gw = w[i][j][r];
+                const float b = p.bias_on_t ? bias_t[j] : bias_s[i][r];
+                float wv;
+                if (p.wt_mode == 1) wv = gw; else if (p.wt_mode == 2) wv = o; else if (p.wt_mode == 3) wv = fabsf(o); else wv = 1.0f;
+                u[i][j][r] = ok ? o - b : 0.0f;
+                w[i][j][r] = ok ? wv : 0.0f;
             }
     }
     const int blk_row = p.sb_on_t ? (t0 + wc * 64) : (s0 + wr * 64);
@@ -835,20 +929,24 @@ __global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
         constexpr int ST = decltype(stage_c)::value;
         constexpr int SO = ST * SW3_TT;
         if (it + 1 < total) wait_vmcnt<2>(); else wait_vmcnt<0>();   // ring depth 3: one tile (2 pieces) may stay in flight
-        __builtin_amdgcn_s_barrier();
+        if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
         if (it + SW3_NS - 1 < total && !(p.dbg & 1)) issue((ST + SW3_NS - 1) % SW3_NS);
         if (p.dbg & 2) { if (++kt == ktiles) { kt = 0; ++c; } return; }
-        const char* sk = smem + kt * SW2_TILE;
+        const char* sk = (p.dbg & 8) ? smem : smem + kt * SW2_TILE;
+        // software pipeline inside the tile: the second K-half's fragments are fetched while the first
+        // half's MFMAs run, so only the first four reads are exposed after the barrier
         const v4i s00 = *reinterpret_cast<const v4i*>(sk + aS00);
         const v4i s10 = *reinterpret_cast<const v4i*>(sk + aS10);
         const v4i t00 = *reinterpret_cast<const v4i*>(fT00 + SO);
         const v4i t10 = *reinterpret_cast<const v4i*>(fT10 + SO);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t00, acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
         const v4i s01 = *reinterpret_cast<const v4i*>(sk + aS01);
         const v4i s11 = *reinterpret_cast<const v4i*>(sk + aS11);
         const v4i t01 = *reinterpret_cast<const v4i*>(fT01 + SO);
         const v4i t11 = *reinterpret_cast<const v4i*>(fT11 + SO);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t00, acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t00, acc[1][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t10, acc[0][1], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t10, acc[1][1], 0, 0, 0);
@@ -856,23 +954,30 @@ __global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t01, acc[1][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s01, t11, acc[0][1], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t11, acc[1][1], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-        if (++kt == ktiles) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 7, 0);
+        if (++kt == ktiles && (p.dbg & 16)) { kt = 0; ++c; }
+        else if (kt == ktiles) {
             const float s1 = s1tab[(c - c_lo) * 8 + wid];
-            float sum = 0.0f;
+            // packed-f32 epilogue (v_pk_fma_f32 / v_pk_mul_f32): two output elements per VALU instruction
+            v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float d = u[i][j][r] - (float)acc[i][j][r] * s1;
-                        if (EPI == EPI_SQ_W) { const float tt2 = w[i][j][r] * d; sum = fmaf(tt2, tt2, sum); }
-                        else if (EPI == EPI_SQ) sum = fmaf(d, d, sum);
-                        else if (EPI == EPI_ABS) sum += fabsf(d);
-                        else sum = fmaf(w[i][j][r] * d, d, sum);
+                    for (int r = 0; r < 16; r += 2) {
+                        const v2f a = {(float)acc[i][j][r], (float)acc[i][j][r + 1]};
+                        const v2f uu = {u[i][j][r], u[i][j][r + 1]};
+                        const v2f ww = {w[i][j][r], w[i][j][r + 1]};
+                        const v2f d = uu - a * s1;
+                        if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                        else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                        else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                        else sum2 = (ww * d) * d + sum2;
                         acc[i][j][r] = 0;
+                        acc[i][j][r + 1] = 0;
                     }
+            float sum = sum2.x + sum2.y;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
