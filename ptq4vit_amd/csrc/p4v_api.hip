@@ -145,6 +145,7 @@ template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams&
         case EPI_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ>), grid, block, lds, c.st, p); break;
         case EPI_ABS: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_ABS>), grid, block, lds, c.st, p); break;
         case EPI_W_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_W_SQ>), grid, block, lds, c.st, p); break;
+        case EPI_STORE: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_STORE>), grid, block, lds, c.st, p); break;
         default: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_COS>), grid, block, lds, c.st, p); break;
     }
     HIPCHK(hipGetLastError());
@@ -305,6 +306,7 @@ struct Pass {
     float* aux_out; float aux_div;
     float* scores_out; int scores_out_ld;
     int32_t* best_out;
+    float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
 };
 
 static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
@@ -315,7 +317,7 @@ int run_pass(Ctx& c, Pass& ps) {
     // stationary-operand sweep (k_sweep3): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
     const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
                           (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 64 == 0)));
-    const bool stat_ok = ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
+    const bool stat_ok = !ps.store_out && ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
                          ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
                          rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
     const int PADR = stat_ok ? 256 : SW_BM;
@@ -333,7 +335,7 @@ int run_pass(Ctx& c, Pass& ps) {
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
-    const bool fast = !stat_ok && ps.i8 && !cosm && !(g_force_v1) &&
+    const bool fast = !stat_ok && !ps.store_out && ps.i8 && !cosm && !(g_force_v1) &&
                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
     // k_sweep3 table: [slabs of 64 stationary rows][groups of 64 streaming rows]
@@ -417,6 +419,7 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = NpP;
         sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
         sp.dbg = g_variant & 3;
+        sp.store = ps.store_out;
         int cgroups = 1;
         if (fast) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
@@ -424,6 +427,7 @@ int run_pass(Ctx& c, Pass& ps) {
         }
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
+    if (ps.store_out) { c.ws.off = mark; return 0; }
     if (!cosm) {
         const int gdiv = stat_ok ? 64 : 32;
         // k_sweep3 activation search (j_mode 0) sums the whole table; its columns are sample groups
@@ -481,6 +485,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     unsigned* enc_a = c.ws.get<unsigned>((size_t)nA);
     float* w_cands = c.ws.get<float>((size_t)ncand * nV * nH);
     float* a_cands = c.ws.get<float>((size_t)ncand * nA);
+    float* Ufold = twin ? c.ws.get<float>((size_t)M * N) : nullptr;   // twin activation search: folded target
     float* w_mix = c.ws.get<float>((size_t)ncand * nV * nH);   // general path: candidates of block column h only
     float* a_mix = c.ws.get<float>((size_t)ncand * nA);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
@@ -616,6 +621,20 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.O = O; ps.G = G; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
                 ps.j_mode = 0;
                 ps.norm = 1.0 / ((double)d->tokens * N);
+                if (twin && wt_mode <= 1 && !(g_variant & 64)) {
+                    // Twin activation search: the negative-range plane and the weights are candidate-invariant, so
+                    // their product is folded into the target once (U = raw_out - bias - s_neg*s_w*(x_neg . W_q))
+                    // and the sweep runs on the positive-range plane alone: half the MFMA work of this pass.
+                    Pass fp = ps;
+                    fp.twin = false; fp.epi = EPI_STORE; fp.wt_mode = 0; fp.eq_n = 1;
+                    fp.row = xneg_operand(); fp.row2 = Operand{};
+                    fp.s1 = ps.s2;
+                    fp.store_out = Ufold;
+                    fp.scores_out = nullptr; fp.best_out = nullptr;
+                    CHK(run_pass(c, fp));
+                    ps.twin = false; ps.row2 = Operand{};
+                    ps.O = Ufold; ps.bias = nullptr;
+                }
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
                 ps.row = w_operand(false, w_iv, 0, true);

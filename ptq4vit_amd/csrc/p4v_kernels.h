@@ -321,7 +321,9 @@ enum EpiMode {
     EPI_SQ = 1,    // d^2         L2_norm
     EPI_ABS = 2,   // |d|         L1_norm
     EPI_W_SQ = 3,  // w*d^2       linear_weighted_L2 (w = |raw_out|)
-    EPI_COS = 4    // cosine: per-row dot / norm partials (rows of the MFMA tile = features)
+    EPI_COS = 4,   // cosine: per-row dot / norm partials (rows of the MFMA tile = features)
+    EPI_STORE = 5  // no metric: store raw_out - bias - scale*acc as an fp32 [M][N] tensor (candidate-invariant
+                   // part of a twin operand folded into the target, see linear_impl)
 };
 
 struct SweepParams {
@@ -348,6 +350,7 @@ struct SweepParams {
     int Np;
     int mtiles, ntiles;
     int dbg;                           // tuning experiments only (0 in production): 1 = no operand loads, 2 = no MFMA
+    float* store;                      // EPI_STORE output [M][N]
 };
 
 static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
@@ -521,7 +524,17 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
             const int c = p.c0 + it / p.ktiles;
             const float s1 = p.S1 ? p.S1[c * p.s_cs + sb] : 1.0f;
             const float s2 = (TWIN && p.S2) ? p.S2[c * p.s_cs + sb] : 1.0f;
-            if constexpr (EPI != EPI_COS) {
+            if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        float o_sim = (float)acc[i][r] * s1;
+                        if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                        if (ncol_ok && m < p.M) p.store[(long)z * p.M * p.N + (long)m * p.N + n] = u[i][r] - o_sim;
+                    }
+            } else if constexpr (EPI != EPI_COS) {
                 float colsum = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
