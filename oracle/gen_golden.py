@@ -162,9 +162,11 @@ PTQ4VIT = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_ro
 BASEPTQ = dict(metric="cosine", eq_alpha=0.5, eq_beta=1.2, eq_n=100, search_round=1)
 
 
-def main():
+def main(only=None):
     _install_shims()
     os.chdir(REF)
+    if only == "minivit":
+        return gen_mini_vit()
     # ---- Linear (quant_layers/linear.py:349-642) ---------------------------------
     gen_linear("linear_qkv_hessian_w8a8", shape_x=(4, 13, 48), oc=36, n_V=3, w_bit=8, a_bit=8, **PTQ4VIT)
     gen_linear("linear_hessian_w6a6_tinygrad", shape_x=(4, 13, 48), oc=24, n_V=1, w_bit=6, a_bit=6,
@@ -203,5 +205,86 @@ def main():
              metric="hessian", eq_alpha=0.3, eq_beta=1.2, eq_n=30, search_round=2)
 
 
+
+
+# --------------------------------------------------------------------------- #
+# whole-calibrator fixture: the reference's net_wrap + HessianQuantCalibrator on a mini ViT
+# --------------------------------------------------------------------------- #
+def gen_mini_vit(name="minivit_ptq4vit"):
+    """Reference wrap + batching_quant_calib (reference utils/quant_calib.py:300-378) on a 2-block mini ViT built
+    from ptq4vit_amd.utils.models (same forward as the patched timm attention, reference utils/models.py:10-26).
+    Stored: images, per-module captured raw_input/raw_out/raw_grad (as the reference's hooks cached them) and the
+    calibrated intervals.  The weights are reproducible from the seed."""
+    import types
+    stub = types.ModuleType("timm")
+    for sub in ("timm.models", "timm.models.vision_transformer", "timm.models.swin_transformer"):
+        sys.modules[sub] = types.ModuleType(sub)
+    sys.modules["timm"] = stub
+    stub.models = sys.modules["timm.models"]
+    sys.modules["timm.models"].vision_transformer = sys.modules["timm.models.vision_transformer"]
+    sys.modules["timm.models.vision_transformer"].Attention = type("Attention", (torch.nn.Module,), {})
+    sys.modules["timm.models.swin_transformer"].WindowAttention = type("WindowAttention", (torch.nn.Module,), {})
+    import importlib
+    ref_models = importlib.import_module("utils.models")
+    ref_wrap = importlib.import_module("utils.net_wrap")
+    ref_calib = importlib.import_module("utils.quant_calib")
+    cfg = importlib.import_module("configs.PTQ4ViT")
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    if repo not in sys.path:
+        sys.path.append(repo)
+    from ptq4vit_amd.utils import models as my_models
+
+    kw = dict(img_size=32, patch_size=8, embed_dim=48, depth=2, num_heads=3, num_classes=10)
+    net = my_models.get_net("vit_tiny_patch16_224", seed=0, device="cpu", **kw)
+    for m in list(net.modules()):           # let the reference's isinstance(m, MatMul) recognise the matmul modules
+        for cname, child in list(m.named_children()):
+            if isinstance(child, my_models.MatMul):
+                setattr(m, cname, ref_models.MatMul())
+    wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(8, 3, 32, 32, generator=g)
+
+    class Loader:
+        batch_size = 8
+
+        def __iter__(self):
+            yield images, torch.zeros(8, dtype=torch.long)
+
+    captured = {}
+    for n, m in wrapped.items():
+        orig = m.calibration_step2
+
+        def rec(_orig=orig, _m=m, _n=n):
+            ri = _m.raw_input
+            captured[_n] = dict(
+                raw_input=[t.clone().numpy() for t in ri] if isinstance(ri, (list, tuple)) else ri.clone().numpy(),
+                raw_out=_m.raw_out.clone().numpy(), raw_grad=_m.raw_grad.clone().numpy())
+            return _orig()
+        m.calibration_step2 = rec
+    cal = ref_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
+    cal.batching_quant_calib()
+    with torch.no_grad():
+        logits = net(images)
+    payload = {"images": images.numpy(), "quant_logits": logits.numpy(), "names": np.array(list(wrapped))}
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        cap = captured[n]
+        if isinstance(cap["raw_input"], list):
+            payload[f"{key}::A"], payload[f"{key}::B"] = cap["raw_input"]
+        else:
+            payload[f"{key}::x"] = cap["raw_input"]
+        payload[f"{key}::out"], payload[f"{key}::grad"] = cap["raw_out"], cap["raw_grad"]
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            v = getattr(m, a, None)
+            if v is not None:
+                payload[f"{key}::{a}"] = np.asarray(v)
+    payload["model_kwargs"] = np.array(json.dumps(kw))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **payload)
+    print(f"wrote {name}.npz ({len(wrapped)} modules)")
+
+
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
+    if len(sys.argv) == 1:
+        gen_mini_vit()

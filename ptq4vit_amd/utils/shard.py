@@ -70,8 +70,8 @@ def exchange_intervals(wrapped_modules, owner):
     rank, world = rank_world()
     names = list(wrapped_modules)
     dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
-    # slot sizes: 5 attrs x up to 4 dims per module, encoded as ints (0 = absent)
-    shape_tab = torch.zeros(len(names), len(INTERVAL_ATTRS), 5, dtype=torch.int64, device=dev)
+    # slot shapes: 5 attrs x (1 + ndim, up to 8 dims) per module, encoded as ints (0 = absent)
+    shape_tab = torch.zeros(len(names), len(INTERVAL_ATTRS), 9, dtype=torch.int64, device=dev)
     packed = {}
     for i, n in enumerate(names):
         if owner[n] != rank:
@@ -81,7 +81,7 @@ def exchange_intervals(wrapped_modules, owner):
         for (a, shp) in meta:
             j = INTERVAL_ATTRS.index(a)
             shape_tab[i, j, 0] = 1 + len(shp)
-            for k, s in enumerate(shp[:4]):
+            for k, s in enumerate(shp[:8]):
                 shape_tab[i, j, 1 + k] = s
     dist.all_reduce(shape_tab, op=dist.ReduceOp.MAX)
     shape_tab = shape_tab.cpu()
@@ -105,8 +105,9 @@ def exchange_intervals(wrapped_modules, owner):
                 off, numel, _ = offsets[(n, a)]
                 vec[off:off + numel] = vals[k].to(dev)
                 k += 1
-    gathered = torch.empty(world, total, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gathered, vec)
+    parts = [torch.empty(total, dtype=torch.float32, device=dev) for _ in range(world)]
+    dist.all_gather(parts, vec)        # one collective: a few KB per rank (RCCL over xGMI on the GPU box, gloo in tests)
+    gathered = torch.stack(parts)
     for n in names:
         r = owner[n]
         if r == rank:

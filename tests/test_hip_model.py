@@ -1,0 +1,147 @@
+"""GPU: the drop-in module classes and the calibrator end to end.
+
+* reference-captured tensors (tests/golden/minivit_ptq4vit.npz) -> module.calibration_step2() on the GPU
+  -> the reference's calibrated intervals;
+* the full HessianQuantCalibrator on the GPU (capture + search) checked module by module against the numpy
+  oracle run on the very tensors the GPU capture produced;
+* size-independent properties at the BASELINE shapes (ViT-B/224, 32 images): run-to-run determinism,
+  agreement of the three sweep kernels, invariance of the selection under a power-of-two rescale of raw_grad.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_scores_close
+
+pytestmark = pytest.mark.gpu
+
+GRID_STEP = 0.03   # one candidate step of (1.2-0.01)/100 relative to the smallest searched multiplier region
+
+
+def _mini():
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = models.get_net("vit_tiny_patch16_224", seed=0, device="cuda", **kw)
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    return g, net, wrapped
+
+
+def test_modules_reproduce_reference_intervals_from_reference_captures():
+    g, net, wrapped = _mini()
+    exact = total = 0
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        t = lambda a: torch.from_numpy(g[f"{key}::{a}"]).cuda()
+        m.raw_input = [t("A"), t("B")] if f"{key}::A" in g.files else t("x")
+        m.raw_out, m.raw_grad = t("out"), t("grad")
+        m.calibration_step2()
+        assert m.calibrated
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            if f"{key}::{a}" not in g.files:
+                continue
+            want = g[f"{key}::{a}"].reshape(-1)
+            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
+            assert got.shape == want.shape, (n, a)
+            rel = np.abs(got - want) / np.abs(want)
+            assert rel.max() <= GRID_STEP, f"{n}.{a}: {rel.max():.3e}"
+            exact += int((got == want).sum())
+            total += want.size
+    assert exact >= 0.97 * total, f"only {exact}/{total} intervals bit-identical to the reference"
+
+
+def test_calibrator_end_to_end_vs_oracle_on_gpu_captures():
+    from oracle.ptq4vit_oracle import ConvOracle, LinearOracle, MatMulOracle
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    g, net, wrapped = _mini()
+    images = torch.from_numpy(g["images"]).cuda()
+
+    class Loader:
+        batch_size = images.shape[0]
+
+        def __iter__(self):
+            yield images, torch.zeros(images.shape[0], dtype=torch.long)
+
+    caps = {}
+    for n, m in wrapped.items():
+        orig = m.calibration_step2
+
+        def rec(_o=orig, _m=m, _n=n):
+            ri = _m.raw_input
+            caps[_n] = ([x.cpu().numpy() for x in ri] if isinstance(ri, list) else ri.cpu().numpy(),
+                        _m.raw_out.cpu().numpy(), _m.raw_grad.cpu().numpy())
+            return _o()
+        m.calibration_step2 = rec
+    cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
+    cal.batching_quant_calib()
+    hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3)
+    exact = total = 0
+    for n, m in wrapped.items():
+        ri, ro, rg = caps[n]
+        if isinstance(m, MinMaxQuantLinear):
+            o = LinearOracle(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), w_bit=8, a_bit=8, n_V=m.n_V,
+                             postgelu=type(m).__name__.startswith("PostGelu"), **hp)
+            res = o.calibration_step2(ri, ro, rg)
+        elif isinstance(m, MinMaxQuantConv2d):
+            o = ConvOracle(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), stride=m.stride, w_bit=8, a_bit=32, **hp)
+            res = o.calibration_step2(ri, ro, rg)
+            res.pop("a_interval")
+        else:
+            o = MatMulOracle(A_bit=8, B_bit=8, sos=type(m).__name__.startswith("SoS"), **hp)
+            res = o.calibration_step2(ri[0], ri[1], ro, rg)
+        for a, want in res.items():
+            want = np.asarray(want).reshape(-1)
+            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
+            rel = np.abs(got - want) / np.abs(want)
+            assert rel.max() <= GRID_STEP, f"{n}.{a}: {rel.max():.3e}"
+            exact += int((got == want).sum())
+            total += want.size
+    assert exact >= 0.95 * total, f"only {exact}/{total} intervals bit-identical to the oracle"
+    with torch.no_grad():
+        assert torch.isfinite(net(images)).all()      # every module now runs in quant_forward mode
+
+
+# ---- BASELINE-size properties (ViT-B/224 qkv: 32 x 197 x 768 -> 2304, n_V = 3) ------------------------
+@pytest.fixture(scope="module")
+def vitb_qkv():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(32, 197, 768, generator=g).cuda()
+    w = (torch.randn(2304, 768, generator=g) * 0.02).cuda()
+    b = (torch.randn(2304, generator=g) * 0.02).cuda()
+    out = torch.nn.functional.linear(x, w, b)
+    grad = (torch.randn(out.shape, generator=g) * 1e-10).cuda()     # the magnitude the reference's KL gradient has
+    return dict(weight=w, bias=b, x=x, out=out, grad=grad)
+
+
+HP = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, n_V=3, n_H=1, n_a=1)
+
+
+def test_full_size_determinism_and_kernel_agreement(vitb_qkv):
+    from ptq4vit_amd import engine
+    r1 = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
+    r2 = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
+    for a, b in zip(r1, r2):
+        assert torch.equal(a, b), "run-to-run results differ"
+    engine.stats_enable(4 << 2)          # variant bit 2: stationary-operand sweep off -> streaming k_sweep2
+    try:
+        r3 = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
+    finally:
+        engine.stats_enable(0)
+    assert_scores_close(r1[2].cpu().numpy(), r3[2].cpu().numpy(), rtol=2e-5, what="k_sweep3 vs k_sweep2")
+    assert torch.equal(r1[3], r3[3]) and torch.equal(r1[0], r3[0]) and torch.equal(r1[1], r3[1])
+    assert torch.isfinite(r1[2]).all() and (r1[2][:, 0] < 0).all() and (r1[2][:, 1, :, 0] < 0).all()
+
+
+def test_full_size_selection_invariant_under_grad_rescale(vitb_qkv):
+    """hessian score = -sum (g*d)^2: scaling raw_grad by 2^k scales every score by exactly 4^k."""
+    from ptq4vit_amd import engine
+    base = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
+    scaled = dict(vitb_qkv, grad=vitb_qkv["grad"] * 1024.0)
+    r = engine.linear_calibrate(**scaled, want_scores=True, **HP)
+    assert torch.equal(base[3], r[3]) and torch.equal(base[0], r[0]) and torch.equal(base[1], r[1])
+    assert torch.equal(base[2] * (1024.0 ** 2), r[2])

@@ -1,0 +1,172 @@
+"""Host-side mirror of the reference's module / wrapper / config / calibrator API (no GPU needed)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import golden_names, load_golden
+
+from ptq4vit_amd.configs import BasePTQ, PTQ4ViT
+from ptq4vit_amd.quant_layers.conv import BatchingEasyQuantConv2d, ChannelwiseBatchingQuantConv2d, MinMaxQuantConv2d
+from ptq4vit_amd.quant_layers.linear import (MinMaxQuantLinear, PostGeluPTQSLBatchingQuantLinear,
+                                             PTQSLBatchingQuantLinear, PTQSLQuantLinear)
+from ptq4vit_amd.quant_layers.matmul import (MinMaxQuantMatMul, PTQSLBatchingQuantMatMul,
+                                             SoSPTQSLBatchingQuantMatMul)
+from ptq4vit_amd.utils import models, net_wrap, quant_calib
+
+
+def test_config_factory_types_and_kwargs():
+    qkv = PTQ4ViT.get_module("qlinear_qkv", 48, 144)
+    assert type(qkv) is PTQSLBatchingQuantLinear and qkv.n_V == 3 and qkv.metric == "hessian"
+    assert (qkv.eq_alpha, qkv.eq_beta, qkv.eq_n, qkv.search_round) == (0.01, 1.2, 100, 3)
+    assert type(PTQ4ViT.get_module("qlinear_MLP_2", 192, 48)) is PostGeluPTQSLBatchingQuantLinear
+    assert type(PTQ4ViT.get_module("qmatmul_scorev")) is SoSPTQSLBatchingQuantMatMul
+    assert type(PTQ4ViT.get_module("qmatmul_qk")) is PTQSLBatchingQuantMatMul
+    conv = PTQ4ViT.get_module("qconv", 3, 48, (8, 8), (8, 8), (0, 0), (1, 1), 1, True, "zeros")
+    assert type(conv) is ChannelwiseBatchingQuantConv2d and conv.a_bit == 32 and conv.n_V == 48
+    assert type(BasePTQ.get_module("qconv", 3, 48, (8, 8), (8, 8), (0, 0), (1, 1), 1, True, "zeros")) is BatchingEasyQuantConv2d
+    assert type(BasePTQ.get_module("qlinear_MLP_2", 192, 48)) is PTQSLBatchingQuantLinear
+    assert BasePTQ.get_module("qlinear_proj", 48, 48).metric == "cosine"
+
+
+def test_wrap_order_and_shared_parameters():
+    net = models.get_net("vit_tiny_patch16_224", depth=2, device="cpu", img_size=32, patch_size=8, embed_dim=48, num_heads=3, num_classes=10)
+    w0 = net.blocks[0].attn.qkv.weight
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    names = list(wrapped)
+    assert names[:7] == ["patch_embed.proj", "blocks.0.attn.qkv", "blocks.0.attn.proj", "blocks.0.attn.matmul1",
+                         "blocks.0.attn.matmul2", "blocks.0.mlp.fc1", "blocks.0.mlp.fc2"] and names[-1] == "head"
+    assert len(wrapped) == 14 and all(m.mode == "raw" for m in wrapped.values())
+    assert net.blocks[0].attn.qkv.weight.data_ptr() == w0.data_ptr()      # storage shared with the float module
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (2, 10)
+
+
+def test_mode_dispatch_and_errors():
+    m = MinMaxQuantLinear(4, 4)
+    m.mode = "bogus"
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4))
+    with pytest.raises(AssertionError):
+        MinMaxQuantLinear(4, 4, bias_bit=8)
+    mm = MinMaxQuantMatMul()
+    mm.mode = "bogus"
+    with pytest.raises(NotImplementedError):
+        mm(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
+    assert not hasattr(PTQSLBatchingQuantLinear(4, 4), "calibrated")
+
+
+def test_calibration_without_gpu_fails_loudly():
+    """The calibration path has no CPU fallback: without a visible GPU it must raise, not silently compute."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = PTQSLBatchingQuantLinear(8, 8, metric="L2_norm")
+    m.raw_input, m.raw_out, m.raw_grad = torch.randn(2, 3, 8), torch.randn(2, 3, 8), None
+    with pytest.raises(RuntimeError, match="no CPU fallback|needs an MI355X"):
+        m.calibration_step2()
+
+
+@pytest.mark.parametrize("name", ["linear_qkv_hessian_w8a8", "postgelu_hessian_w6a6", "linear_blocks_nH2_na2"])
+def test_linear_quant_forward_matches_reference(name):
+    """quant_forward (reference linear.py:62-67,601-607) with the reference's calibrated intervals."""
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    oc = p.pop("oc")
+    cls = PostGeluPTQSLBatchingQuantLinear if p.pop("postgelu") else PTQSLBatchingQuantLinear
+    m = cls(g["x"].shape[-1], oc, bias="bias" in g, **p)
+    m.weight.data = torch.from_numpy(g["weight"])
+    if "bias" in g:
+        m.bias.data = torch.from_numpy(g["bias"])
+    m.w_interval = torch.from_numpy(g["w_interval"])
+    m.a_interval = torch.from_numpy(g["a_interval"])
+    m.calibrated, m.mode = True, "quant_forward"
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["quant_forward"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["matmul_qk_hessian_w8a8", "matmul_sos_hessian_w8a8"])
+def test_matmul_quant_forward_matches_reference(name):
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    sos = p.pop("sos")
+    m = (SoSPTQSLBatchingQuantMatMul if sos else PTQSLBatchingQuantMatMul)(**p)
+    A, B = torch.from_numpy(g["A"]), torch.from_numpy(g["B"])
+    m.n_G_A = m.n_G_B = A.shape[1]
+    m._get_padding_parameters(A, B)
+    m.B_interval = torch.from_numpy(g["B_interval"])
+    m.A_interval = torch.from_numpy(np.asarray(g["A_interval"]))
+    if sos:
+        m.split = torch.tensor(float(g["split"]))
+    m.calibrated, m.mode = True, "quant_forward"
+    with torch.no_grad():
+        y = m(A, B)
+    np.testing.assert_allclose(y.numpy(), g["quant_forward"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["conv_channelwise_hessian", "conv_layerwise_cosine"])
+def test_conv_quant_forward_matches_reference(name):
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    st = p.pop("stride")
+    cls = ChannelwiseBatchingQuantConv2d if p.pop("channelwise") else BatchingEasyQuantConv2d
+    oc, ic, k, _ = g["weight"].shape
+    m = cls(ic, oc, k, st, **p)
+    m.weight.data, m.bias.data = torch.from_numpy(g["weight"]), torch.from_numpy(g["bias"])
+    m.w_interval = torch.from_numpy(np.asarray(g["w_interval"]))
+    m.a_interval = torch.from_numpy(np.asarray(g["a_interval"]))
+    m.calibrated, m.mode = True, "quant_forward"
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["quant_forward"], rtol=1e-5, atol=1e-6)
+
+
+def _mini_net(kw):
+    return models.get_net("vit_tiny_patch16_224", seed=0, device="cpu", **kw)
+
+
+class _Loader:
+    def __init__(self, images):
+        self.images, self.batch_size = images, images.shape[0]
+
+    def __iter__(self):
+        yield self.images, torch.zeros(self.images.shape[0], dtype=torch.long)
+
+
+@pytest.mark.parametrize("budget", [1 << 40, 1])
+def test_one_pass_capture_equals_reference_capture(budget):
+    """Capture contract (reference quant_calib.py:309-356): raw_input / raw_out / raw_grad cached by ONE set of
+    passes hooking all modules (or groups of modules under a cache budget) are bit-identical to what the
+    reference's per-module passes cached (fixture made by oracle/gen_golden.py from the reference)."""
+    g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = _mini_net(kw)
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    assert list(wrapped) == [str(n) for n in g["names"]]
+    seen = {}
+    for n, m in wrapped.items():
+        def rec(_m=m, _n=n):
+            ri = _m.raw_input
+            seen[_n] = ([t.clone() for t in ri] if isinstance(ri, list) else ri.clone(), _m.raw_out.clone(), _m.raw_grad.clone())
+            _m.calibrated = True
+        m.calibration_step2 = rec
+    cal = quant_calib.HessianQuantCalibrator(net, wrapped, _Loader(torch.from_numpy(g["images"])), sequential=False,
+                                             batch_size=4, cache_budget_bytes=budget)
+    cal.batching_quant_calib()
+    assert all(m.mode == "quant_forward" for m in wrapped.values())
+    for n in wrapped:
+        key = n.replace(".", "__")
+        ri, ro, rg = seen[n]
+        if isinstance(ri, list):
+            np.testing.assert_array_equal(ri[0].numpy(), g[f"{key}::A"])
+            np.testing.assert_array_equal(ri[1].numpy(), g[f"{key}::B"])
+        else:
+            np.testing.assert_array_equal(ri.numpy(), g[f"{key}::x"])
+        np.testing.assert_array_equal(ro.numpy(), g[f"{key}::out"])
+        np.testing.assert_array_equal(rg.numpy(), g[f"{key}::grad"])
