@@ -84,13 +84,17 @@ def main():
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("P4V_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0)))   # P4V_FORCE_DEVICE: testing N ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("P4V_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for single-GPU testing
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ptq4vit_amd import engine
     from ptq4vit_amd.configs import PTQ4ViT
@@ -139,22 +143,24 @@ def main():
     value = n_mod * args.steps / elapsed
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        # live HIP-event timing of the dominant kernel (k_sweep<int8>) over one more, untimed-for-value step
+    if not args.no_roofline:
+        # live HIP-event timing of the dominant kernels (the int8 sweeps) on their launch stream, over one more
+        # step that is not part of `value` (every rank runs it: the step ends with a collective)
         engine.stats_reset()
-        engine.stats_enable(True)
+        engine.stats_enable(rank == 0)
         with quiet:
-            one_step() if world == 1 else None
-        torch.cuda.synchronize()
+            cal_r = one_step()
+        sync()
         st = engine.stats_get()
         engine.stats_enable(False)
-        if st["sweep_i8_launches"] > 0:
-            lin, mm, conv = search_macs(wrapped, args.calib, tokens, heads, head_dim)
-            algo_ops = 2.0 * (lin + mm)            # ops of the reference GEMMs that run on the int8 sweep
+        if rank == 0 and st["sweep_i8_launches"] > 0:
+            mine = {n: m for n, m in wrapped.items() if cal_r.owner[n] == rank}
+            lin, mm, conv = search_macs(mine, args.calib, tokens, heads, head_dim)
+            algo_ops = 2.0 * (lin + mm)            # ops of the reference GEMMs rank 0 ran on the int8 sweeps
             issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-            roof = {"bound": "mfma", "kernel": "k_sweep<int8>", "achieved": algo_ops / secs / 1e12, "peak": peak,
+            roof = {"bound": "mfma", "kernel": "k_sweep3 + k_sweep2 (int8 candidate sweeps)", "achieved": algo_ops / secs / 1e12, "peak": peak,
                     "unit": "TOP/s", "frac": algo_ops / secs / 1e12 / peak, "traffic": None,
                     "issued": issued_ops / secs / 1e12, "launches": st["sweep_i8_launches"],
                     "avg_launch_ms": st["sweep_i8_ms"] / st["sweep_i8_launches"],
@@ -165,7 +171,12 @@ def main():
         dt, sample_macs = cpu_baseline()
         lin, mm, conv = search_macs(wrapped, args.calib, tokens, heads, head_dim)
         est_total = dt * (lin + mm + conv) / sample_macs
-        cpu = {"value": n_mod / est_total, "unit": "layers/s", "cores": os.cpu_count(), "kind": "port",
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([t.get("num_threads", 1) for t in threadpool_info()] + [1])
+        except Exception:
+            threads = os.cpu_count()
+        cpu = {"value": n_mod / est_total, "unit": "layers/s", "cores": threads, "kind": "port",
                "sample": f"numpy oracle, ViT-B proj layer 32x197x768->768, 1 search round: {dt:.1f} s; scaled by algorithmic MACs to 74 modules x 3 rounds (search only, no capture)"}
 
     if rank == 0:

@@ -227,6 +227,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         rank, world = shard.rank_world()
         owner = shard.assign_modules(self.wrapped_modules, world) if (world > 1 and not self.sequential) else {n: rank for n in names}
         mine = [n for n in names if owner[n] == rank]
+        self.owner = owner
         t0 = time.time()
         raw_pred_softmax = self._raw_pred_softmax() if with_grad else None
 

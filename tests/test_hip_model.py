@@ -145,3 +145,57 @@ def test_full_size_selection_invariant_under_grad_rescale(vitb_qkv):
     r = engine.linear_calibrate(**scaled, want_scores=True, **HP)
     assert torch.equal(base[3], r[3]) and torch.equal(base[0], r[0]) and torch.equal(base[1], r[1])
     assert torch.equal(base[2] * (1024.0 ** 2), r[2])
+
+
+# ---- layer sharding on the GPU box: 2 ranks (gloo, same GPU) must reproduce the 1-rank intervals bit for bit ----
+def _sharded_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, net, wrapped = _mini()
+    images = torch.from_numpy(g["images"]).cuda()
+
+    class Loader:
+        batch_size = images.shape[0]
+
+        def __iter__(self):
+            yield images, torch.zeros(images.shape[0], dtype=torch.long)
+
+    cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
+    cal.batching_quant_calib()
+    out = {}
+    for n, m in wrapped.items():
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            v = getattr(m, a, None)
+            if v is not None:
+                out[f"{n}.{a}"] = torch.as_tensor(v).detach().cpu().numpy().copy()
+    q.put((rank, cal.timings["owned"], out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_calibration_matches_single_rank():
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(60)
+        results[world] = sorted(res, key=lambda t: t[0])
+    single = results[1][0][2]
+    owned = [r[1] for r in results[2]]
+    assert sum(owned) == 14 and min(owned) >= 3, owned
+    for rank, _, out in results[2]:
+        assert out.keys() == single.keys()
+        for k in single:
+            np.testing.assert_array_equal(out[k], single[k], err_msg=f"rank {rank}: {k}")
