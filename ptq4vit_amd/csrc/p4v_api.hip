@@ -176,10 +176,10 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
     return 0;
 }
 
-int launch_sweep3(Ctx& c, const Sweep3Params& p, int epi, int cgroups, double algo_macs) {
+int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW3_NS * SW3_TT + (size_t)per * 8 * sizeof(float) * 2;
+    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW4_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2;
     dim3 grid(p.stiles * p.ttiles, 1, cgroups), block(512);
     bool timed;
     StatRec rec{};
@@ -191,26 +191,25 @@ int launch_sweep3(Ctx& c, const Sweep3Params& p, int epi, int cgroups, double al
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
         rec.kind = 0;
-        rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 256 * (double)p.ldk * (p.c1 - p.c0);
-        (void)algo_macs;
+        rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
-#define P4V_LAUNCH3(E)                                                                                         \
+#define P4V_LAUNCH4(E)                                                                                         \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep3<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep3<E>), grid, block, lds, c.st, p);                                          \
+        hipLaunchKernelGGL((k_sweep4<E>), grid, block, lds, c.st, p);                                          \
     } while (0)
     switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH3(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH3(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH3(EPI_ABS); break;
-        default: P4V_LAUNCH3(EPI_W_SQ); break;
+        case EPI_SQ_W: P4V_LAUNCH4(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH4(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH4(EPI_ABS); break;
+        default: P4V_LAUNCH4(EPI_W_SQ); break;
     }
-#undef P4V_LAUNCH3
+#undef P4V_LAUNCH4
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
@@ -311,16 +310,31 @@ struct Pass {
 
 static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
 
+// How many candidate groups (gridDim.z) to split a sweep into.  Splitting raises the workgroup count (fills the
+// 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary
+// operand) again.  Cost model in microseconds, constants measured on MI355X (profiles/): minimise
+// rounds * (prologue + candidates_per_group * ktiles * tile_time).
+int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_us, double tile_us) {
+    int best = 1;
+    double best_t = 1e30;
+    for (int cg = 1; cg <= std::min(ncand, 25); ++cg) {
+        const long rounds = (wgs * cg + slots - 1) / slots;
+        const double t = (double)rounds * (prologue_us + (double)cdiv(ncand, cg) * ktiles * tile_us);
+        if (t < best_t * 0.999) { best_t = t; best = cg; }
+    }
+    return best;
+}
+
 int run_pass(Ctx& c, Pass& ps) {
     const int esz = ps.i8 ? 1 : 4;
     const int Kp = (int)rup(ps.K, 64 / esz);          // 64-byte k-tiles
-    // stationary-operand sweep (k_sweep3): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
+    // stationary-operand sweep (k_sweep4): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
     const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
                           (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 64 == 0)));
     const bool stat_ok = !ps.store_out && ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
                          ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
                          rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
-    const int PADR = stat_ok ? 256 : SW_BM;
+    const int PADR = SW_BM;
     const int Mp = (int)rup(ps.Mrows, PADR), Np = (int)rup(ps.Ncols, PADR);
     const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
     const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
@@ -329,18 +343,20 @@ int run_pass(Ctx& c, Pass& ps) {
     int chunk = (int)std::max<long>(1, std::min<long>(ps.eq_n, PLANE_BUDGET / std::max<long>(1, exp_plane)));
 
     const size_t mark = c.ws.off;
-    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk : 1));
+    const size_t slack = stat_ok ? 4096 : 0;   // k_sweep4's ring keeps issuing a few tiles past the last candidate
+    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
-    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk : 1));
+    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk : 1) + slack);
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
     const bool fast = !stat_ok && !ps.store_out && ps.i8 && !cosm && !(g_force_v1) &&
                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
-    // k_sweep3 table: [slabs of 64 stationary rows][groups of 64 streaming rows]
+    // k_sweep4 table: [slabs of 64 stationary rows][groups of 32 streaming rows]
     const bool a_search = ps.row.expanded;          // stationary = weights (col operand), streaming = activations
-    const int s3_slabs = (a_search ? Np : Mp) / 64, s3_groups = (a_search ? Mp : Np) / 64;
+    const int s3_gw = 32;                           // streaming rows per wave (column group width of the table)
+    const int s3_slabs = (a_search ? Np : Mp) / 64, s3_groups = (a_search ? Mp : Np) / s3_gw;
     const int NpP = stat_ok ? s3_groups : fast ? Np / 32 : Np;          // columns of the partial-sum table
     const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
@@ -362,6 +378,7 @@ int run_pass(Ctx& c, Pass& ps) {
         pk.Rp = Rp; pk.Kp = Kp; pk.dst = buf;
         pk.Z = shared ? 1 : ps.Z;
         pk.C = op.expanded ? nc : 1;
+        pk.c_inner = (stat_ok && op.expanded) ? 1 : 0;   // k_sweep4 streams [row][candidate][K]
         if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
         return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
     };
@@ -377,9 +394,9 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
         if (stat_ok) {
             Sweep3Params q{};
-            const long tplane = a_search ? row_plane1 : col_plane1;
             q.S = a_search ? colbuf : rowbuf; q.s_zs = 0;
-            q.T = (a_search ? rowbuf : colbuf) - (long)c0 * tplane; q.t_cs = tplane; q.t_zs = 0;
+            q.T = a_search ? rowbuf : colbuf; q.t_cs = 0; q.t_zs = 0;
+            q.t_rs = (long)nc * Kp;                      // [row][candidate][K] layout written by k_pack (c_inner)
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.s_cs = ps.s_cs; q.sb_on_t = a_search ? 0 : 1; q.sb_div = std::max(1, ps.sb_div);
             q.bias = ps.bias ? ps.bias : zero_bias; q.bias_on_t = a_search ? 0 : 1;
@@ -388,11 +405,11 @@ int run_pass(Ctx& c, Pass& ps) {
             q.SR = a_search ? ps.Ncols : ps.Mrows; q.TR = a_search ? ps.Mrows : ps.Ncols;
             q.c0 = c0; q.c1 = c0 + nc;
             q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
-            q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 256;
-            q.dbg = (g_variant & 3) | ((g_variant >> 3) << 2);
+            q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 128;
+            q.dbg = 0;
             const long wgs = (long)q.stiles * q.ttiles;
-            const int cgroups = (int)std::max<long>(1, std::min<long>(std::min(nc, 20), (1536 + wgs - 1) / wgs));
-            CHK(launch_sweep3(c, q, ps.epi, cgroups, 0.0));
+            const int cgroups = choose_cgroups(wgs, nc, q.ktiles, 256, 30.0, 0.15);
+            CHK(launch_sweep4(c, q, ps.epi, cgroups));
             continue;
         }
         SweepParams sp{};
@@ -423,15 +440,16 @@ int run_pass(Ctx& c, Pass& ps) {
         int cgroups = 1;
         if (fast) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
-            cgroups = (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs));
+            cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
+                                        : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
     if (ps.store_out) { c.ws.off = mark; return 0; }
     if (!cosm) {
-        const int gdiv = stat_ok ? 64 : 32;
-        // k_sweep3 activation search (j_mode 0) sums the whole table; its columns are sample groups
-        const int fin_cols = stat_ok ? (a_search ? s3_groups : cdiv(ps.Ncols, 64)) : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
+        const int gdiv = stat_ok ? s3_gw : 32;
+        // k_sweep4 activation search (j_mode 0) sums the whole table; its columns are sample groups
+        const int fin_cols = stat_ok ? (a_search ? s3_groups : cdiv(ps.Ncols, s3_gw)) : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
         FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
                         std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));

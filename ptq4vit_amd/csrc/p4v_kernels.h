@@ -132,7 +132,8 @@ struct PackParams {
     long s_z, s_r, s_k;   // element strides of the logical [Z][R][K] view
     long s_z2; int zdiv;  // two-level batch: offset = (z / zdiv) * s_z2 + (z % zdiv) * s_z  (zdiv <= 0: single level)
     int Z, R, K;
-    int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp]
+    int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp], or [Z][Rp][C][Kp] when c_inner
+    int c_inner;
     void* dst;
     int C;
     const float* scales;  // scales[c*sc_cs + blk]; for SOS modes: split candidates / the split
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         for (int j = 0; j < PACK_CG; ++j) {
             const int c = cbeg + j;
             if (c >= cend) break;
-            const long o = (((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16;
+            const long o = p.c_inner ? ((((long)z * p.Rp + r) * p.C + c) * p.Kp + (long)kc * 16)
+                                     : ((((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16);
             if constexpr (sizeof(T) == 1) {
                 const float s = sc[j];
                 int w[4];
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_sweep3: int8 sweep with the candidate-INVARIANT operand stationary in LDS (Linear layers, K <= 768)
+// Stationary-operand int8 sweep (k_sweep4 below): parameter block
 // ------------------------------------------------------------------------------------------
 // The candidate-invariant operand (activations in the weight search, weights in the activation search) is
 // re-used by all ~100 candidates.  k_sweep2 re-streams its 128 x K tile from L2 for every candidate; here the
@@ -809,7 +811,8 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
 // (rows = output features, columns = samples); the raw_out / raw_grad tile is gathered through strides.
 struct Sweep3Params {
     const void* S; long s_zs;           // stationary plane [rows_p][ldk] (never candidate-expanded)
-    const void* T; long t_cs, t_zs;     // streaming plane  [C][rows_p][ldk]
+    const void* T; long t_cs, t_zs;     // streaming plane  [rows_p][C][ldk]: t_rs = bytes between rows (= C_chunk * ldk)
+    long t_rs;
     int ldk, ktiles;
     const float* S1;                    // [C][s_cs] combined scales
     int s_cs, sb_on_t, sb_div;          // scale block = (stationary or streaming row) / sb_div
@@ -823,15 +826,30 @@ struct Sweep3Params {
     int dbg;
 };
 
-static constexpr int SW3_NS = 3;
-static constexpr int SW3_TT = 256 * 64;  // bytes of one streaming k-tile
+// ------------------------------------------------------------------------------------------
+// k_sweep4: int8 sweep with the candidate-INVARIANT operand stationary in LDS (Linear layers, K <= 768)
+// ------------------------------------------------------------------------------------------
+// The candidate-invariant operand (activations in the weight search, weights in the activation search) is
+// re-used by all ~100 candidates: its whole 128 x K tile (K/64 k-tiles of 8 KB, <= 96 KB) is loaded into LDS
+// ONCE per workgroup and only the candidate-expanded operand streams, through a 6-deep LDS-DMA ring.
+// Tile 128 (stationary rows) x 128 (streaming rows), 8 waves as 2 x 4, 64 x 32 per wave.  What profiling the
+// earlier variants taught (profiles/):
+//   * every wave keeps TWO fragment sets: the ds_reads of k-tile t+1 are in flight while the MFMAs of k-tile t
+//     run, and the barrier only has to prove that tile t+1 has landed;
+//   * the loop is scalar-instruction bound if it does any bookkeeping: the expanded plane is therefore laid out
+//     [row][candidate][K] so the stream cursor advances by a constant 64 B per tile (no candidate wrap), the
+//     ring always issues (the plane has slack behind it; stale tiles are never consumed) so the vmcnt wait is a
+//     constant, and ring / k-tile offsets wrap with one s_cselect each.
+// The MFMA rows are the stationary rows: in the activation search the output tile is transposed (rows = output
+// features, columns = samples); the raw_out / raw_grad tile is gathered through strides.
+static constexpr int SW4_NS = 6;
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
+__global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ktiles = p.ktiles;
-    char* ring = smem + ktiles * SW2_TILE;
-    float* res = reinterpret_cast<float*>(ring + SW3_NS * SW3_TT);
+    const int ring0 = ktiles * SW2_TILE;                 // LDS byte offset of the ring
+    float* res = reinterpret_cast<float*>(smem + ring0 + SW4_NS * SW2_TILE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -841,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
     const int nwg = p.stiles * p.ttiles;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
-    const int s0 = st * 128, t0 = tt * 256;
+    const int s0 = st * 128, t0 = tt * 128;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
     if (c_lo >= c_hi) return;
@@ -853,157 +871,135 @@ __global__ __launch_bounds__(512, 2) void k_sweep3(Sweep3Params p) {
         const char* gS = (const char*)p.S + (long)(s0 + ld_row) * p.ldk + ld_chunk * 16;
         for (int kt = 0; kt < ktiles; ++kt) glds16(gS + kt * SW_BKB, smem + kt * SW2_TILE + wid * 1024);
     }
-    // ---- streaming operand cursor: wave `wid` fills rows [32*wid, 32*wid+32) of a stage (2 pieces) ---------
-    const unsigned voffT0 = (unsigned)((wid * 32 + (lane >> 2)) * p.ldk + (((lane & 3) ^ (((wid * 32 + (lane >> 2)) >> 2) & 3)) << 4));
-    const unsigned voffT1 = (unsigned)((wid * 32 + 16 + (lane >> 2)) * p.ldk + (((lane & 3) ^ (((wid * 32 + 16 + (lane >> 2)) >> 2) & 3)) << 4));
-    const char* curT = (const char*)p.T + (long)t0 * p.ldk + (long)c_lo * p.t_cs;
-    const long wrapT = p.t_cs - (long)ktiles * SW_BKB;
+    // ---- streaming operand [row][candidate][K]: one 16-row piece per wave per tile, cursor += 64 B per tile --------
+    const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
     const int total = (c_hi - c_lo) * ktiles;
-    int ikt = 0;
-    auto issue = [&](int stage) {
-        char* sdst = ring + stage * SW3_TT + wid * 2048;
-        glds16(curT + voffT0, sdst);
-        glds16(curT + voffT1, sdst + 1024);
-        curT += SW_BKB;
-        if (++ikt == ktiles) { ikt = 0; curT += wrapT; }
-    };
-    const int npre = min(SW3_NS - 1, total);
-    for (int i = 0; i < npre; ++i) issue(i);
-
-    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 ------------------------------
-    // C/D layout: col = lane&31 (streaming row), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (stationary row)
-    float u[2][2][16], w[2][2][16];
-    // Phase 1: all raw_out / weight loads back to back at clamped addresses (no per-element branches)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long toff = (long)min(t0 + wc * 64 + j * 32 + l31, p.TR - 1) * p.o_ts;
+    for (int i = 0; i < SW4_NS - 1; ++i) { glds16(curT, smem + ring0 + i * SW2_TILE + wid * 1024); curT += SW_BKB; }
+
+    // ---- candidate-invariant epilogue operands: 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming) --
+    float u[2][16], w[2][16];
+    {
+        const int tr = t0 + wc * 32 + l31;
+        const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long idx = toff + (long)min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1) * p.o_ss;
-                u[i][j][r] = p.O[idx];
-                w[i][j][r] = p.Wt[idx];
+                u[i][r] = p.O[idx];
+                w[i][r] = p.Wt[idx];
             }
-    }
-    // bias per streaming row (weight search) or per stationary row (activation search); p.bias is never NULL
-    // (the host passes a zero vector for bias-free layers)
-    float bias_t[2], bias_s[2][16];
+        float bias_s[2][16];
+        const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
+        if (!p.bias_on_t) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bias_t[j] = p.bias[p.bias_on_t ? min(t0 + wc * 64 + j * 32 + l31, p.TR - 1) : 0];
-    if (!p.bias_on_t) {
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias_s[i][r] = p.bias[min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1)];
-    }
-    // Phase 2: pure ALU
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool t_ok = (t0 + wc * 64 + j * 32 + l31) < p.TR;
+                for (int r = 0; r < 16; ++r) bias_s[i][r] = p.bias[min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1)];
+        }
+        const bool t_ok = tr < p.TR;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = t_ok && (s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
-                const float o = u[i][j][r], gw = w[i][j][r];
-                const float b = p.bias_on_t ? bias_t[j] : bias_s[i][r];
+                const float o = u[i][r], gw = w[i][r];
+                const float b = p.bias_on_t ? bias_t : bias_s[i][r];
                 float wv;
                 if (p.wt_mode == 1) wv = gw; else if (p.wt_mode == 2) wv = o; else if (p.wt_mode == 3) wv = fabsf(o); else wv = 1.0f;
-                u[i][j][r] = ok ? o - b : 0.0f;
-                w[i][j][r] = ok ? wv : 0.0f;
+                u[i][r] = ok ? o - b : 0.0f;
+                w[i][r] = ok ? wv : 0.0f;
             }
     }
-    const int blk_row = p.sb_on_t ? (t0 + wc * 64) : (s0 + wr * 64);
+    const int blk_row = p.sb_on_t ? (t0 + wc * 32) : (s0 + wr * 64);
     const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
     float* s1tab = res + per * 8;
     for (int i = lane; i < c_hi - c_lo; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
-    v16i acc[2][2];
+    v16i acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
 
-    // fragment addresses: stationary rows (runtime k-tile offset added per tile), streaming rows (immediate stage offsets)
-    const int rs0 = wr * 64 + l31, rs1 = rs0 + 32, rt0 = wc * 64 + l31, rt1 = rt0 + 32;
-    const int ss0 = (rs0 >> 2) & 3, ss1 = (rs1 >> 2) & 3, st0 = (rt0 >> 2) & 3, st1 = (rt1 >> 2) & 3;
+    // fragment addresses (LDS byte offsets): stationary rows + k-tile offset, streaming rows + stage offset
+    const int rs0 = wr * 64 + l31, rs1 = rs0 + 32, rt = wc * 32 + l31;
+    const int ss0 = (rs0 >> 2) & 3, ss1 = (rs1 >> 2) & 3, stz = (rt >> 2) & 3;
     const int aS00 = rs0 * 64 + ((g ^ ss0) << 4), aS01 = rs0 * 64 + (((2 + g) ^ ss0) << 4);
     const int aS10 = rs1 * 64 + ((g ^ ss1) << 4), aS11 = rs1 * 64 + (((2 + g) ^ ss1) << 4);
-    const char* fT00 = ring + rt0 * 64 + ((g ^ st0) << 4);
-    const char* fT01 = ring + rt0 * 64 + (((2 + g) ^ st0) << 4);
-    const char* fT10 = ring + rt1 * 64 + ((g ^ st1) << 4);
-    const char* fT11 = ring + rt1 * 64 + (((2 + g) ^ st1) << 4);
+    const int aT0 = ring0 + rt * 64 + ((g ^ stz) << 4), aT1 = ring0 + rt * 64 + (((2 + g) ^ stz) << 4);
+    const int issue_base = ring0 + wid * 1024;
 
-    int kt = 0, c = c_lo;
-    auto tile = [&](int it, auto stage_c) {
-        constexpr int ST = decltype(stage_c)::value;
-        constexpr int SO = ST * SW3_TT;
-        if (it + 1 < total) wait_vmcnt<2>(); else wait_vmcnt<0>();   // ring depth 3: one tile (2 pieces) may stay in flight
-        if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
-        if (it + SW3_NS - 1 < total && !(p.dbg & 1)) issue((ST + SW3_NS - 1) % SW3_NS);
-        if (p.dbg & 2) { if (++kt == ktiles) { kt = 0; ++c; } return; }
-        const char* sk = (p.dbg & 8) ? smem : smem + kt * SW2_TILE;
-        // software pipeline inside the tile: the second K-half's fragments are fetched while the first
-        // half's MFMAs run, so only the first four reads are exposed after the barrier
-        const v4i s00 = *reinterpret_cast<const v4i*>(sk + aS00);
-        const v4i s10 = *reinterpret_cast<const v4i*>(sk + aS10);
-        const v4i t00 = *reinterpret_cast<const v4i*>(fT00 + SO);
-        const v4i t10 = *reinterpret_cast<const v4i*>(fT10 + SO);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t00, acc[0][0], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        const v4i s01 = *reinterpret_cast<const v4i*>(sk + aS01);
-        const v4i s11 = *reinterpret_cast<const v4i*>(sk + aS11);
-        const v4i t01 = *reinterpret_cast<const v4i*>(fT01 + SO);
-        const v4i t11 = *reinterpret_cast<const v4i*>(fT11 + SO);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t00, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s00, t10, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s10, t10, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s01, t01, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t01, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s01, t11, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(s11, t11, acc[1][1], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 7, 0);
-        if (++kt == ktiles && (p.dbg & 16)) { kt = 0; ++c; }
-        else if (kt == ktiles) {
-            const float s1 = s1tab[(c - c_lo) * 8 + wid];
-            // packed-f32 epilogue (v_pk_fma_f32 / v_pk_mul_f32): two output elements per VALU instruction
+    struct Frag { v4i s00, s10, s01, s11, t0, t1; };
+    Frag fa, fb;
+    // wave-uniform loop state (SGPRs): byte offsets of the stage / stationary k-tile of the tile to READ next, the
+    // stage to ISSUE into next, and the k-tile counter of the tile to COMPUTE next
+    int rd_stage = 0, is_stage = (SW4_NS - 1) * SW2_TILE, rd_koff = 0;
+    const int koff_end = ktiles * SW2_TILE;
+    int kt = 0, cidx = 0;
+    auto read_frags = [&](Frag& f) __attribute__((always_inline)) {
+        f.s00 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS00);
+        f.s10 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS10);
+        f.t0 = *reinterpret_cast<const v4i*>(smem + rd_stage + aT0);
+        f.s01 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS01);
+        f.s11 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS11);
+        f.t1 = *reinterpret_cast<const v4i*>(smem + rd_stage + aT1);
+        rd_stage = (rd_stage + SW2_TILE == SW4_NS * SW2_TILE) ? 0 : rd_stage + SW2_TILE;
+        rd_koff = (rd_koff + SW2_TILE == koff_end) ? 0 : rd_koff + SW2_TILE;
+    };
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s00, f.t0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s10, f.t0, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s01, f.t1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s11, f.t1, acc[1], 0, 0, 0);
+        if (++kt == ktiles) {
+            const float s1 = s1tab[cidx * 8 + wid];
             v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const v2f a = {(float)acc[i][j][r], (float)acc[i][j][r + 1]};
-                        const v2f uu = {u[i][j][r], u[i][j][r + 1]};
-                        const v2f ww = {w[i][j][r], w[i][j][r + 1]};
-                        const v2f d = uu - a * s1;
-                        if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
-                        else if (EPI == EPI_SQ) sum2 = d * d + sum2;
-                        else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
-                        else sum2 = (ww * d) * d + sum2;
-                        acc[i][j][r] = 0;
-                        acc[i][j][r + 1] = 0;
-                    }
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f a = {(float)acc[i][r], (float)acc[i][r + 1]};
+                    const v2f uu = {u[i][r], u[i][r + 1]};
+                    const v2f ww = {w[i][r], w[i][r + 1]};
+                    const v2f d = uu - a * s1;
+                    if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                    else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                    else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                    else sum2 = (ww * d) * d + sum2;
+                    acc[i][r] = 0;
+                    acc[i][r + 1] = 0;
+                }
             float sum = sum2.x + sum2.y;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
+            if (lane == 0) res[cidx * 8 + wid] = sum;
             kt = 0;
-            ++c;
+            ++cidx;
         }
     };
-    for (int it = 0; it < total; it += SW3_NS) {
-        tile(it, std::integral_constant<int, 0>{});
-        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{});
-        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{});
-    }
-    __syncthreads();
+    // step: tile `it` is in `cur`.  Prove tile it+1 landed (own piece waited for, then the barrier), issue tile
+    // it+NS-1 into the stage of tile it-1 (everybody finished reading it one step ago), start the ds_reads of tile
+    // it+1 into the idle fragment set and run the MFMAs of tile it.  No tail conditionals: the ring keeps issuing
+    // (slack behind the plane) so exactly NS-3 younger pieces are outstanding at every wait.
+    auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
+        wait_vmcnt<SW4_NS - 3>();
+        __builtin_amdgcn_s_barrier();
+        glds16(curT, smem + issue_base + is_stage);
+        curT += SW_BKB;
+        is_stage = (is_stage + SW2_TILE == SW4_NS * SW2_TILE) ? 0 : is_stage + SW2_TILE;
+        read_frags(nxt);
+        mma(cur);
+    };
+    // tile 0 (older loads -- the stationary operand -- complete first: vmcnt is in order)
+    wait_vmcnt<SW4_NS - 2>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(fa);
+    int it = 0;
+    for (; it + 1 < total; it += 2) { step(fa, fb); step(fb, fa); }
+    if (it < total) step(fa, fb);
+    __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)(st * 2 + (wv >> 2)) * p.NG + tt * 4 + (wv & 3)] = res[i];
