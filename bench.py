@@ -156,13 +156,18 @@ def main():
         if rank == 0 and st["sweep_i8_launches"] > 0:
             mine = {n: m for n, m in wrapped.items() if cal_r.owner[n] == rank}
             lin, mm, conv = search_macs(mine, args.calib, tokens, heads, head_dim)
-            algo_ops = 2.0 * (lin + mm)            # ops of the reference GEMMs rank 0 ran on the int8 sweeps
+            # ops of the reference GEMMs that the executed int8 sweep launches stand for (unpadded, one plane per
+            # candidate); passes restored from the memo are not launched and are not counted here
+            algo_ops = 2.0 * st["sweep_i8_alg_macs"]
+            ref_ops = 2.0 * (lin + mm)             # what the reference would run for rank 0's modules (no memo)
             issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-            roof = {"bound": "mfma", "kernel": "k_sweep3 + k_sweep2 (int8 candidate sweeps)", "achieved": algo_ops / secs / 1e12, "peak": peak,
+            roof = {"bound": "mfma", "kernel": "k_sweep4 + k_sweep2 (int8 candidate sweeps)", "achieved": algo_ops / secs / 1e12, "peak": peak,
                     "unit": "TOP/s", "frac": algo_ops / secs / 1e12 / peak, "traffic": None,
                     "issued": issued_ops / secs / 1e12, "launches": st["sweep_i8_launches"],
+                    "reference_ops_fraction_executed": algo_ops / ref_ops,
+                    "memo_hits": st["memo_hits"], "memo_misses": st["memo_misses"],
                     "avg_launch_ms": st["sweep_i8_ms"] / st["sweep_i8_launches"],
                     "f32_sweep_ms": st["sweep_f32_ms"], "f32_sweep_tflops": (2.0 * st["sweep_f32_macs"] / (st["sweep_f32_ms"] * 1e-3) / 1e12) if st["sweep_f32_ms"] else None}
 

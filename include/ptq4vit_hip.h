@@ -70,7 +70,7 @@ typedef struct p4v_linear_desc {
     int32_t twin_postgelu;
     int32_t init_layerwise;
     int32_t has_bias;
-    int32_t reserved;
+    int32_t reserved;     /* bit 0: force the generic fp32-operand path; bit 1: disable pass memoisation */
 } p4v_linear_desc;
 
 size_t p4v_linear_workspace_bytes(const p4v_linear_desc* desc);
@@ -171,6 +171,10 @@ typedef struct p4v_kernel_stats {
     double sweep_f32_ms;
     int64_t sweep_f32_launches;
     double sweep_f32_macs;
+    double sweep_i8_alg_macs;  /* MACs of the reference GEMMs those launches stand for (unpadded, one plane) */
+    double sweep_f32_alg_macs;
+    int64_t memo_hits;      /* search passes skipped because their input interval had already been evaluated */
+    int64_t memo_misses;    /* search passes executed (with memoisation enabled)                            */
 } p4v_kernel_stats;
 
 /* Enable (1) / disable (0) per-launch HIP-event timing of the sweep kernels (adds a sync per launch). */

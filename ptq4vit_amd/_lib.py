@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptq4vit_hip.so")
+LIB_PATH = os.environ.get("P4V_LIB") or os.path.join(_HERE, "csrc", "libptq4vit_hip.so")   # P4V_LIB: tuning builds only
 
 METRICS = {
     "L1_norm": 0,
@@ -40,7 +40,9 @@ class ConvDesc(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("sweep_i8_ms", C.c_double), ("sweep_i8_launches", C.c_int64), ("sweep_i8_macs", C.c_double),
-                ("sweep_f32_ms", C.c_double), ("sweep_f32_launches", C.c_int64), ("sweep_f32_macs", C.c_double)]
+                ("sweep_f32_ms", C.c_double), ("sweep_f32_launches", C.c_int64), ("sweep_f32_macs", C.c_double),
+                ("sweep_i8_alg_macs", C.c_double), ("sweep_f32_alg_macs", C.c_double),
+                ("memo_hits", C.c_int64), ("memo_misses", C.c_int64)]
 
 
 EXPORTS = [

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -68,7 +69,8 @@ struct Arena {
 };
 
 // ---- optional per-launch timing of the sweep kernels (bench.py roofline) -----------------------
-struct StatRec { hipEvent_t a, b; int kind; double macs; };
+struct StatRec { hipEvent_t a, b; int kind; double macs, alg; };
+thread_local double g_alg_macs_cand = 0;   // unpadded single-plane MACs of one candidate of the pass being launched
 std::mutex g_stat_mu;
 bool g_stat_on = false;
 std::vector<StatRec> g_stat_recs;
@@ -179,7 +181,7 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
 int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW4_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2;
+    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW4_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2 + 256;
     dim3 grid(p.stiles * p.ttiles, 1, cgroups), block(512);
     bool timed;
     StatRec rec{};
@@ -192,6 +194,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         HIPCHK(hipEventCreate(&rec.b));
         rec.kind = 0;
         rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0);
+        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
 #define P4V_LAUNCH4(E)                                                                                         \
@@ -233,6 +236,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         rec.kind = i8 ? 0 : 1;
         const double kelems = (double)p.ldk / (i8 ? 1 : 4);
         rec.macs = (double)p.mtiles * SW_BM * (double)p.ntiles * SW_BN * kelems * p.Z * (p.c1 - p.c0) * (twin ? 2 : 1);
+        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
@@ -327,6 +331,7 @@ int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_u
 
 int run_pass(Ctx& c, Pass& ps) {
     const int esz = ps.i8 ? 1 : 4;
+    g_alg_macs_cand = (double)ps.Mrows * ps.Ncols * ps.K * ps.Z;
     const int Kp = (int)rup(ps.K, 64 / esz);          // 64-byte k-tiles
     // stationary-operand sweep (k_sweep4): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
     const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
@@ -406,7 +411,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.c0 = c0; q.c1 = c0 + nc;
             q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
             q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 128;
-            q.dbg = 0;
+            q.dbg = g_variant & 3;
             const long wgs = (long)q.stiles * q.ttiles;
             const int cgroups = choose_cgroups(wgs, nc, q.ktiles, 256, 30.0, 0.15);
             CHK(launch_sweep4(c, q, ps.epi, cgroups));
@@ -465,6 +470,37 @@ int run_pass(Ctx& c, Pass& ps) {
     c.ws.off = mark;   // scratch of this pass is reusable by the next one (same stream => ordered)
     return 0;
 }
+
+// ---- exact memoisation of search passes ---------------------------------------------------------------------
+// Every candidate table is built once from the initial interval (reference linear.py:544-545), so a search pass
+// is a deterministic function of the counterpart's CURRENT interval only.  Rounds 2-3 often see an interval that
+// was already evaluated (the alternation has converged): the pass would recompute, bit for bit, the selection it
+// produced before.  Such a pass is skipped and its recorded output restored.  Exact by construction (the kernels
+// are deterministic); disabled when the caller asks for score tables, with desc.reserved bit 1, or P4V variant 512.
+struct PassMemo {
+    struct Entry { std::vector<float> in, out; };
+    std::vector<Entry> entries;
+    const std::vector<float>* find(const std::vector<float>& in) const {
+        for (const auto& e : entries)
+            if (e.in.size() == in.size() && std::memcmp(e.in.data(), in.data(), in.size() * sizeof(float)) == 0) return &e.out;
+        return nullptr;
+    }
+};
+
+int read_dev(Ctx& c, const float* d, int n, std::vector<float>& h) {
+    h.resize(n);
+    HIPCHK(hipMemcpyAsync(h.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
+    HIPCHK(hipStreamSynchronize(c.st));
+    return 0;
+}
+
+int write_dev(Ctx& c, float* d, const std::vector<float>& h) {
+    HIPCHK(hipMemcpyAsync(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, c.st));
+    HIPCHK(hipStreamSynchronize(c.st));   // h may go out of scope
+    return 0;
+}
+
+std::atomic<long> g_memo_hits{0}, g_memo_misses{0};
 
 PackParams pack2d(const float* src, long rows, long cols, long ld) {
     PackParams p{};
@@ -555,9 +591,17 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         return op;
     };
 
+    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    PassMemo memo_w, memo_a;
+    std::vector<float> key, val;
     for (int round = 0; round < d->search_round; ++round) {
         // ================= weight search (linear.py:455-495) =================
-        for (int h = 0; h < nH; ++h) {
+        bool skip_w = false;
+        if (memo_on) {
+            CHK(read_dev(c, a_iv, nA, key));
+            if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
+        }
+        for (int h = 0; h < nH && !skip_w; ++h) {
             Pass ps{};
             ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
             const float* wc = w_cands;
@@ -607,8 +651,14 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass(c, ps));
         }
+        if (memo_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
         // ================= activation search (linear.py:497-533 / 609-642) =================
-        for (int a = 0; a < nA; ++a) {
+        bool skip_a = false;
+        if (memo_on) {
+            CHK(read_dev(c, w_iv, nV * nH, key));
+            if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
+        }
+        for (int a = 0; a < nA && !skip_a; ++a) {
             Pass ps{};
             ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
             const float* ac = a_cands;
@@ -667,6 +717,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass(c, ps));
         }
+        if (memo_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
     }
     return 0;
 }
@@ -746,10 +797,25 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
                ps.cos_ZB = Z; ps.cos_ZV = 1; }
     };
 
+    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    PassMemo memo_A, memo_B;
+    std::vector<float> key, val;
+    const int nAiv = d->sos ? 1 : H;
     for (int round = 0; round < d->search_round; ++round) {
         float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * H : nullptr;
         int32_t* bo = best_out ? best_out + (long)(round * 2) * H : nullptr;
-        if (!d->sos) {
+        // the A search (or, with sos, the split search against the RAW B: a function of nothing -> always a hit after round 1)
+        bool skip_A = false;
+        if (memo_on) {
+            if (d->sos) key.assign(1, 0.0f); else CHK(read_dev(c, B_iv, H, key));
+            if (const auto* hit = memo_A.find(key)) {
+                if (d->sos) { std::vector<float> sp(1, (*hit)[0]), ai(1, (*hit)[1]); CHK(write_dev(c, split, sp)); CHK(write_dev(c, A_iv, ai)); }
+                else CHK(write_dev(c, A_iv, *hit));
+                skip_A = true; g_memo_hits++;
+            }
+        }
+        if (skip_A) {
+        } else if (!d->sos) {
             // ---- A search, B fixed at its current head-wise interval (matmul.py:483-522) ----
             Pass ps{};
             common(ps);
@@ -778,7 +844,17 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.scores_out = (d->eq_n >= NSPLIT) ? so : nullptr; ps.scores_out_ld = H; ps.best_out = bo;
             CHK(run_pass(c, ps));
         }
-        {
+        if (memo_on && !skip_A) {
+            if (d->sos) { std::vector<float> sp, ai; CHK(read_dev(c, split, 1, sp)); CHK(read_dev(c, A_iv, 1, ai)); val = {sp[0], ai[0]}; }
+            else CHK(read_dev(c, A_iv, nAiv, val));
+            memo_A.entries.push_back({key, val}); g_memo_misses++;
+        }
+        bool skip_B = false;
+        if (memo_on) {
+            CHK(read_dev(c, A_iv, nAiv, key));
+            if (const auto* hit = memo_B.find(key)) { CHK(write_dev(c, B_iv, *hit)); skip_B = true; g_memo_hits++; }
+        }
+        if (!skip_B) {
             // ---- B search, A fixed (matmul.py:524-563); with sos, A is the two-range twin (matmul.py:595-598) ----
             Pass ps{};
             common(ps);
@@ -803,6 +879,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.scores_out = so ? so + (long)d->eq_n * H : nullptr; ps.scores_out_ld = H;
             ps.best_out = bo ? bo + H : nullptr;
             CHK(run_pass(c, ps));
+            if (memo_on) { CHK(read_dev(c, B_iv, H, val)); memo_B.entries.push_back({key, val}); g_memo_misses++; }
         }
     }
     return 0;
@@ -895,10 +972,19 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
         }
     };
 
+    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    PassMemo memo_w, memo_a;
+    std::vector<float> key, val;
     for (int round = 0; round < d->search_round; ++round) {
         float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * nw : nullptr;
         int32_t* bo = best_out ? best_out + (long)(round * 2) * nw : nullptr;
-        {   // ---- weight search (conv.py:526-557 / 365-396) ----
+        bool skip_w = false;
+        if (memo_on) {
+            // with a_bit >= 32 the input is never quantised: the weight search depends on nothing (conv.py:544)
+            if (aquant) CHK(read_dev(c, a_iv, 1, key)); else key.assign(1, 0.0f);
+            if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
+        }
+        if (!skip_w) {   // ---- weight search (conv.py:526-557 / 365-396) ----
             Pass ps{};
             setup(ps, true);
             ps.nj = nw;
@@ -908,8 +994,14 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             ps.cands = w_cands; ps.cand_cs = nw; ps.cand_js = 1; ps.interval = w_iv; ps.out_js = 1;
             ps.scores_out = so; ps.scores_out_ld = nw; ps.best_out = bo;
             CHK(run_pass(c, ps));
+            if (memo_on) { CHK(read_dev(c, w_iv, nw, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
         }
-        if (aquant) {  // ---- activation search (conv.py:559-589), channel-wise class only ----
+        bool skip_a = false;
+        if (memo_on && aquant) {
+            CHK(read_dev(c, w_iv, nw, key));
+            if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
+        }
+        if (aquant && !skip_a) {  // ---- activation search (conv.py:559-589), channel-wise class only ----
             Pass ps{};
             setup(ps, false);
             ps.nj = 1; ps.j_mode = 0; ps.norm = 1.0 / ((double)L * oc);
@@ -917,6 +1009,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             ps.scores_out = so ? so + (long)d->eq_n * nw : nullptr; ps.scores_out_ld = nw;
             ps.best_out = bo ? bo + nw : nullptr;
             CHK(run_pass(c, ps));
+            if (memo_on) { CHK(read_dev(c, a_iv, 1, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
         }
     }
     return 0;
@@ -1020,8 +1113,8 @@ static int stats_drain_locked() {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        if (r.kind == 0) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; }
-        else { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; }
+        if (r.kind == 0) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        else { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }
@@ -1033,6 +1126,7 @@ int p4v_stats_reset(void) {
     std::lock_guard<std::mutex> lk(g_stat_mu);
     int r = stats_drain_locked();
     g_stats = p4v_kernel_stats{};
+    g_memo_hits = 0; g_memo_misses = 0;
     return r;
 }
 
@@ -1040,6 +1134,7 @@ int p4v_stats_get(p4v_kernel_stats* out) {
     if (!out) return fail(P4V_ERR_INVALID, "stats_get: null");
     std::lock_guard<std::mutex> lk(g_stat_mu);
     int r = stats_drain_locked();
+    g_stats.memo_hits = g_memo_hits.load(); g_stats.memo_misses = g_memo_misses.load();
     *out = g_stats;
     return r;
 }

@@ -74,7 +74,7 @@ def metric_id(name):
 
 
 def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
-                     n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False):
+                     n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False, memoize=True):
     """Run calibration_step2 of a (post-GELU) Linear on the GPU.  Returns (w_interval[n_V*n_H], a_interval[n_a], scores, best)."""
     lib = _lib.load()
     dev = device_of(x, weight)
@@ -86,7 +86,7 @@ def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alp
     tokens = x.numel() // (batch * K)
     N = weight.shape[0]
     d = _lib.LinearDesc(batch, tokens, K, N, n_V, n_H, n_a, w_bit, a_bit, metric_id(metric), eq_n, search_round,
-                        int(postgelu), int(init_layerwise), int(bias is not None), int(force_f32))
+                        int(postgelu), int(init_layerwise), int(bias is not None), int(force_f32) | (0 if memoize else 2))
     need = lib.p4v_linear_workspace_bytes(C.byref(d))
     if need == 0:
         _lib.check(-1 if not lib.p4v_last_error() else -2, "p4v_linear_workspace_bytes")

@@ -199,3 +199,18 @@ def test_sharded_calibration_matches_single_rank():
         assert out.keys() == single.keys()
         for k in single:
             np.testing.assert_array_equal(out[k], single[k], err_msg=f"rank {rank}: {k}")
+
+
+def test_pass_memoisation_is_exact(vitb_qkv):
+    """Rounds whose input interval was already evaluated are restored from the memo instead of recomputed: the
+    calibrated intervals must be bit-identical to the full computation, and some passes must actually be skipped."""
+    from ptq4vit_amd import engine
+    engine.stats_reset()
+    memo = engine.linear_calibrate(**vitb_qkv, **HP)                      # memoised (default)
+    st = engine.stats_get()
+    full = engine.linear_calibrate(**vitb_qkv, memoize=False, **HP)       # all 6 passes computed
+    ref = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)     # score tables requested -> never memoised
+    torch.cuda.synchronize()
+    assert torch.equal(memo[0], full[0]) and torch.equal(memo[1], full[1])
+    assert torch.equal(memo[0], ref[0]) and torch.equal(memo[1], ref[1])
+    assert st["memo_hits"] + st["memo_misses"] == 6 and st["memo_misses"] >= 2
