@@ -178,11 +178,35 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
     return 0;
 }
 
-int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
+#ifdef P4V_TRACE
+// tuning builds only (-DP4V_TRACE): per-workgroup timestamps of the stationary sweeps, appended to $P4V_TRACE_FILE
+unsigned long long* g_trace = nullptr;
+int trace_attach(Sweep3Params& p) {
+    if (!g_trace) HIPCHK(hipMalloc(&g_trace, sizeof(unsigned long long) * 16 * 65536));
+    p.trace = g_trace;
+    return 0;
+}
+int trace_dump(Ctx& c, dim3 grid, int ktiles) {
+    if (!getenv("P4V_TRACE_FILE")) return 0;
+    const size_t n = (size_t)grid.x * grid.z * 16;
+    HIPCHK(hipStreamSynchronize(c.st));
+    std::vector<unsigned long long> h(n);
+    HIPCHK(hipMemcpy(h.data(), g_trace, n * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(getenv("P4V_TRACE_FILE"), "ab");
+    unsigned long long hdr[4] = {0xABCDull, grid.x, grid.z, (unsigned long long)ktiles};
+    fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, n, f); fclose(f);
+    return 0;
+}
+#endif
+
+int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair) {
     if (c.dry) return 0;
-    const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)SW4_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2 + 256;
+    const int per = pair ? 2 * cdiv(p.c1 - p.c0, 2 * cgroups) : cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)p.ktiles * SW2_TILE + (size_t)(pair ? SW5_NP * 2 : SW4_NS) * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2 + 256;
     dim3 grid(p.stiles * p.ttiles, 1, cgroups), block(512);
+#ifdef P4V_TRACE
+    CHK(trace_attach(const_cast<Sweep3Params&>(p)));
+#endif
     bool timed;
     StatRec rec{};
     {
@@ -204,7 +228,13 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
             HIPCHK(hipFuncSetAttribute((const void*)k_sweep4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep4<E>), grid, block, lds, c.st, p);                                          \
+        static bool attr5_set = false;                                                                         \
+        if (!attr5_set) {                                                                                      \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep5<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr5_set = true;                                                                                  \
+        }                                                                                                      \
+        if (pair) hipLaunchKernelGGL((k_sweep5<E>), grid, block, lds, c.st, p);                                \
+        else hipLaunchKernelGGL((k_sweep4<E>), grid, block, lds, c.st, p);                                     \
     } while (0)
     switch (epi) {
         case EPI_SQ_W: P4V_LAUNCH4(EPI_SQ_W); break;
@@ -214,6 +244,70 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     }
 #undef P4V_LAUNCH4
     HIPCHK(hipGetLastError());
+#ifdef P4V_TRACE
+    CHK(trace_dump(c, grid, p.ktiles));
+#endif
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        g_stat_recs.push_back(rec);
+    }
+    return 0;
+}
+
+template <int KT>
+int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds) {
+#define P4V_LAUNCH6(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep6<E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep6<E, KT>), grid, dim3(256), lds, c.st, p);                                  \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH6(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH6(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH6(EPI_ABS); break;
+        default: P4V_LAUNCH6(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH6
+    return 0;
+}
+
+// k_sweep6 (stationary operand in registers): K = 192 / 384 / 768 bytes, the Linear layers of ViT/DeiT-T/S/B
+bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 6 || ktiles == 12; }
+
+int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
+    if (c.dry) return 0;
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)per * 8 * sizeof(float) + (size_t)per * 4 * sizeof(float) + 256;
+    dim3 grid(p.stiles * p.ttiles, 1, cgroups);
+#ifdef P4V_TRACE
+    CHK(trace_attach(const_cast<Sweep3Params&>(p)));
+#endif
+    bool timed;
+    StatRec rec{};
+    {
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        timed = g_stat_on;
+    }
+    if (timed) {
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        rec.kind = 0;
+        rec.macs = (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
+        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
+        HIPCHK(hipEventRecord(rec.a, c.st));
+    }
+    int r = p.ktiles == 12 ? launch_sweep6_kt<12>(c, p, epi, grid, lds)
+          : p.ktiles == 6 ? launch_sweep6_kt<6>(c, p, epi, grid, lds) : launch_sweep6_kt<3>(c, p, epi, grid, lds);
+    if (r) return r;
+    HIPCHK(hipGetLastError());
+#ifdef P4V_TRACE
+    CHK(trace_dump(c, grid, p.ktiles));
+#endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
         std::lock_guard<std::mutex> lk(g_stat_mu);
@@ -339,8 +433,12 @@ int run_pass(Ctx& c, Pass& ps) {
     const bool stat_ok = !ps.store_out && ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
                          ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
                          rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
+    const bool regs6 = stat_ok && sweep6_supported(Kp / SW_BKB) && !(g_variant & 16);   // k_sweep6: stationary operand in registers
+    const bool pairs = stat_ok && !regs6 && !(g_variant & 8);                           // k_sweep5: two candidates per pass
     const int PADR = SW_BM;
-    const int Mp = (int)rup(ps.Mrows, PADR), Np = (int)rup(ps.Ncols, PADR);
+    // k_sweep6 tiles the stationary operand (the one that is NOT candidate-expanded) in 256-row slabs
+    const int Mp = (int)rup(ps.Mrows, (regs6 && !ps.row.expanded) ? 256 : PADR);
+    const int Np = (int)rup(ps.Ncols, (regs6 && !ps.col.expanded) ? 256 : PADR);
     const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
     const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
     const long col_plane1 = ps.col_zs_shared ? (long)Np * Kp * esz : col_plane;
@@ -349,9 +447,11 @@ int run_pass(Ctx& c, Pass& ps) {
 
     const size_t mark = c.ws.off;
     const size_t slack = stat_ok ? 4096 : 0;   // k_sweep4's ring keeps issuing a few tiles past the last candidate
-    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk : 1) + slack);
+    if (pairs && chunk > 1) chunk &= ~1;                  // chunks start on a candidate pair
+    const int chunk_al = pairs ? ((chunk + 1) & ~1) : chunk;   // an odd count is padded to a whole pair
+    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
-    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk : 1) + slack);
+    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk_al : 1) + slack);
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
@@ -383,7 +483,7 @@ int run_pass(Ctx& c, Pass& ps) {
         pk.Rp = Rp; pk.Kp = Kp; pk.dst = buf;
         pk.Z = shared ? 1 : ps.Z;
         pk.C = op.expanded ? nc : 1;
-        pk.c_inner = (stat_ok && op.expanded) ? 1 : 0;   // k_sweep4 streams [row][candidate][K]
+        pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
         if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
         return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
     };
@@ -401,7 +501,7 @@ int run_pass(Ctx& c, Pass& ps) {
             Sweep3Params q{};
             q.S = a_search ? colbuf : rowbuf; q.s_zs = 0;
             q.T = a_search ? rowbuf : colbuf; q.t_cs = 0; q.t_zs = 0;
-            q.t_rs = (long)nc * Kp;                      // [row][candidate][K] layout written by k_pack (c_inner)
+            q.t_rs = (long)(pairs ? ((nc + 1) & ~1) : nc) * Kp;   // [row][candidate][K] layout written by k_pack (c_inner)
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.s_cs = ps.s_cs; q.sb_on_t = a_search ? 0 : 1; q.sb_div = std::max(1, ps.sb_div);
             q.bias = ps.bias ? ps.bias : zero_bias; q.bias_on_t = a_search ? 0 : 1;
@@ -412,9 +512,15 @@ int run_pass(Ctx& c, Pass& ps) {
             q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
             q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 128;
             q.dbg = g_variant & 3;
+            if (regs6) {
+                q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = (a_search ? Mp : Np) / 64;
+                const int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
+                CHK(launch_sweep6(c, q, ps.epi, cg6));
+                continue;
+            }
             const long wgs = (long)q.stiles * q.ttiles;
             const int cgroups = choose_cgroups(wgs, nc, q.ktiles, 256, 30.0, 0.15);
-            CHK(launch_sweep4(c, q, ps.epi, cgroups));
+            CHK(launch_sweep4(c, q, ps.epi, cgroups, pairs));
             continue;
         }
         SweepParams sp{};

@@ -132,7 +132,8 @@ struct PackParams {
     long s_z, s_r, s_k;   // element strides of the logical [Z][R][K] view
     long s_z2; int zdiv;  // two-level batch: offset = (z / zdiv) * s_z2 + (z % zdiv) * s_z  (zdiv <= 0: single level)
     int Z, R, K;
-    int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp], or [Z][Rp][C][Kp] when c_inner
+    int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp], [Z][Rp][C][Kp] when c_inner == 1,
+                          // [Z][Rp][C/2][Kp/64][2][64] (candidate pairs interleaved per k-tile) when c_inner == 2
     int c_inner;
     void* dst;
     int C;
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         for (int j = 0; j < PACK_CG; ++j) {
             const int c = cbeg + j;
             if (c >= cend) break;
-            const long o = p.c_inner ? ((((long)z * p.Rp + r) * p.C + c) * p.Kp + (long)kc * 16)
+            const long o = p.c_inner == 2 ? ((((long)z * p.Rp + r) * ((p.C + 1) & ~1) + (c & ~1)) * p.Kp + (long)(kc >> 2) * 128 + (c & 1) * 64 + (kc & 3) * 16)
+                         : p.c_inner ? ((((long)z * p.Rp + r) * p.C + c) * p.Kp + (long)kc * 16)
                                      : ((((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16);
             if constexpr (sizeof(T) == 1) {
                 const float s = sc[j];
@@ -601,6 +603,24 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// Wave-wide fp32 sum on the VALU (DPP), result valid in lane 63.  __shfl_xor lowers to ds_bpermute_b32: six LDS
+// round trips with a full lgkmcnt(0) each -- about 0.4 us per reduction when nothing else runs on the SIMD.
+// Fixed combination order: deterministic.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl, auto rmask) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                      decltype(rmask)::value, 0xf, false));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});   // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});   // row_mirror: every lane = its row's sum
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast15 -> rows 1, 3
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool TWIN, int EPI>
@@ -824,6 +844,9 @@ struct Sweep3Params {
     float* part; long p_cs; int NG;     // part[c*p_cs + (st*2+wr)*NG + tt*4+wc]
     int stiles, ttiles;
     int dbg;
+#ifdef P4V_TRACE
+    unsigned long long* trace;          // tuning builds only: [workgroup][8] timestamps (100 MHz) + hw id
+#endif
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1004,6 +1027,454 @@ __global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)(st * 2 + (wv >> 2)) * p.NG + tt * 4 + (wv & 3)] = res[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep5: k_sweep4 with TWO candidates per pass (candidate pair = one "pair-step" per k-tile)
+// ------------------------------------------------------------------------------------------
+// k_sweep4's inner loop is bound by LDS bandwidth, not by the matrix pipe: per k-tile every wave reads 4 KB of
+// stationary and 2 KB of streaming fragments for 4 MFMAs (1.5 KB / MFMA; 8 waves -> 48 KB + 8 KB of LDS-DMA
+// writes = 448 clk of the 128 B/clk LDS against 256 clk of MFMA; measured 458, tools/ubench_mfma.hip).  The
+// candidate-invariant state -- stationary fragments and the raw_out / raw_grad registers -- can be shared by
+// several candidates: here each wave keeps two accumulator sets and feeds both candidates of a pair from ONE read
+// of the stationary fragments (1 KB / MFMA -> 320 clk per candidate-step).  The expanded plane is laid out
+// [row][pair][k-tile][2][64 B] (k_pack c_inner = 2) so that the stream cursor still advances by a constant
+// (128 B per pair-step).  Ring = 3 pair-stages of 2 x 8 KB; every step ends with lgkmcnt(0), so the stage whose
+// fragments were read during step t-1 can be refilled right after the barrier of step t (two steps of L2 latency
+// covered with three stages).  An odd candidate count runs one padding candidate whose score is dropped.
+static constexpr int SW5_NP = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef P4V_TRACE
+    unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+    if (threadIdx.x == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[8] = __builtin_amdgcn_s_memtime(); trc[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); trc[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
+#endif
+    const int ktiles = p.ktiles;
+    const int ring0 = ktiles * SW2_TILE;                 // LDS byte offset of the ring
+    float* res = reinterpret_cast<float*>(smem + ring0 + SW5_NP * 2 * SW2_TILE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.stiles * p.ttiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
+    const int s0 = st * 128, t0 = tt * 128;
+    const int per = 2 * ((p.c1 - p.c0 + 2 * gridDim.z - 1) / (2 * gridDim.z));   // even: groups start on a pair
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    {
+        const char* gS = (const char*)p.S + (long)(s0 + ld_row) * p.ldk + ld_chunk * 16;
+        for (int kt = 0; kt < ktiles; ++kt) glds16(gS + kt * SW_BKB, smem + kt * SW2_TILE + wid * 1024);
+    }
+    // streaming operand [row][pair][k-tile][2][64 B]: two 16-row pieces per wave per pair-step, cursor += 128 B
+    const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
+    const int total = ((c_hi - c_lo + 1) >> 1) * ktiles;
+#pragma unroll
+    for (int i = 0; i < SW5_NP; ++i) {
+        glds16(curT, smem + ring0 + i * 2 * SW2_TILE + wid * 1024);
+        glds16(curT + SW_BKB, smem + ring0 + i * 2 * SW2_TILE + SW2_TILE + wid * 1024);
+        curT += 2 * SW_BKB;
+    }
+
+    // ---- candidate-invariant epilogue operands: 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming) --
+    float u[2][16], w[2][16];
+    {
+        const int tr = t0 + wc * 32 + l31;
+        const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long idx = toff + (long)min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1) * p.o_ss;
+                u[i][r] = p.O[idx];
+                w[i][r] = p.Wt[idx];
+            }
+        float bias_s[2][16];
+        const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
+        if (!p.bias_on_t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias_s[i][r] = p.bias[min(s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1)];
+        }
+        const bool t_ok = tr < p.TR;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t_ok && (s0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
+                const float o = u[i][r], gw = w[i][r];
+                const float b = p.bias_on_t ? bias_t : bias_s[i][r];
+                float wv;
+                if (p.wt_mode == 1) wv = gw; else if (p.wt_mode == 2) wv = o; else if (p.wt_mode == 3) wv = fabsf(o); else wv = 1.0f;
+                u[i][r] = ok ? o - b : 0.0f;
+                w[i][r] = ok ? wv : 0.0f;
+            }
+    }
+    const int blk_row = p.sb_on_t ? (t0 + wc * 32) : (s0 + wr * 64);
+    const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
+    float* s1tab = res + per * 8;
+    for (int i = lane; i < per; i += 64) s1tab[i * 8 + wid] = (p.S1 && c_lo + i < c_hi) ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+
+    v16i acc[2][2];   // [candidate of the pair][stationary 32-row half]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][i][r] = 0;
+
+    const int rs0 = wr * 64 + l31, rs1 = rs0 + 32, rt = wc * 32 + l31;
+    const int ss0 = (rs0 >> 2) & 3, ss1 = (rs1 >> 2) & 3, stz = (rt >> 2) & 3;
+    const int aS00 = rs0 * 64 + ((g ^ ss0) << 4), aS01 = rs0 * 64 + (((2 + g) ^ ss0) << 4);
+    const int aS10 = rs1 * 64 + ((g ^ ss1) << 4), aS11 = rs1 * 64 + (((2 + g) ^ ss1) << 4);
+    const int aT0 = ring0 + rt * 64 + ((g ^ stz) << 4), aT1 = ring0 + rt * 64 + (((2 + g) ^ stz) << 4);
+    const int issue_base = ring0 + wid * 1024;
+
+    struct Frag { v4i s00, s10, s01, s11, a0, a1, b0, b1; };
+    Frag fa, fb;
+    constexpr int PST = 2 * SW2_TILE;                    // bytes of one pair-stage
+    int rd_stage = 0, is_stage = 0, rd_koff = 0;
+    const int koff_end = ktiles * SW2_TILE;
+    int kt = 0, cidx = 0;
+    auto read_frags = [&](Frag& f) __attribute__((always_inline)) {
+        f.s00 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS00);
+        f.s10 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS10);
+        f.a0 = *reinterpret_cast<const v4i*>(smem + rd_stage + aT0);
+        f.b0 = *reinterpret_cast<const v4i*>(smem + rd_stage + SW2_TILE + aT0);
+        f.s01 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS01);
+        f.s11 = *reinterpret_cast<const v4i*>(smem + rd_koff + aS11);
+        f.a1 = *reinterpret_cast<const v4i*>(smem + rd_stage + aT1);
+        f.b1 = *reinterpret_cast<const v4i*>(smem + rd_stage + SW2_TILE + aT1);
+        rd_stage = (rd_stage + PST == SW5_NP * PST) ? 0 : rd_stage + PST;
+        rd_koff = (rd_koff + SW2_TILE == koff_end) ? 0 : rd_koff + SW2_TILE;
+    };
+    auto epilogue = [&](v16i (&a2)[2], int ci) __attribute__((always_inline)) {
+        const float s1 = s1tab[ci * 8 + wid];
+        v2f sum2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const v2f a = {(float)a2[i][r], (float)a2[i][r + 1]};
+                const v2f uu = {u[i][r], u[i][r + 1]};
+                const v2f ww = {w[i][r], w[i][r + 1]};
+                const v2f d = uu - a * s1;
+                if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                else sum2 = (ww * d) * d + sum2;
+                a2[i][r] = 0;
+                a2[i][r + 1] = 0;
+            }
+        float sum = sum2.x + sum2.y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) res[ci * 8 + wid] = sum;
+    };
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s00, f.a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s10, f.a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s00, f.b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s10, f.b0, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s01, f.a1, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s11, f.a1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s01, f.b1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.s11, f.b1, acc[1][1], 0, 0, 0);
+        // issue order: the 8 fragment reads of the NEXT pair-step go out in the shadow of the first MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 x ds_read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 x MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (++kt == ktiles) {
+            epilogue(acc[0], cidx);
+            epilogue(acc[1], cidx + 1);
+            kt = 0;
+            cidx += 2;
+        }
+    };
+    // step: pair-step `it` is in `cur`.  Own pieces of pair-step it+1 waited for (only the 2 pieces of it+2 may be
+    // in flight), barrier, refill the stage of pair-step `it` (its fragment reads completed before every wave's
+    // previous lgkmcnt(0)) with pair-step it+3, start the ds_reads of it+1 and run the 8 MFMAs of `it`.
+    auto step = [&](Frag& cur, Frag& nxt) __attribute__((always_inline)) {
+        wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        glds16(curT, smem + issue_base + is_stage);
+        glds16(curT + SW_BKB, smem + issue_base + is_stage + SW2_TILE);
+        curT += 2 * SW_BKB;
+        is_stage = (is_stage + PST == SW5_NP * PST) ? 0 : is_stage + PST;
+        read_frags(nxt);
+        mma(cur);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); a real S_WAITCNT so that the compiler's own wait insertion sees it
+    };
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) trc[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    wait_vmcnt<4>();      // stationary operand + pair-step 0 (vmcnt completes in order)
+    __builtin_amdgcn_s_barrier();
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) trc[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    read_frags(fa);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); a real S_WAITCNT so that the compiler's own wait insertion sees it
+    int it = 0;
+    for (; it + 1 < total; it += 2) { step(fa, fb); step(fb, fa); }
+    if (it < total) step(fa, fb);
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
+    for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
+        const int cc = c_lo + i / 8, wv = i % 8;
+        p.part[(long)cc * p.p_cs + (long)(st * 2 + (wv >> 2)) * p.NG + tt * 4 + (wv & 3)] = res[i];
+    }
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)total; trc[9] = __builtin_amdgcn_s_memtime(); }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep6: stationary operand in REGISTERS, one wave per SIMD (K = KT * 64 bytes, KT <= 12)
+// ------------------------------------------------------------------------------------------
+// What bounds k_sweep4/5 (tools/ubench_mfma.hip, profiles/r1_ubench.txt): not the matrix pipe but the LDS --
+// 6 (4) ds_read_b128 per 4 MFMAs plus the LDS-DMA writes of the streamed tile, which interfere badly with the
+// reads (MFMA only 133 ns per k-tile step, + reads 162 ns, + LDS-DMA 231 ns, + epilogue 261 ns = the kernel).
+// The cure is fewer LDS bytes per MFMA on BOTH paths:
+//   * 4 waves per workgroup, one per SIMD, 512 registers each.  Every wave keeps its 64 stationary rows for the
+//     WHOLE K in registers (KT * 16 VGPRs = 192 at K = 768) -- the stationary operand never touches the LDS;
+//   * workgroup tile = 256 stationary rows x 64 streaming rows: per k-tile step a wave reads the 64 x 64 B
+//     streaming tile (4 x ds_read_b128) for 8 MFMAs (0.5 KB / MFMA instead of 1.5), and the tile that has to be
+//     streamed in is 4 KB per step instead of 8 KB (half the LDS-DMA and half the L2 traffic per MAC);
+//   * the ring holds whole candidates (KT x 4 KB per stage, 3 stages): ONE barrier and one counted vmcnt wait per
+//     candidate instead of per k-tile; the epilogue of candidate c-1 runs after the barrier of candidate c, under
+//     the latency of its first fragment reads.
+// Output tile orientation, scales, bias, partial-sum table and plane layout ([row][candidate][K], c_inner = 1)
+// are those of k_sweep4, so k_pack / k_finish are unchanged.
+template <int EPI, int KT>
+__global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef P4V_TRACE
+    unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+    if (threadIdx.x == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[8] = __builtin_amdgcn_s_memtime(); trc[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
+#endif
+    constexpr int KT_TILE = 64 * 64;                     // bytes of one k-tile of the 64-row streaming tile
+    constexpr int STG = KT * KT_TILE;                    // one candidate
+    float* res = reinterpret_cast<float*>(smem + 3 * STG);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.stiles * p.ttiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
+    const int s0 = st * 256 + wid * 64, t0 = tt * 64;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo;
+
+    // ---- streaming operand [row][candidate][K]: wave w moves rows w*16 .. w*16+15 of every k-tile ----------------
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
+    auto issue = [&](int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) glds16(curT + kt * SW_BKB, smem + stage_off + kt * KT_TILE + wid * 1024);
+        curT += p.ldk;
+    };
+    issue(0);
+    issue(STG);      // always two candidates ahead (slack behind the plane; stale stages are never consumed)
+
+    // ---- stationary operand: 64 rows x K bytes of this wave, MFMA A-fragments, registers for the whole kernel -----
+    v4i sfr[KT][2][2];   // [k-tile][32-row block][32-byte half]
+    {
+        const char* gS = (const char*)p.S + (long)(s0 + l31) * p.ldk + g * 16;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    sfr[kt][i][h] = *reinterpret_cast<const v4i*>(gS + (long)i * 32 * p.ldk + kt * SW_BKB + h * 32);
+    }
+
+    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming) --
+    float u[2][2][16], w[2][2][16];
+    // activation search: the tile is transposed (stationary rows = output features = the contiguous dimension), so
+    // the four rows (r & 3) of one lane are 16 contiguous bytes -> one dwordx4 load instead of four scattered dwords
+    const bool vec_ok = p.o_ss == 1 && (p.SR & 3) == 0 && (p.o_ts & 3) == 0 &&
+                        ((((unsigned long long)p.O) | ((unsigned long long)p.Wt) | ((unsigned long long)p.bias)) & 15) == 0;
+    // weight = raw_grad (mode 1) | raw_out (2) | |raw_out| (3) | 1 (0), selected with bit masks
+    const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
+    const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
+    const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
+    // two phases per column block: every load is issued unconditionally (clamped addresses) before anything is
+    // consumed -- a conditional load costs a branch and a full vmcnt(0) per element
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int tr = t0 + cb * 32 + l31;
+        const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
+        const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
+        const bool t_ok = tr < p.TR;
+        float bs[2][16];
+        if (vec_ok) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int src = min(s0 + i * 32 + 8 * q + 4 * g, p.SR - 4);
+                    const v4f o4 = *reinterpret_cast<const v4f*>(p.O + toff + src);
+                    const v4f g4 = *reinterpret_cast<const v4f*>(p.Wt + toff + src);
+                    const v4f b4 = *reinterpret_cast<const v4f*>(p.bias + (p.bias_on_t ? 0 : src));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = o4[e]; w[i][cb][q * 4 + e] = g4[e]; bs[i][q * 4 + e] = b4[e]; }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int src = min(s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1);
+                    const long idx = toff + (long)src * p.o_ss;
+                    u[i][cb][r] = p.O[idx];
+                    w[i][cb][r] = p.Wt[idx];
+                    bs[i][r] = p.bias[p.bias_on_t ? 0 : src];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = t_ok && (s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
+                const float o = u[i][cb][r], gw = w[i][cb][r];
+                const float b = p.bias_on_t ? bias_t : bs[i][r];
+                // branch-free weight selection (a uniform if-chain becomes scalar branches that split the block and
+                // turn every later wait into vmcnt(0))
+                const unsigned wbits = (__builtin_bit_cast(unsigned, gw) & m_g) | (__builtin_bit_cast(unsigned, o) & m_o) | m_1;
+                u[i][cb][r] = ok ? o - b : 0.0f;
+                w[i][cb][r] = ok ? __builtin_bit_cast(float, wbits) : 0.0f;
+            }
+    }
+    const int blk_row = p.sb_on_t ? t0 : s0;
+    const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
+    float* s1tab = res + per * 8;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * 4 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+
+    v16i acc[2][2];
+    // streaming fragments: column block cb (32 streaming rows), 32-byte half h.  Read with inline-asm ds_read_b128:
+    // the compiler's wait insertion treats LDS reads as out-of-order once an LDS-DMA is pending and would put
+    // lgkmcnt(0) in front of every MFMA group (measured: 45 % matrix-pipe utilisation with one wave per SIMD);
+    // here the software pipeline is waited for explicitly with counted lgkmcnt instead.
+    const int sw0 = (l31 >> 2) & 3;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned tbase0 = lds0 + l31 * 64 + ((g ^ sw0) << 4);          // half 0; column block 1 is +2048
+    const unsigned tbase1 = lds0 + l31 * 64 + (((2 + g) ^ sw0) << 4);    // half 1
+    struct TF { v4i f[2][2]; };
+#define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto epilogue = [&](int ci) __attribute__((always_inline)) {
+        const float s1 = s1tab[ci * 4 + wid];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            v2f sum2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f a = {(float)acc[i][cb][r], (float)acc[i][cb][r + 1]};
+                    const v2f uu = {u[i][cb][r], u[i][cb][r + 1]};
+                    const v2f ww = {w[i][cb][r], w[i][cb][r + 1]};
+                    const v2f d = uu - a * s1;
+                    if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                    else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                    else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                    else sum2 = (ww * d) * d + sum2;
+                }
+            const float sum = wave_sum_dpp(sum2.x + sum2.y);
+            if (lane == 63) res[ci * 8 + wid * 2 + cb] = sum;
+        }
+    };
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int stage = 0;                                        // byte offset of the stage holding the current candidate
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) { trc[1] = __builtin_amdgcn_s_memrealtime(); trc[6] = trc[1]; }
+#endif
+    for (int ci = 0; ci < ncand; ++ci) {
+        // own pieces of this candidate have landed (only the KT pieces of the next one may be in flight); after the
+        // barrier everybody's have, and everybody is done with the stage of candidate ci-1 (its fragments were
+        // consumed by MFMAs that precede this barrier) -> refill it with candidate ci+2
+#if !(defined(P4V_ABL) && (P4V_ABL & 1))
+        wait_vmcnt<KT>();
+#endif
+        __builtin_amdgcn_s_barrier();
+        {
+            int is = stage + 2 * STG;
+            if (is >= 3 * STG) is -= 3 * STG;
+#if !(defined(P4V_ABL) && (P4V_ABL & 1))
+            issue(is);
+#endif
+        }
+        TF ta, tb;
+        const unsigned ad0 = tbase0 + stage, ad1 = tbase1 + stage;
+        P4V_DSR(ta.f[0][0], ad0, 0); P4V_DSR(ta.f[0][1], ad1, 0);
+        P4V_DSR(ta.f[1][0], ad0, 2048); P4V_DSR(ta.f[1][1], ad1, 2048);
+#if !(defined(P4V_ABL) && (P4V_ABL & 4))
+        if (ci > 0) epilogue(ci - 1);                     // under the latency of the first fragment reads
+#endif
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            TF& cur = (kt & 1) ? tb : ta;
+            TF& nxt = (kt & 1) ? ta : tb;
+            // software pipeline: the 4 fragment reads of k-tile kt+1 go out first, then the 8 MFMAs of k-tile kt wait
+            // only for the OLDER reads -- lgkmcnt(4) leaves the new ones in flight
+#if defined(P4V_ABL) && (P4V_ABL & 2)
+            if (false) {
+#else
+            if (kt + 1 < KT) {
+#endif
+                P4V_DSR(nxt.f[0][0], ad0, (kt + 1) * KT_TILE); P4V_DSR(nxt.f[0][1], ad1, (kt + 1) * KT_TILE);
+                P4V_DSR(nxt.f[1][0], ad0, (kt + 1) * KT_TILE + 2048); P4V_DSR(nxt.f[1][1], ad1, (kt + 1) * KT_TILE + 2048);
+                __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4)
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            }
+            // the MFMAs below may not be hoisted above the reads / the wait: their fragments pass through this fence
+            asm volatile("" : "+v"(cur.f[0][0]), "+v"(cur.f[0][1]), "+v"(cur.f[1][0]), "+v"(cur.f[1][1]) :: "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[cb][h],
+                                                                           (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = (stage + STG == 3 * STG) ? 0 : stage + STG;
+    }
+    epilogue(ncand - 1);
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
+    for (int i = tid; i < ncand * 8; i += 256) {
+        const int cc = c_lo + i / 8, wv = (i % 8) >> 1, cb = i & 1;
+        p.part[(long)cc * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = res[i];
+    }
+#undef P4V_DSR
+#ifdef P4V_TRACE
+    if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)ncand; trc[9] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
