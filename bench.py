@@ -163,7 +163,7 @@ def main():
             issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-            roof = {"bound": "mfma", "kernel": "k_sweep4 + k_sweep2 (int8 candidate sweeps)", "achieved": algo_ops / secs / 1e12, "peak": peak,
+            roof = {"bound": "mfma", "kernel": "k_sweep6 + k_sweep2 (int8 candidate sweeps)", "achieved": algo_ops / secs / 1e12, "peak": peak,
                     "unit": "TOP/s", "frac": algo_ops / secs / 1e12 / peak, "traffic": None,
                     "issued": issued_ops / secs / 1e12, "launches": st["sweep_i8_launches"],
                     "reference_ops_fraction_executed": algo_ops / ref_ops,

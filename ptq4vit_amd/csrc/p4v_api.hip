@@ -282,7 +282,7 @@ bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 6 || ktiles 
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)per * 8 * sizeof(float) + (size_t)per * 4 * sizeof(float) + 256;
+    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 8 * sizeof(float) + (size_t)per * 4 * sizeof(float) + 64 * sizeof(float) + 256;
     dim3 grid(p.stiles * p.ttiles, 1, cgroups);
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));

@@ -1368,108 +1368,143 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     }
     const int blk_row = p.sb_on_t ? t0 : s0;
     const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
-    float* s1tab = res + per * 8;
+    // LDS behind the ring: res [(per + 1) candidates][8] (slot 0 is a dump for the warm-up epilogue), s1tab [per][4],
+    // dump [64] (target of the lanes that do not hold the wave sum)
+    float* s1tab = res + (per + 1) * 8;
     for (int i = lane; i < ncand; i += 64) s1tab[i * 4 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
-    v16i acc[2][2];
-    // streaming fragments: column block cb (32 streaming rows), 32-byte half h.  Read with inline-asm ds_read_b128:
-    // the compiler's wait insertion treats LDS reads as out-of-order once an LDS-DMA is pending and would put
-    // lgkmcnt(0) in front of every MFMA group (measured: 45 % matrix-pipe utilisation with one wave per SIMD);
-    // here the software pipeline is waited for explicitly with counted lgkmcnt instead.
+    // ---- main loop ----------------------------------------------------------------------------------------------
+    // One candidate = 2 phases (column block cb = 0, then 1) of KT steps; a step = 2 fragment reads + 4 MFMAs.  With a
+    // single wave per SIMD nothing hides behind another wave, so everything is interleaved by construction:
+    //   * fragment reads run two steps ahead of their MFMAs (three fragment buffers, counted lgkmcnt(4) waits;
+    //     inline-asm ds_reads, because the compiler's own wait insertion falls back to lgkmcnt(0) whenever an
+    //     LDS-DMA is pending) -- also across the candidate boundary, which therefore has no bubble;
+    //   * the epilogue of a column block (cvt, packed fma, DPP wave sum, one LDS store) is cut into KT slices that
+    //     ride in the VALU slots between the MFMAs of the OTHER column block: block 0 of candidate c during phase 1
+    //     of c, block 1 during phase 0 of c+1;
+    //   * the ring barrier sits in the middle of phase 1: every wave's pieces of candidate c+1 have landed (issued
+    //     one candidate earlier), and the stage of candidate c-1 is refilled with c+2.
     const int sw0 = (l31 >> 2) & 3;
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     const unsigned tbase0 = lds0 + l31 * 64 + ((g ^ sw0) << 4);          // half 0; column block 1 is +2048
     const unsigned tbase1 = lds0 + l31 * 64 + (((2 + g) ^ sw0) << 4);    // half 1
-    struct TF { v4i f[2][2]; };
+    const unsigned s1addr0 = lds0 + 3 * STG + (per + 1) * 32 + wid * 4;   // &s1tab[0 * 4 + wid]
+    float* dump = s1tab + per * 4;
 #define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    auto epilogue = [&](int ci) __attribute__((always_inline)) {
-        const float s1 = s1tab[ci * 4 + wid];
+    struct TF2 { v4i f[2]; };                 // the two 32-byte halves of one column block of one k-tile
+    constexpr int PD = 2;                     // fragment reads run PD steps ahead of their MFMAs (3 and 5 measured the same)
+    constexpr int NB = PD + 1;                // fragment buffers, ring indexed by (step % NB)
+    TF2 tf[NB];
+    static_assert((2 * KT) % NB == 0, "fragment ring needs 2 * KT divisible by the buffer count");
+    constexpr int NSTEP = 2 * KT;
+    constexpr int NSL = KT - 2;                              // slices that carry element math
+    constexpr int PPS = (16 + NSL - 1) / NSL;                // packed pairs per slice (16 pairs per column block)
+    v16i acc[2][2];
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][1] = zero16; acc[1][1] = zero16;                 // consumed by the warm-up epilogue of candidate "-1"
+    v2f esum = {0.0f, 0.0f};
+    float ered = 0.0f, es1 = 1.0f, es1_next = 1.0f;
+    // epilogue slice `sl` of column block cbE; result goes to res slot `slot` (= candidate + 1)
+    auto epi_slice = [&](auto sl_c, auto cb_c, int slot) __attribute__((always_inline)) {
+        constexpr int sl = decltype(sl_c)::value, cbE = decltype(cb_c)::value;
+        if constexpr (sl == 0) esum = v2f{0.0f, 0.0f};
+        if constexpr (sl < NSL) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            v2f sum2 = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const v2f a = {(float)acc[i][cb][r], (float)acc[i][cb][r + 1]};
-                    const v2f uu = {u[i][cb][r], u[i][cb][r + 1]};
-                    const v2f ww = {w[i][cb][r], w[i][cb][r + 1]};
-                    const v2f d = uu - a * s1;
-                    if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
-                    else if (EPI == EPI_SQ) sum2 = d * d + sum2;
-                    else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
-                    else sum2 = (ww * d) * d + sum2;
-                }
-            const float sum = wave_sum_dpp(sum2.x + sum2.y);
-            if (lane == 63) res[ci * 8 + wid * 2 + cb] = sum;
+            for (int j = sl * PPS; j < (sl + 1) * PPS && j < 16; ++j) {
+                const int i = j >> 3, r = (j & 7) * 2;
+                const v2f a = {(float)acc[i][cbE][r], (float)acc[i][cbE][r + 1]};
+                const v2f uu = {u[i][cbE][r], u[i][cbE][r + 1]};
+                const v2f ww = {w[i][cbE][r], w[i][cbE][r + 1]};
+                const v2f d = uu - a * es1;
+                if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; esum = t2 * t2 + esum; }
+                else if (EPI == EPI_SQ) esum = d * d + esum;
+                else if (EPI == EPI_ABS) esum += v2f{fabsf(d.x), fabsf(d.y)};
+                else esum = (ww * d) * d + esum;
+            }
+        } else if constexpr (sl == NSL) {
+            ered = wave_sum_dpp(esum.x + esum.y);
+        } else {
+            float* dst = (lane == 63) ? res + slot * 8 + wid * 2 + cbE : dump + lane;   // branch-free: every lane stores
+            *dst = ered;
         }
     };
-    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // one step: prefetch the fragments of step s+2, wait for those of step s, 4 MFMAs, one epilogue slice
+    auto step = [&](auto s_c, unsigned ad0, unsigned ad1, unsigned adn0, unsigned adn1, int ci) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int cb = s / KT, kt = s % KT;
+        TF2& cur = tf[s % NB];
+        TF2& pre = tf[(s + PD) % NB];
+        constexpr int t = s + PD;
+        if constexpr (t < NSTEP) {
+            P4V_DSR(pre.f[0], ad0, (t % KT) * KT_TILE + (t / KT) * 2048); P4V_DSR(pre.f[1], ad1, (t % KT) * KT_TILE + (t / KT) * 2048);
+        } else {   // first PD steps of the next candidate (its stage landed before the barrier of the previous phase 1)
+            P4V_DSR(pre.f[0], adn0, (t - NSTEP) * KT_TILE); P4V_DSR(pre.f[1], adn1, (t - NSTEP) * KT_TILE);
+        }
+        if constexpr (s == 0) {   // scale of this candidate for the epilogues that start in phase 1
+            asm volatile("ds_read_b32 %0, %1" : "=v"(es1_next) : "v"(s1addr0 + ci * 16));
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * PD + 1) << 8));   // the scale read is newer than the fragments of this step
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * PD) << 8));       // lgkmcnt(2 * PD): the fragments of steps s+1 .. s+PD stay in flight
+        }
+        // the MFMAs below may not be hoisted above the reads / the wait: their fragments pass through this fence
+        asm volatile("" : "+v"(cur.f[0]), "+v"(cur.f[1]) :: "memory");
+        if constexpr (s == KT) { asm volatile("" : "+v"(es1_next)); es1 = es1_next; }   // landed KT waits ago
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+        // phase 0 carries the epilogue of block 1 of the previous candidate (slot ci), phase 1 that of block 0 of this one
+        if constexpr (cb == 0) epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 1>{}, ci);
+        else epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 0>{}, ci + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // both prologue candidates (and the register operands) have landed; make them visible to every wave
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
     int stage = 0;                                        // byte offset of the stage holding the current candidate
+    auto pro_read = [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        TF2& d = tf[S];
+        const unsigned b0 = tbase0, b1 = tbase1;
+        P4V_DSR(d.f[0], b0, (S % KT) * KT_TILE + (S / KT) * 2048);
+        P4V_DSR(d.f[1], b1, (S % KT) * KT_TILE + (S / KT) * 2048);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
+        (pro_read(std::integral_constant<int, S>{}), ...);
+    }(std::make_integer_sequence<int, PD>{});
 #ifdef P4V_TRACE
     if (threadIdx.x == 0) { trc[1] = __builtin_amdgcn_s_memrealtime(); trc[6] = trc[1]; }
 #endif
     for (int ci = 0; ci < ncand; ++ci) {
-        // own pieces of this candidate have landed (only the KT pieces of the next one may be in flight); after the
-        // barrier everybody's have, and everybody is done with the stage of candidate ci-1 (its fragments were
-        // consumed by MFMAs that precede this barrier) -> refill it with candidate ci+2
-#if !(defined(P4V_ABL) && (P4V_ABL & 1))
-        wait_vmcnt<KT>();
-#endif
-        __builtin_amdgcn_s_barrier();
-        {
-            int is = stage + 2 * STG;
-            if (is >= 3 * STG) is -= 3 * STG;
-#if !(defined(P4V_ABL) && (P4V_ABL & 1))
-            issue(is);
-#endif
-        }
-        TF ta, tb;
-        const unsigned ad0 = tbase0 + stage, ad1 = tbase1 + stage;
-        P4V_DSR(ta.f[0][0], ad0, 0); P4V_DSR(ta.f[0][1], ad1, 0);
-        P4V_DSR(ta.f[1][0], ad0, 2048); P4V_DSR(ta.f[1][1], ad1, 2048);
-#if !(defined(P4V_ABL) && (P4V_ABL & 4))
-        if (ci > 0) epilogue(ci - 1);                     // under the latency of the first fragment reads
-#endif
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            TF& cur = (kt & 1) ? tb : ta;
-            TF& nxt = (kt & 1) ? ta : tb;
-            // software pipeline: the 4 fragment reads of k-tile kt+1 go out first, then the 8 MFMAs of k-tile kt wait
-            // only for the OLDER reads -- lgkmcnt(4) leaves the new ones in flight
-#if defined(P4V_ABL) && (P4V_ABL & 2)
-            if (false) {
-#else
-            if (kt + 1 < KT) {
-#endif
-                P4V_DSR(nxt.f[0][0], ad0, (kt + 1) * KT_TILE); P4V_DSR(nxt.f[0][1], ad1, (kt + 1) * KT_TILE);
-                P4V_DSR(nxt.f[1][0], ad0, (kt + 1) * KT_TILE + 2048); P4V_DSR(nxt.f[1][1], ad1, (kt + 1) * KT_TILE + 2048);
-                __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4)
-            } else {
-                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-            }
-            // the MFMAs below may not be hoisted above the reads / the wait: their fragments pass through this fence
-            asm volatile("" : "+v"(cur.f[0][0]), "+v"(cur.f[0][1]), "+v"(cur.f[1][0]), "+v"(cur.f[1][1]) :: "memory");
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[cb][h],
-                                                                           (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage = (stage + STG == 3 * STG) ? 0 : stage + STG;
+        const int stage_n = (stage + STG == 3 * STG) ? 0 : stage + STG;
+        const unsigned ad0 = tbase0 + stage, ad1 = tbase1 + stage, adn0 = tbase0 + stage_n, adn1 = tbase1 + stage_n;
+        auto run = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
+            // compile-time loop over steps [lo, hi)
+            [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
+                (step(std::integral_constant<int, decltype(lo_c)::value + S>{}, ad0, ad1, adn0, adn1, ci), ...);
+            }(std::make_integer_sequence<int, decltype(hi_c)::value - decltype(lo_c)::value>{});
+        };
+        constexpr int SB = KT + KT / 2;                   // the ring barrier sits in the middle of phase 1
+        run(std::integral_constant<int, 0>{}, std::integral_constant<int, SB>{});
+        wait_vmcnt<0>();                                  // own pieces of candidate ci+1 (issued one candidate ago)
+        __builtin_amdgcn_s_barrier();                     // ci+1 visible to all; nobody reads the stage of ci-1 any more
+        issue((stage_n + STG == 3 * STG) ? 0 : stage_n + STG);   // candidate ci+2 -> stage of ci-1
+        run(std::integral_constant<int, SB>{}, std::integral_constant<int, NSTEP>{});
+        stage = stage_n;
     }
-    epilogue(ncand - 1);
+    // block 1 of the last candidate
+    [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
+        (epi_slice(std::integral_constant<int, S>{}, std::integral_constant<int, 1>{}, ncand), ...);
+    }(std::make_integer_sequence<int, KT>{});
 #ifdef P4V_TRACE
     if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
     for (int i = tid; i < ncand * 8; i += 256) {
         const int cc = c_lo + i / 8, wv = (i % 8) >> 1, cb = i & 1;
-        p.part[(long)cc * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = res[i];
+        p.part[(long)cc * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = res[8 + i];
     }
 #undef P4V_DSR
 #ifdef P4V_TRACE

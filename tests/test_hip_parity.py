@@ -151,7 +151,14 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True),
     dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="cosine", postgelu=False),
     dict(b=3, T=50, K=96, N=160, n_V=2, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
-], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-N{c['N']}-nV{c['n_V']}")
+    # K = 192 / 384 / 768 bytes: register-stationary sweep (k_sweep6<KT = 3 / 6 / 12>), every epilogue flavour
+    dict(b=3, T=50, K=192, N=128, n_V=2, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),
+    dict(b=3, T=50, K=192, N=130, n_V=1, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
+    dict(b=3, T=50, K=384, N=192, n_V=3, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=False),
+    dict(b=3, T=50, K=384, N=200, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=False),
+    dict(b=2, T=70, K=768, N=300, n_V=1, w_bit=8, a_bit=8, metric="square_weighted_L2_norm", postgelu=False),
+    dict(b=2, T=70, K=768, N=192, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
+], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-K{c['K']}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
     cfg = dict(cfg)
