@@ -37,7 +37,23 @@ class MinMaxQuantConv2d(nn.Conv2d):
         return dispatch(self, x)
 
     def _conv(self, x, w, b):
+        if x.is_cuda and self._is_patchify(x):
+            # non-overlapping patches (the ViT patch embedding): the convolution IS a GEMM over unfolded patches.
+            # MIOpen answers this fp32 shape with its naive direct kernel (2-6 ms per call on MI355X, the largest
+            # single item of the capture pass); rocBLAS does the same product in ~0.2 ms.
+            B, C, H, W = x.shape
+            kh, kw = self.kernel_size
+            gh, gw = H // kh, W // kw
+            cols = x.reshape(B, C, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * kh * kw)
+            out = F.linear(cols, w.reshape(w.shape[0], -1), b)
+            return out.reshape(B, gh, gw, -1).permute(0, 3, 1, 2).contiguous()
         return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+
+    def _is_patchify(self, x):
+        pair = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        k, s, p, d = pair(self.kernel_size), pair(self.stride), pair(self.padding), pair(self.dilation)
+        return (self.groups == 1 and x.dim() == 4 and k == s and p == (0, 0) and d == (1, 1)
+                and x.shape[2] % k[0] == 0 and x.shape[3] % k[1] == 0)
 
     def raw_forward(self, x):
         return self._conv(x, self.weight, self.bias)

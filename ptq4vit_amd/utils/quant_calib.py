@@ -39,6 +39,18 @@ def grad_hook(module, grad_input, grad_output):
     module.raw_grad.append(grad_output[0].detach())
 
 
+def _with_output_grad(forward_hook):
+    """Forward hook that also records the gradient w.r.t. the module output -- what the reference's
+    register_backward_hook(grad_hook) (quant_calib.py:330) delivers as grad_output[0] -- through a tensor hook on
+    the output.  Same tensor, without the two extra autograd nodes per module call that
+    register_full_backward_hook inserts (the capture pass is launch-overhead bound)."""
+    def hook(module, input, output):
+        forward_hook(module, input, output)
+        if output.requires_grad:
+            output.register_hook(lambda g, m=module: grad_hook(m, None, (g,)))
+    return hook
+
+
 def linear_forward_hook(module, input, output):
     if module.raw_input is None:
         module.raw_input = []
@@ -63,26 +75,26 @@ def matmul_forward_hook(module, input, output):
 
 def _register(module, with_grad):
     hooks = []
+    wrap = _with_output_grad if with_grad else (lambda h: h)
     if isinstance(module, MinMaxQuantLinear):
-        hooks.append(module.register_forward_hook(linear_forward_hook))
+        hooks.append(module.register_forward_hook(wrap(linear_forward_hook)))
     if isinstance(module, MinMaxQuantConv2d):
-        hooks.append(module.register_forward_hook(conv2d_forward_hook))
+        hooks.append(module.register_forward_hook(wrap(conv2d_forward_hook)))
     if isinstance(module, MinMaxQuantMatMul):
-        hooks.append(module.register_forward_hook(matmul_forward_hook))
-    if with_grad:
-        hooks.append(module.register_full_backward_hook(grad_hook))
+        hooks.append(module.register_forward_hook(wrap(matmul_forward_hook)))
     return hooks
 
 
 def _concat(module, with_grad):
     """Lists of per-sub-batch tensors -> one tensor per cache (reference quant_calib.py:343-354)."""
+    cat = lambda t: t[0] if len(t) == 1 else torch.cat(t, dim=0)   # a single piece needs no copy
     if isinstance(module, MinMaxQuantMatMul):
-        module.raw_input = [torch.cat(t, dim=0) for t in module.raw_input]
+        module.raw_input = [cat(t) for t in module.raw_input]
     else:
-        module.raw_input = torch.cat(module.raw_input, dim=0)
-    module.raw_out = torch.cat(module.raw_out, dim=0)
+        module.raw_input = cat(module.raw_input)
+    module.raw_out = cat(module.raw_out)
     if with_grad:
-        module.raw_grad = torch.cat(module.raw_grad, dim=0)
+        module.raw_grad = cat(module.raw_grad)
 
 
 class QuantCalibrator:
@@ -169,6 +181,111 @@ class HessianQuantCalibrator(QuantCalibrator):
             if hasattr(m, "metric"):
                 m.raw_grad = None   # step 2 deletes the caches (reference linear.py:554): re-create for re-calibration
             hooks += _register(m, with_grad and hasattr(m, "metric"))
+        # Only gradients w.r.t. ACTIVATIONS are captured (grad_hook): the weight-gradient GEMMs of the wrapped
+        # Linear / Conv modules -- a third of the backward pass -- are never looked at.  Their matrices stop requiring
+        # grad for the duration of the capture; biases, norms and embeddings keep the graph connected, so every
+        # hooked output still receives exactly the same grad_output.
+        frozen = []
+        if with_grad:
+            for m in self.wrapped_modules.values():
+                wt = getattr(m, "weight", None)
+                if isinstance(wt, torch.nn.Parameter) and wt.requires_grad and wt.dim() >= 2 and getattr(m, "bias", None) is not None:
+                    wt.requires_grad_(False)
+                    frozen.append(wt)
+        try:
+            done = False
+            if with_grad and dev.type == "cuda" and not self.sequential:
+                # recording + instantiating the graph costs about five eager passes: worth it from ~24 sub-batches on
+                # (use_graph = True / False forces the choice)
+                n_sub = sum(-(-inp.shape[0] // bs) for inp, _ in self.calib_loader)
+                use_graph = getattr(self, "use_graph", None)
+                if use_graph or (use_graph is None and n_sub >= 24):
+                    done = self._capture_passes_graph(names, dev, bs, raw_pred_softmax)
+            if not done:
+                self._capture_passes(dev, bs, raw_pred_softmax, with_grad)
+        finally:
+            for wt in frozen:
+                wt.requires_grad_(True)
+        for h in hooks:
+            h.remove()
+        for n in names:
+            m = self.wrapped_modules[n]
+            _concat(m, with_grad and hasattr(m, "metric"))
+
+    def _capture_passes_graph(self, names, dev, bs, raw_pred_softmax):
+        """The sub-batch forward + KL backward replayed from ONE HIP graph.
+
+        With batch_size=4 (the reference's setting) the eager pass is bound by launch overhead, not by the GPU
+        (~130 ms of Python / dispatcher time for ~70 ms of kernels on ViT-B, tools/prof_capture.py).  All modules run
+        in "raw" mode during a non-sequential capture, so every sub-batch executes the same kernel sequence: it is
+        recorded once (hooks included -- they see the graph's static tensors) and replayed per sub-batch; after each
+        replay the hooked tensors are copied into their slice of the preallocated caches (the copy torch.cat would
+        have done).  Returns False -- caller falls back to the eager pass -- if the loader is not a single batch
+        divisible into equal sub-batches or if graph capture is not available.
+        """
+        batches = [inp for inp, _ in self.calib_loader]
+        if len(batches) != 1 or batches[0].shape[0] % bs != 0 or batches[0].shape[0] // bs < 2:
+            return False
+        inp = batches[0]
+        total = inp.shape[0]
+        mods = [self.wrapped_modules[n] for n in names]
+
+        def reset():
+            for m in mods:
+                m.raw_input = m.raw_out = None
+                if hasattr(m, "metric"):
+                    m.raw_grad = None
+
+        def one_pass(x, tgt):
+            self.net.zero_grad(set_to_none=True)
+            pred = self.net(x)
+            loss = F.kl_div(F.log_softmax(pred, dim=-1), tgt, reduction="batchmean")
+            loss.backward()
+
+        try:
+            static_in = inp[:bs].to(dev).clone()
+            static_tgt = raw_pred_softmax[:bs].clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):            # warm-up outside the graph (allocator, autograd, library handles)
+                one_pass(static_in, static_tgt)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            reset()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_pass(static_in, static_tgt)
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            print(f"[ptq4vit_amd] graph capture unavailable ({type(e).__name__}: {e}); eager capture")
+            reset()
+            return False
+        # the hooks ran once, during capture: what they appended are the graph's static output tensors
+        srcs, dsts = [], []
+        for m in mods:
+            with_g = hasattr(m, "metric") and m.raw_grad is not None
+            if isinstance(m, MinMaxQuantMatMul):
+                stat = [m.raw_input[0][0], m.raw_input[1][0], m.raw_out[0]]
+            else:
+                stat = [m.raw_input[0], m.raw_out[0]]
+            if with_g:
+                stat.append(m.raw_grad[0])
+            full = [torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in stat]
+            if isinstance(m, MinMaxQuantMatMul):
+                m.raw_input, m.raw_out = [[full[0]], [full[1]]], [full[2]]
+            else:
+                m.raw_input, m.raw_out = [full[0]], [full[1]]
+            if with_g:
+                m.raw_grad = [full[-1]]
+            srcs += stat
+            dsts.append(full)
+        flat_dsts = [t for f in dsts for t in f]
+        for st in range(0, total, bs):
+            static_in.copy_(inp[st:st + bs])
+            static_tgt.copy_(raw_pred_softmax[st:st + bs])
+            graph.replay()
+            torch._foreach_copy_([t[st:st + bs] for t in flat_dsts], srcs)
+        return True
+
+    def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad):
         for inp, _ in self.calib_loader:
             total = inp.shape[0]
             for st in range(0, total, bs):
@@ -181,11 +298,6 @@ class HessianQuantCalibrator(QuantCalibrator):
                 else:
                     with torch.no_grad():
                         self.net(inp_)
-        for h in hooks:
-            h.remove()
-        for n in names:
-            m = self.wrapped_modules[n]
-            _concat(m, with_grad and hasattr(m, "metric"))
 
     def _estimate_cache_bytes(self, names):
         """One cheap probe forward of a single image to size the caches of `names`."""

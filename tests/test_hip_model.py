@@ -214,3 +214,39 @@ def test_pass_memoisation_is_exact(vitb_qkv):
     assert torch.equal(memo[0], full[0]) and torch.equal(memo[1], full[1])
     assert torch.equal(memo[0], ref[0]) and torch.equal(memo[1], ref[1])
     assert st["memo_hits"] + st["memo_misses"] == 6 and st["memo_misses"] >= 2
+
+
+def test_graph_capture_equals_eager_capture():
+    """The HIP-graph replay of the sub-batch passes records exactly what the eager passes record."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+
+    class L:
+        def __init__(self, x):
+            self.x, self.batch_size = x, x.shape[0]
+
+        def __iter__(self):
+            yield self.x, None
+
+    dev = torch.device("cuda:0")
+    net = models.get_net("vit_tiny_patch16_224", seed=3, device=dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    caps = []
+    for use_graph in (True, False):
+        cal = HessianQuantCalibrator(net, wrapped, L(x), sequential=False, batch_size=2)
+        cal.use_graph = use_graph
+        sm = cal._raw_pred_softmax()
+        cal._capture(list(wrapped), sm, True)
+        torch.cuda.synchronize()
+        cap = {}
+        for n, m in wrapped.items():
+            ri = m.raw_input if isinstance(m.raw_input, list) else [m.raw_input]
+            cap[n] = [t.clone() for t in ri] + [m.raw_out.clone(), m.raw_grad.clone()]
+        caps.append(cap)
+    for n in caps[0]:
+        for a, b in zip(caps[0][n], caps[1][n]):
+            assert a.shape == b.shape and torch.equal(a, b), n
