@@ -133,6 +133,7 @@ int launch_scale(Ctx& c, ScaleParams p) {
 template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
     if (c.dry) return 0;
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
+    if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack (%ld 16-element runs)", total);
     const int blocks = (int)std::min<long>(cdiv(total, 256), 256L * 64);
     hipLaunchKernelGGL(k_pack<T>, dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, c.st, p);
     HIPCHK(hipGetLastError());

@@ -201,31 +201,37 @@ __device__ __forceinline__ int pack_blk(const PackParams& p, int z, int r, int k
     return 0;
 }
 
-// Exact clamp(rint(x / s)) without a division per element: t = x * (1/s) differs from the correctly rounded
-// quotient by < 2 ulp, so rint(t) can only differ when t sits within 2^-12 of a half-integer (or would
-// saturate anyway).  Such elements are flagged and redone with the IEEE division (about 1 element in 2000).
-__device__ __forceinline__ float quant_fast(float x, float r, float lo, float hi, bool& redo) {
-    const float t = x * r;
-    const float n = rintf(t);
-    redo = (fabsf(t - n) > 0.49975586f) && (fabsf(t) < 256.0f);
-    return fminf(fmaxf(n, lo), hi);
+// Exact clamp(rint(x / s), lo, hi) without a division per element.  With r = fl(1/s) correctly rounded,
+// t = fl(x * r) = (x/s)(1+e), |e| <= 2^-23, and q = fl(x/s) = (x/s)(1+e'), |e'| <= 2^-24: rint(t) and rint(q) can
+// only differ if a half-integer lies within |x/s| * 2^-22 of t.  t is first clamped to [lo - 0.49, hi + 0.49]
+// (beyond that both paths saturate to the same index, and |lo|, |hi| <= 128 bounds the distance by 3.2e-5), so an
+// element needs the IEEE division only if |tc - rint(tc)| > 0.5 - 4e-5: about 1 in 12 000; the lane then redoes its
+// run (5 % of the waves take that branch).  rint is done by adding 1.5 * 2^23 (round-to-nearest-even of the add):
+// the low byte of the sum's bit pattern is the two's-complement grid index, which is what the plane stores.
+static constexpr float PACK_MAGIC = 12582912.0f;
+__device__ __forceinline__ unsigned quant_fast1(float x, float r, float lo49, float hi49, float magic, float& maxdev) {
+    const float t = __builtin_amdgcn_fmed3f(x * r, lo49, hi49);
+    const float biased = t + magic;
+    maxdev = fmaxf(maxdev, fabsf(t - (biased - magic)));
+    return __builtin_bit_cast(unsigned, biased);
 }
 
 // One thread owns 16 consecutive k of one (z, r) for a group of PACK_CG candidates (blockIdx.y): the source
 // (L2 / Infinity-Cache resident: it is re-read once per candidate group) is loaded once per group, the scales
 // are loaded up front, and every plane is written as one contiguous stream of full 16-byte (int8) /
 // 64-byte (fp32) runs -- a pure streaming-write kernel.
-static constexpr int PACK_CG = 4;
+static constexpr int PACK_CG = 10;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack(PackParams p) {
-    const long kchunks = p.Kp / 16;
-    const long total = (long)p.Z * p.Rp * kchunks;
+    const unsigned kchunks = p.Kp / 16;
+    const unsigned total = (unsigned)p.Z * p.Rp * kchunks;      // < 2^31: checked by the launcher
     const int cbeg = blockIdx.y * PACK_CG, cend = min(p.C, cbeg + PACK_CG);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int kc = (int)(i % kchunks);
-        const int r = (int)((i / kchunks) % p.Rp);
-        const int z = (int)(i / (kchunks * p.Rp));
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = i / kchunks;
+        const int kc = (int)(i - row * kchunks);
+        const int z = (int)(row / (unsigned)p.Rp);
+        const int r = (int)(row - (unsigned)z * p.Rp);
         const float* zbase = p.zdiv > 0 ? p.src + (long)(z / p.zdiv) * p.s_z2 + (long)(z % p.zdiv) * p.s_z
                                         : p.src + (long)z * p.s_z;
         float x[16];
@@ -255,25 +261,28 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                 if (p.mode == PACK_SYM && live && kc * 16 + 16 <= p.K) {
                     // hot path: symmetric grid, no padding inside this 16-element run
                     const float rcp = 1.0f / s, flo = (float)p.lo, fhi = (float)p.hi;
-                    float qv[16];
-                    unsigned bad = (rcp < 3.0e38f) ? 0u : 0xffffu;   // 1/s overflowed: take the division for every element
+                    unsigned qb[16];
+                    float maxdev = 0.0f;
+                    float magic = PACK_MAGIC;
+                    asm volatile("" : "+v"(magic));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        bool redo;
-                        qv[e] = quant_fast(x[e], rcp, flo, fhi, redo);
-                        bad |= redo ? (1u << e) : 0u;
-                    }
-                    if (__any(bad != 0)) {
+                    for (int e = 0; e < 16; ++e) qb[e] = quant_fast1(x[e], rcp, flo - 0.49f, fhi + 0.49f, magic, maxdev);
+                    // 1/s overflowed, a grid wider than 8 bit, or a NaN: divide
+                    const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || !(fmaxf(-flo, fhi) < 129.0f);
+                    if (__any(bad)) {
+                        float sd = s;
+                        asm volatile("" : "+v"(sd));   // the divisions depend on this: they cannot be hoisted out of the rare branch
+                        if (bad) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            if (bad & (1u << e)) qv[e] = fminf(fmaxf(rintf(x[e] / s), flo), fhi);
+                            for (int e = 0; e < 16; ++e)
+                                qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), flo), fhi) + PACK_MAGIC);
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int b0 = (int)qv[q * 4], b1 = (int)qv[q * 4 + 1], b2 = (int)qv[q * 4 + 2], b3 = (int)qv[q * 4 + 3];
-                        const unsigned lo16 = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u);
-                        const unsigned hi16 = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u);
-                        w[q] = (int)(lo16 | (hi16 << 16));
+                        const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
+                        const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
+                        w[q] = (int)(lo16 | (hi16 << 16));   // (an OR of two perms with selector 0x04000c0c is mis-folded by the backend)
                     }
                 } else {
 #pragma unroll
