@@ -111,10 +111,12 @@ def main():
     heads = net.blocks[0].attn.num_heads
     head_dim = net.blocks[0].attn.qkv.in_features // heads
 
-    def one_step():
+    def one_step(search_streams=None):
         for m in wrapped.values():
             m.mode = "raw"
         cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4)
+        if search_streams:
+            cal.search_streams = search_streams
         cal.batching_quant_calib()
         return cal
 
@@ -149,7 +151,7 @@ def main():
         engine.stats_reset()
         engine.stats_enable(rank == 0)
         with quiet:
-            cal_r = one_step()
+            cal_r = one_step(search_streams=1)   # kernels timed in isolation: no second stream sharing the CUs
         sync()
         st = engine.stats_get()
         engine.stats_enable(False)

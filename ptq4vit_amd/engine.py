@@ -34,13 +34,15 @@ def to_dev(t, dev):
 
 
 def workspace(dev, nbytes):
-    ws = _workspace.get(dev)
+    """Scratch for one calibration call; one buffer per (device, stream) so that searches running on different
+    streams (utils/quant_calib.py runs two modules at a time) never share scratch."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspace.get(key)
     if ws is None or ws.numel() < nbytes:
-        _workspace.pop(dev, None)
+        _workspace.pop(key, None)
         ws = None
-        torch.cuda.empty_cache()
         ws = torch.empty(int(nbytes * 1.05) + (1 << 20), dtype=torch.uint8, device=dev)
-        _workspace[dev] = ws
+        _workspace[key] = ws
     return ws
 
 

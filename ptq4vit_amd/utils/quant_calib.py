@@ -11,6 +11,8 @@ reference experiment uses.  Differences in HOW (not WHAT):
 * with ``torch.distributed`` initialised the modules are sharded over the ranks (one process per GPU) and the
   calibrated intervals are exchanged with one all-gather at the end (ptq4vit_amd/utils/shard.py).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -299,6 +301,55 @@ class HessianQuantCalibrator(QuantCalibrator):
                     with torch.no_grad():
                         self.net(inp_)
 
+    def _search_concurrent(self, names, n_streams):
+        """Independent modules (sequential=False) searched `n_streams` at a time, one host thread + HIP stream each.
+
+        A search is a chain of ~50 kernels with a host round trip after every pass (the pass memo reads the selected
+        interval back); with a single stream the GPU idles during those round trips, during the small
+        finish/select kernels and in the tail of every sweep (1200 workgroups on 256 CUs).  A second stream fills
+        these holes with another module's kernels.  Results do not depend on the interleaving: the kernels are
+        deterministic and every call has its own scratch (engine.workspace is per stream).
+        """
+        import threading
+        dev = _dev_of(self.net)
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        for s in streams:
+            s.wait_stream(main)                       # the captured tensors were produced on the current stream
+        # the caches are freed by calibration_step2 (reference linear.py:554) while the other stream may still be
+        # running: hold them until everything has been joined so that the allocator cannot hand the memory out again
+        keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
+        todo = list(names)
+        lock = threading.Lock()
+        errors = []
+
+        def worker(s):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(s), torch.no_grad():
+                    while True:
+                        with lock:
+                            if not todo or errors:
+                                return
+                            n = todo.pop(0)
+                        module = self.wrapped_modules[n]
+                        module.calibration_step2()
+                        module.mode = "raw"
+            except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for s in streams:
+            main.wait_stream(s)
+        torch.cuda.synchronize(dev)
+        del keep
+        if errors:
+            raise errors[0]
+
     def _estimate_cache_bytes(self, names):
         """One cheap probe forward of a single image to size the caches of `names`."""
         dev = _dev_of(self.net)
@@ -363,16 +414,20 @@ class HessianQuantCalibrator(QuantCalibrator):
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()
-            for n in tqdm(grp, desc="Hessian"):
-                module = self.wrapped_modules[n]
-                with torch.no_grad():
-                    if batching:
-                        module.calibration_step2()
-                    elif isinstance(module, MinMaxQuantMatMul):
-                        module.calibration_step2(module.raw_input[0], module.raw_input[1])
-                    else:
-                        module.calibration_step2(module.raw_input)
-                module.mode = "quant_forward" if self.sequential else "raw"
+            n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "3"))
+            if batching and not self.sequential and n_streams > 1 and _dev_of(self.net).type == "cuda" and len(grp) > 1:
+                self._search_concurrent(grp, n_streams)
+            else:
+                for n in tqdm(grp, desc="Hessian"):
+                    module = self.wrapped_modules[n]
+                    with torch.no_grad():
+                        if batching:
+                            module.calibration_step2()
+                        elif isinstance(module, MinMaxQuantMatMul):
+                            module.calibration_step2(module.raw_input[0], module.raw_input[1])
+                        else:
+                            module.calibration_step2(module.raw_input)
+                    module.mode = "quant_forward" if self.sequential else "raw"
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t_cap += t2 - t1
