@@ -633,13 +633,13 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool TWIN, int EPI>
-__global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
+__global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = TWIN ? 3 : 2;
     constexpr int STAGE = NPL * SW2_TILE;
     // tail of the LDS image: per-(candidate, wave) results and the scale tables (ONE __shared__ object: a
     // second one makes hipcc drain vmcnt(0) before every ds_read of an LDS-DMA pipeline)
-    float* res = reinterpret_cast<float*>(smem + SW2_NS * STAGE);   // [per][8 waves]
+    float* res = reinterpret_cast<float*>(smem + SW2_NS * STAGE);   // [per][8 waves], behind the NPL planes of SW2_NS stages
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -718,11 +718,13 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
     const int lds_wave = wid * 1024;
     const int total = (c_hi - c_lo) * ktiles;
     int ikt = 0;   // k-tile of the next tile to issue
-    auto issue = [&](int stage) {
-        char* s = smem + stage * STAGE + lds_wave;
+    // LDS image: [plane][stage][8 KB] -- every fragment read is (per-lane base VGPR) + (immediate < 64 KB)
+    constexpr int PLANE = SW2_NS * SW2_TILE;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        char* s = smem + stage * SW2_TILE + lds_wave;
         glds16(curA + voffA, s);
-        if (TWIN) glds16(curA2 + voffA, s + SW2_TILE);
-        glds16(curB + voffA, s + (NPL - 1) * SW2_TILE);
+        if (TWIN) glds16(curA2 + voffA, s + PLANE);
+        glds16(curB + voffA, s + (NPL - 1) * PLANE);
         curA += SW_BKB; curB += SW_BKB;
         if (TWIN) curA2 += SW_BKB;
         if (++ikt == ktiles) { ikt = 0; curA += wrapA; curB += wrapB; if (TWIN) curA2 += wrapA2; }
@@ -737,53 +739,58 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
     // swizzled fragment addresses (per lane, stage-independent): row R, logical chunk c -> physical chunk c ^ ((R>>2)&3)
     const int ra0 = wr * 64 + l31, ra1 = ra0 + 32, rb = wc * 32 + l31;
     const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sbz = (rb >> 2) & 3;
-    const char* fA0 = smem + ra0 * 64;            // + ((chunk ^ sa0) << 4)
-    const char* fA1 = smem + ra1 * 64;
-    const char* fB = smem + (NPL - 1) * SW2_TILE + rb * 64;
-    const int oa00 = (g ^ sa0) << 4, oa01 = ((2 + g) ^ sa0) << 4;
-    const int oa10 = (g ^ sa1) << 4, oa11 = ((2 + g) ^ sa1) << 4;
-    const int ob0 = (g ^ sbz) << 4, ob1 = ((2 + g) ^ sbz) << 4;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned aA00 = lds0 + ra0 * 64 + ((g ^ sa0) << 4), aA01 = lds0 + ra0 * 64 + (((2 + g) ^ sa0) << 4);
+    const unsigned aA10 = lds0 + ra1 * 64 + ((g ^ sa1) << 4), aA11 = lds0 + ra1 * 64 + (((2 + g) ^ sa1) << 4);
+    const unsigned aB0 = lds0 + (NPL - 1) * PLANE + rb * 64 + ((g ^ sbz) << 4);
+    const unsigned aB1 = lds0 + (NPL - 1) * PLANE + rb * 64 + (((2 + g) ^ sbz) << 4);
 
     const int npre = min(SW2_NS - 1, total);
     for (int i = 0; i < npre; ++i) issue(i);
 
+    // Fragment reads are software pipelined one k-tile ahead with inline-asm ds_read_b128 and counted lgkmcnt waits
+    // (the compiler's wait insertion degrades to lgkmcnt(0) while an LDS-DMA is pending and, left alone, re-serialises
+    // read -> wait -> MFMA: a full LDS round trip exposed per k-tile with both waves of a SIMD in lock step).
+#define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    struct Fr { v4i b0, b1, a00, a10, a01, a11, c00, c10, c01, c11; };
+    constexpr int NRD = TWIN ? 10 : 6;                       // ds_reads per k-tile
+    auto read_fr = [&](Fr& f, auto stage_c) __attribute__((always_inline)) {
+        constexpr int SO = decltype(stage_c)::value * SW2_TILE;
+        P4V_DSR(f.b0, aB0, SO); P4V_DSR(f.a00, aA00, SO); P4V_DSR(f.a10, aA10, SO);
+        if (TWIN) { P4V_DSR(f.c00, aA00, SO + PLANE); P4V_DSR(f.c10, aA10, SO + PLANE); }
+        P4V_DSR(f.b1, aB1, SO); P4V_DSR(f.a01, aA01, SO); P4V_DSR(f.a11, aA11, SO);
+        if (TWIN) { P4V_DSR(f.c01, aA01, SO + PLANE); P4V_DSR(f.c11, aA11, SO + PLANE); }
+    };
+    Fr fa, fb;
     int kt = 0, c = c_lo;
-    // one k-tile with a COMPILE-TIME stage: every LDS address is a VGPR base + immediate offset
-    auto tile = [&](int it, auto stage_c) {
+    // step `it` (compile-time stage of tile it): tile it is in `cur` (read during step it-1).  Prove tile it+1 landed
+    // (own pieces waited for, then the barrier), refill the stage of tile it-1 with tile it+3, start the reads of
+    // tile it+1 into `nxt`, run the MFMAs of tile it.
+    auto tile = [&](int it, auto stage_c, Fr& cur, Fr& nxt) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_c)::value;
-        constexpr int SO = ST * STAGE;
-        if (it + 2 < total) wait_vmcnt<2 * NPL>(); else if (it + 1 < total) wait_vmcnt<NPL>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // tile `it` is in LDS for everyone; stage (it-1)%NS is free for everyone
-        if (it + SW2_NS - 1 < total && !(p.dbg & 1)) issue((ST + SW2_NS - 1) % SW2_NS);
-        if (p.dbg & 2) { if (++kt == ktiles) { kt = 0; ++c; } return; }
-        const v4i b0 = *reinterpret_cast<const v4i*>(fB + SO + ob0);
-        const v4i a00 = *reinterpret_cast<const v4i*>(fA0 + SO + oa00);
-        const v4i a10 = *reinterpret_cast<const v4i*>(fA1 + SO + oa10);
-        const v4i b1 = *reinterpret_cast<const v4i*>(fB + SO + ob1);
-        const v4i a01 = *reinterpret_cast<const v4i*>(fA0 + SO + oa01);
-        const v4i a11 = *reinterpret_cast<const v4i*>(fA1 + SO + oa11);
-        v4i c00, c10, c01, c11;
-        if (TWIN) {
-            c00 = *reinterpret_cast<const v4i*>(fA0 + SO + SW2_TILE + oa00);
-            c10 = *reinterpret_cast<const v4i*>(fA1 + SO + SW2_TILE + oa10);
-            c01 = *reinterpret_cast<const v4i*>(fA0 + SO + SW2_TILE + oa01);
-            c11 = *reinterpret_cast<const v4i*>(fA1 + SO + SW2_TILE + oa11);
+        if (it + 2 < total) wait_vmcnt<NPL>(); else wait_vmcnt<0>();   // pieces of tile it+2 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (it + SW2_NS - 1 < total) issue((ST + SW2_NS - 1) % SW2_NS);
+        if (it + 1 < total) {
+            read_fr(nxt, std::integral_constant<int, (ST + 1) % SW2_NS>{});
+            __builtin_amdgcn_s_waitcnt(0xC07F | (NRD << 8));          // the reads just issued stay in flight
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
         }
-        // keep the fragment reads ahead of the MFMAs (the scheduler otherwise re-serialises read->wait->mfma)
-        __builtin_amdgcn_sched_group_barrier(0x100, TWIN ? 10 : 6, 0);
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a00, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, b0, acc[1], 0, 0, 0);
+        asm volatile("" : "+v"(cur.b0), "+v"(cur.b1), "+v"(cur.a00), "+v"(cur.a10), "+v"(cur.a01), "+v"(cur.a11) :: "memory");
+        if (TWIN) asm volatile("" : "+v"(cur.c00), "+v"(cur.c10), "+v"(cur.c01), "+v"(cur.c11));
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a00, cur.b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a10, cur.b0, acc[1], 0, 0, 0);
         if (TWIN) {
-            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c00, b0, acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c10, b0, acc2[1], 0, 0, 0);
+            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c00, cur.b0, acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c10, cur.b0, acc2[1], 0, 0, 0);
         }
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01, b1, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a01, cur.b1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a11, cur.b1, acc[1], 0, 0, 0);
         if (TWIN) {
-            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c01, b1, acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c11, b1, acc2[1], 0, 0, 0);
+            acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c01, cur.b1, acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c11, cur.b1, acc2[1], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x8, TWIN ? 8 : 4, 0);
         if (++kt == ktiles) {
             // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             const float s1 = s1tab[(c - c_lo) * 8 + wid];
@@ -805,20 +812,23 @@ __global__ __launch_bounds__(512, TWIN ? 2 : 4) void k_sweep2(SweepParams p) {
                     acc[i][r] = 0; acc[i][r + 1] = 0;
                     if (TWIN) { acc2[i][r] = 0; acc2[i][r + 1] = 0; }
                 }
-            float sum = sum2.x + sum2.y;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);   // fixed butterfly: deterministic
-            if (lane == 0) res[(c - c_lo) * 8 + wid] = sum;
+            const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
+            if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
             kt = 0;
             ++c;
         }
     };
+    // tile 0
+    if (total > 2) wait_vmcnt<NPL * 2>(); else if (total > 1) wait_vmcnt<NPL>(); else wait_vmcnt<0>();   // tiles 1, 2 may be in flight
+    __builtin_amdgcn_s_barrier();
+    read_fr(fa, std::integral_constant<int, 0>{});
     for (int it = 0; it < total; it += SW2_NS) {
-        tile(it, std::integral_constant<int, 0>{});
-        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{});
-        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{});
-        if (it + 3 < total) tile(it + 3, std::integral_constant<int, 3>{});
+        tile(it, std::integral_constant<int, 0>{}, fa, fb);
+        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{}, fb, fa);
+        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{}, fa, fb);
+        if (it + 3 < total) tile(it + 3, std::integral_constant<int, 3>{}, fb, fa);
     }
+#undef P4V_DSR
     __syncthreads();
     // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
