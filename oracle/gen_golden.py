@@ -284,7 +284,64 @@ def gen_mini_vit(name="minivit_ptq4vit"):
     print(f"wrote {name}.npz ({len(wrapped)} modules)")
 
 
+def gen_integer(name="minivit_integer"):
+    """Reference utils/integer.py (quantize_int_weight, quantize_int_activation, get_model_int_weight) applied to
+    the calibrated mini ViT of minivit_ptq4vit.npz: the reference modules get the stored intervals, the stored
+    captured inputs are pushed through the reference's pre-hook.  Stored: int8 / uint8 images only."""
+    import types, importlib
+    _install_shims()
+    os.chdir(REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for sub in ("timm", "timm.models", "timm.models.vision_transformer", "timm.models.swin_transformer"):
+        sys.modules.setdefault(sub, types.ModuleType(sub))
+    sys.modules["timm.models.vision_transformer"].Attention = type("Attention", (torch.nn.Module,), {})
+    sys.modules["timm.models.swin_transformer"].WindowAttention = type("WindowAttention", (torch.nn.Module,), {})
+    ref_models = importlib.import_module("utils.models")
+    ref_wrap = importlib.import_module("utils.net_wrap")
+    ref_int = importlib.import_module("utils.integer")
+    cfg = importlib.import_module("configs.PTQ4ViT")
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    if repo not in sys.path:
+        sys.path.append(repo)
+    from ptq4vit_amd.utils import models as my_models
+    g = np.load(os.path.join(OUT, "minivit_ptq4vit.npz"), allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = my_models.get_net("vit_tiny_patch16_224", seed=0, device="cpu", **kw)
+    for m in list(net.modules()):
+        for cname, child in list(m.named_children()):
+            if isinstance(child, my_models.MatMul):
+                setattr(m, cname, ref_models.MatMul())
+    wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+    payload = {}
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            if f"{key}::{a}" in g.files:
+                setattr(m, a, torch.from_numpy(g[f"{key}::{a}"]))
+        m.calibrated = True
+        inputs = (torch.from_numpy(g[f"{key}::A"]), torch.from_numpy(g[f"{key}::B"])) if f"{key}::A" in g.files \
+            else (torch.from_numpy(g[f"{key}::x"]),)
+        if hasattr(m, "a_bit") and m.a_bit != 8:     # the patch-embedding conv keeps fp32 activations (PTQ4ViT.py:54)
+            continue
+        if len(inputs) == 2:
+            m._get_padding_parameters(*inputs)          # crb_* / pad_* (set by calibration in a real run, matmul.py:411-417)
+        ref_int.quantize_int_activation(m, inputs)
+        for i, t in enumerate(getattr(m, "int_input", [])):
+            payload[f"{key}::int_input{i}"] = t.numpy()
+    for n, w_int in ref_int.get_model_int_weight(wrapped).items():
+        payload[f"{n.replace('.', '__')}::w_int"] = w_int.numpy()
+        m = wrapped[n]
+        payload[f"{n.replace('.', '__')}::w_deq"] = ref_int.dequantize_int_weight(m, w_int).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **payload)
+    print(f"wrote {name}.npz ({len(payload)} arrays)")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)
-    if len(sys.argv) == 1:
-        gen_mini_vit()
+    if len(sys.argv) > 1 and sys.argv[1] == "integer":
+        gen_integer()
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else None)
+        if len(sys.argv) == 1:
+            gen_mini_vit()
+            gen_integer()

@@ -161,6 +161,12 @@ class PTQSLBatchingQuantMatMul(PTQSLQuantMatMul):
         numel = self.raw_input[0].numel() + self.raw_input[1].numel() + 2 * self.raw_out.numel()
         self.calib_batch_size, self.parallel_eq_n, self.calib_need_batching = calib_parameters(numel, self.calib_size)
 
+    def _get_padding_parameters(self, A, B):
+        """Head-wise quantisation (reference matmul.py:411-417): the group count follows the operands."""
+        self.n_G_A = A.shape[1]
+        self.n_G_B = B.shape[1]
+        super()._get_padding_parameters(A, B)
+
     def calibration_step2(self):
         self._initialize_calib_parameters()
         self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
