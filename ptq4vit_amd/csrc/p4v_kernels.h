@@ -1447,6 +1447,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
             *dst = ered;
         }
     };
+    const char* fillT = curT - p.ldk;                     // candidate being streamed in (warm-up: candidate 1 again)
+    int fill_stage = STG;
     // one step: prefetch the fragments of step s+2, wait for those of step s, 4 MFMAs, one epilogue slice
     auto step = [&](auto s_c, unsigned ad0, unsigned ad1, unsigned adn0, unsigned adn1, int ci) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
@@ -1473,6 +1475,13 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+        // the streamed tile of candidate ci+2 trickles in one 1 KB piece per step (a burst of KT pieces right after
+        // the barrier stalls the fragment reads of this single-wave-per-SIMD kernel)
+        {
+            constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
+            constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index
+            if constexpr (j < KT) glds16(fillT + j * SW_BKB, smem + fill_stage + j * KT_TILE + wid * 1024);
+        }
         // phase 0 carries the epilogue of block 1 of the previous candidate (slot ci), phase 1 that of block 0 of this one
         if constexpr (cb == 0) epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 1>{}, ci);
         else epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 0>{}, ci + 1);
@@ -1509,7 +1518,9 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, SB>{});
         wait_vmcnt<0>();                                  // own pieces of candidate ci+1 (issued one candidate ago)
         __builtin_amdgcn_s_barrier();                     // ci+1 visible to all; nobody reads the stage of ci-1 any more
-        issue((stage_n + STG == 3 * STG) ? 0 : stage_n + STG);   // candidate ci+2 -> stage of ci-1
+        fill_stage = (stage_n + STG == 3 * STG) ? 0 : stage_n + STG;   // candidate ci+2 -> stage of ci-1, piece by piece
+        fillT = curT;
+        curT += p.ldk;
         run(std::integral_constant<int, SB>{}, std::integral_constant<int, NSTEP>{});
         stage = stage_n;
     }
