@@ -337,11 +337,47 @@ def gen_integer(name="minivit_integer"):
     print(f"wrote {name}.npz ({len(payload)} arrays)")
 
 
+def gen_swin_attention(name="swin_window_attention"):
+    """Reference utils/models.py:28-56 `window_attention_forward` bound onto a window-attention module carrying the
+    build's parameters (timm's WindowAttention attributes: qkv, proj, relative_position_bias_table / _index, softmax,
+    scale, window_size, num_heads + the two MatMul modules): input, shift mask, output."""
+    import types, importlib
+    from types import MethodType
+    _install_shims()
+    os.chdir(REF)
+    for sub in ("timm", "timm.models", "timm.models.vision_transformer", "timm.models.swin_transformer"):
+        sys.modules.setdefault(sub, types.ModuleType(sub))
+    sys.modules["timm.models.vision_transformer"].Attention = type("Attention", (torch.nn.Module,), {})
+    sys.modules["timm.models.swin_transformer"].WindowAttention = type("WindowAttention", (torch.nn.Module,), {})
+    ref_models = importlib.import_module("utils.models")
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    if repo not in sys.path:
+        sys.path.append(repo)
+    from ptq4vit_amd.utils import models as my_models
+    torch.manual_seed(0)
+    blk = my_models.SwinBlock(24, (14, 14), num_heads=3, window_size=7, shift_size=3)
+    att = blk.attn
+    torch.nn.init.trunc_normal_(att.relative_position_bias_table, std=0.5)
+    att.matmul1, att.matmul2 = ref_models.MatMul(), ref_models.MatMul()
+    att.forward = MethodType(ref_models.window_attention_forward, att)
+    x = torch.randn(8, 49, 24)          # 2 images x 4 windows
+    with torch.no_grad():
+        y_mask = att(x, blk.attn_mask)
+        y_nomask = att(x)
+    sd = {k: v.numpy() for k, v in att.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x=x.numpy(), mask=blk.attn_mask.numpy(), y_mask=y_mask.numpy(),
+                        y_nomask=y_nomask.numpy(), **{"sd::" + k: v for k, v in sd.items()})
+    print(f"wrote {name}.npz")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "integer":
+    if len(sys.argv) > 1 and sys.argv[1] == "swin":
+        gen_swin_attention()
+    elif len(sys.argv) > 1 and sys.argv[1] == "integer":
         gen_integer()
     else:
         main(sys.argv[1] if len(sys.argv) > 1 else None)
         if len(sys.argv) == 1:
             gen_mini_vit()
             gen_integer()
+            gen_swin_attention()

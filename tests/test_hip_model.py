@@ -53,13 +53,12 @@ def test_modules_reproduce_reference_intervals_from_reference_captures():
     assert exact >= 0.97 * total, f"only {exact}/{total} intervals bit-identical to the reference"
 
 
-def test_calibrator_end_to_end_vs_oracle_on_gpu_captures():
+def _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.95):
+    """Run the calibrator on the GPU, record what every module captured, replay the oracle on those tensors."""
     from oracle.ptq4vit_oracle import ConvOracle, LinearOracle, MatMulOracle
     from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
     from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
-    g, net, wrapped = _mini()
-    images = torch.from_numpy(g["images"]).cuda()
 
     class Loader:
         batch_size = images.shape[0]
@@ -80,15 +79,16 @@ def test_calibrator_end_to_end_vs_oracle_on_gpu_captures():
     cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
     cal.batching_quant_calib()
     hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3)
+    npy = lambda t: None if t is None else t.detach().cpu().numpy()
     exact = total = 0
     for n, m in wrapped.items():
         ri, ro, rg = caps[n]
         if isinstance(m, MinMaxQuantLinear):
-            o = LinearOracle(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), w_bit=8, a_bit=8, n_V=m.n_V,
+            o = LinearOracle(npy(m.weight), npy(m.bias), w_bit=8, a_bit=8, n_V=m.n_V,
                              postgelu=type(m).__name__.startswith("PostGelu"), **hp)
             res = o.calibration_step2(ri, ro, rg)
         elif isinstance(m, MinMaxQuantConv2d):
-            o = ConvOracle(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), stride=m.stride, w_bit=8, a_bit=32, **hp)
+            o = ConvOracle(npy(m.weight), npy(m.bias), stride=m.stride, w_bit=8, a_bit=32, **hp)
             res = o.calibration_step2(ri, ro, rg)
             res.pop("a_interval")
         else:
@@ -101,9 +101,27 @@ def test_calibrator_end_to_end_vs_oracle_on_gpu_captures():
             assert rel.max() <= GRID_STEP, f"{n}.{a}: {rel.max():.3e}"
             exact += int((got == want).sum())
             total += want.size
-    assert exact >= 0.95 * total, f"only {exact}/{total} intervals bit-identical to the oracle"
+    assert exact >= min_exact * total, f"only {exact}/{total} intervals bit-identical to the oracle"
     with torch.no_grad():
         assert torch.isfinite(net(images)).all()      # every module now runs in quant_forward mode
+
+
+def test_calibrator_end_to_end_vs_oracle_on_gpu_captures():
+    g, net, wrapped = _mini()
+    _calibrate_and_compare_with_oracle(net, wrapped, torch.from_numpy(g["images"]).cuda())
+
+
+def test_swin_calibration_end_to_end_vs_oracle():
+    """Swin: window attention (batch = images x windows, shifted windows with mask), bias-free `reduction` Linear."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    net = models.get_net("swin_tiny_patch4_window7_224", seed=2, device="cuda", img_size=56, embed_dim=24, depths=(2, 2),
+                         num_heads=(2, 4), num_classes=10)
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.randn(8, 3, 56, 56, generator=torch.Generator().manual_seed(4)).cuda()
+    _calibrate_and_compare_with_oracle(net, wrapped, images)
 
 
 # ---- BASELINE-size properties (ViT-B/224 qkv: 32 x 197 x 768 -> 2304, n_V = 3) ------------------------
