@@ -33,23 +33,38 @@ class SyntheticLoader:
         yield self.images, torch.zeros(self.images.shape[0], dtype=torch.long)
 
 
-def search_macs(wrapped, calib, tokens, heads, head_dim, eq_n=100, rounds=3):
-    """Algorithmic MACs of the reference's candidate-sweep GEMMs for one calibration."""
+def search_macs(wrapped, shapes, calib, eq_n=100, rounds=3):
+    """Algorithmic MACs of the reference's candidate-sweep GEMMs for one calibration, from the
+    per-image operand shapes seen by a probe forward (`shapes[name]` = (input shapes, output shape) for 1 image)."""
     from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
     from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
     lin = mm = conv = 0.0
     for name, m in wrapped.items():
+        ins, out = shapes[name]
         if isinstance(m, MinMaxQuantLinear):
-            rows = calib * (1 if name == "head" else tokens)
+            rows = calib * int(torch.tensor(ins[0][:-1]).prod())
             lin += rounds * 2 * eq_n * rows * m.in_features * m.out_features
         elif isinstance(m, MinMaxQuantConv2d):
             k = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-            conv += rounds * eq_n * calib * (tokens - 1) * k * m.out_channels
+            conv += rounds * eq_n * calib * out[2] * out[3] * k * m.out_channels
         else:
             sos = type(m).__name__.startswith("SoS")
-            per = calib * heads * tokens * tokens * head_dim
+            A, B = ins
+            per = calib * A[0] * A[1] * A[2] * A[3] * B[3]          # (windows x) heads x M x K x N per image
             mm += rounds * ((20 + eq_n) if sos else 2 * eq_n) * per
     return lin, mm, conv
+
+
+def probe_shapes(net, wrapped, image):
+    shapes, hooks = {}, []
+    for n, m in wrapped.items():
+        hooks.append(m.register_forward_hook(
+            lambda mod, inp, out, _n=n: shapes.__setitem__(_n, ([tuple(t.shape) for t in inp], tuple(out.shape)))))
+    with torch.no_grad():
+        net(image)
+    for h in hooks:
+        h.remove()
+    return shapes
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -103,13 +118,11 @@ def main():
 
     net = models.get_net(args.model, seed=0, device=dev)
     wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
-    img = net.patch_embed.proj.kernel_size[0] * int(round((net.pos_embed.shape[1] - 1) ** 0.5))
+    img = models.input_size(args.model)
     g = torch.Generator(device="cpu").manual_seed(0)
     images = torch.randn(args.calib, 3, img, img, generator=g).to(dev)
     loader = SyntheticLoader(images)
-    tokens = net.pos_embed.shape[1]
-    heads = net.blocks[0].attn.num_heads
-    head_dim = net.blocks[0].attn.qkv.in_features // heads
+    shapes = probe_shapes(net, wrapped, images[:1])
 
     def one_step(search_streams=None):
         for m in wrapped.values():
@@ -157,7 +170,7 @@ def main():
         engine.stats_enable(False)
         if rank == 0 and st["sweep_i8_launches"] > 0:
             mine = {n: m for n, m in wrapped.items() if cal_r.owner[n] == rank}
-            lin, mm, conv = search_macs(mine, args.calib, tokens, heads, head_dim)
+            lin, mm, conv = search_macs(mine, shapes, args.calib)
             # ops of the reference GEMMs that the executed int8 sweep launches stand for (unpadded, one plane per
             # candidate); passes restored from the memo are not launched and are not counted here
             algo_ops = 2.0 * st["sweep_i8_alg_macs"]
@@ -176,7 +189,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, sample_macs = cpu_baseline()
-        lin, mm, conv = search_macs(wrapped, args.calib, tokens, heads, head_dim)
+        lin, mm, conv = search_macs(wrapped, shapes, args.calib)
         est_total = dt * (lin + mm + conv) / sample_macs
         try:
             from threadpoolctl import threadpool_info

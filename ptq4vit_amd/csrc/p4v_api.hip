@@ -277,8 +277,9 @@ int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t l
     return 0;
 }
 
-// k_sweep6 (stationary operand in registers): K = 192 / 384 / 768 bytes, the Linear layers of ViT/DeiT-T/S/B
-bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 6 || ktiles == 12; }
+// k_sweep6 (stationary operand in registers): K = 192 / 256 / 384 / 512 / 768 bytes -- the Linear layers of
+// ViT/DeiT-T/S/B and of Swin stages 2-3
+bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 4 || ktiles == 6 || ktiles == 8 || ktiles == 12; }
 
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
@@ -303,7 +304,9 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r = p.ktiles == 12 ? launch_sweep6_kt<12>(c, p, epi, grid, lds)
-          : p.ktiles == 6 ? launch_sweep6_kt<6>(c, p, epi, grid, lds) : launch_sweep6_kt<3>(c, p, epi, grid, lds);
+          : p.ktiles == 8 ? launch_sweep6_kt<8>(c, p, epi, grid, lds)
+          : p.ktiles == 6 ? launch_sweep6_kt<6>(c, p, epi, grid, lds)
+          : p.ktiles == 4 ? launch_sweep6_kt<4>(c, p, epi, grid, lds) : launch_sweep6_kt<3>(c, p, epi, grid, lds);
     if (r) return r;
     HIPCHK(hipGetLastError());
 #ifdef P4V_TRACE

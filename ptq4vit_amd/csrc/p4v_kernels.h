@@ -1411,10 +1411,10 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     float* dump = s1tab + per * 4;
 #define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct TF2 { v4i f[2]; };                 // the two 32-byte halves of one column block of one k-tile
-    constexpr int PD = 2;                     // fragment reads run PD steps ahead of their MFMAs (3 and 5 measured the same)
+    constexpr int PD = ((2 * KT) % 3 == 0) ? 2 : 3;   // fragment reads run PD steps ahead of their MFMAs (2, 3, 5 measured the same)
     constexpr int NB = PD + 1;                // fragment buffers, ring indexed by (step % NB)
     TF2 tf[NB];
-    static_assert((2 * KT) % NB == 0, "fragment ring needs 2 * KT divisible by the buffer count");
+    static_assert((2 * KT) % NB == 0 && KT >= 3, "fragment ring needs 2 * KT divisible by the buffer count");
     constexpr int NSTEP = 2 * KT;
     constexpr int NSL = KT - 2;                              // slices that carry element math
     constexpr int PPS = (16 + NSL - 1) / NSL;                // packed pairs per slice (16 pairs per column block)

@@ -298,6 +298,13 @@ _ZOO = {
 }
 
 
+def input_size(name):
+    """Image side the named model is defined for."""
+    if name in _SWIN_ZOO:
+        return _SWIN_ZOO[name][0]
+    return _ZOO[name][0]
+
+
 def get_net(name, seed=0, device=None, **overrides):
     """Build a ViT / DeiT / Swin by timm name (reference utils/models.py:62-91, without the pretrained download).
 

@@ -230,6 +230,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             return False
         inp = batches[0]
         total = inp.shape[0]
+        n_sub = total // bs
         mods = [self.wrapped_modules[n] for n in names]
 
         def reset():
@@ -270,7 +271,8 @@ class HessianQuantCalibrator(QuantCalibrator):
                 stat = [m.raw_input[0], m.raw_out[0]]
             if with_g:
                 stat.append(m.raw_grad[0])
-            full = [torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in stat]
+            # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
+            full = [torch.empty((n_sub * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in stat]
             if isinstance(m, MinMaxQuantMatMul):
                 m.raw_input, m.raw_out = [[full[0]], [full[1]]], [full[2]]
             else:
@@ -280,11 +282,11 @@ class HessianQuantCalibrator(QuantCalibrator):
             srcs += stat
             dsts.append(full)
         flat_dsts = [t for f in dsts for t in f]
-        for st in range(0, total, bs):
+        for i, st in enumerate(range(0, total, bs)):
             static_in.copy_(inp[st:st + bs])
             static_tgt.copy_(raw_pred_softmax[st:st + bs])
             graph.replay()
-            torch._foreach_copy_([t[st:st + bs] for t in flat_dsts], srcs)
+            torch._foreach_copy_([d[i * s.shape[0]:(i + 1) * s.shape[0]] for d, s in zip(flat_dsts, srcs)], srcs)
         return True
 
     def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad):

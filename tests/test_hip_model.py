@@ -234,7 +234,11 @@ def test_pass_memoisation_is_exact(vitb_qkv):
     assert st["memo_hits"] + st["memo_misses"] == 6 and st["memo_misses"] >= 2
 
 
-def test_graph_capture_equals_eager_capture():
+@pytest.mark.parametrize("model,side,kw", [
+    ("vit_tiny_patch16_224", 224, {}),
+    ("swin_tiny_patch4_window7_224", 56, dict(img_size=56, embed_dim=24, depths=(2, 2), num_heads=(2, 4), num_classes=10)),
+], ids=["vit", "swin"])
+def test_graph_capture_equals_eager_capture(model, side, kw):
     """The HIP-graph replay of the sub-batch passes records exactly what the eager passes record."""
     import contextlib, io
     from ptq4vit_amd.configs import PTQ4ViT
@@ -249,10 +253,10 @@ def test_graph_capture_equals_eager_capture():
             yield self.x, None
 
     dev = torch.device("cuda:0")
-    net = models.get_net("vit_tiny_patch16_224", seed=3, device=dev)
+    net = models.get_net(model, seed=3, device=dev, **kw)
     with contextlib.redirect_stdout(io.StringIO()):
         wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
-    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    x = torch.randn(8, 3, side, side, generator=torch.Generator().manual_seed(5)).to(dev)
     caps = []
     for use_graph in (True, False):
         cal = HessianQuantCalibrator(net, wrapped, L(x), sequential=False, batch_size=2)

@@ -158,6 +158,8 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=3, T=50, K=384, N=200, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=False),
     dict(b=2, T=70, K=768, N=300, n_V=1, w_bit=8, a_bit=8, metric="square_weighted_L2_norm", postgelu=False),
     dict(b=2, T=70, K=768, N=192, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
+    dict(b=3, T=49, K=256, N=128, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False),        # KT = 4 (Swin)
+    dict(b=3, T=49, K=512, N=192, n_V=3, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),        # KT = 8 (Swin)
 ], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-K{c['K']}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
