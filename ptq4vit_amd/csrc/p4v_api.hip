@@ -256,16 +256,16 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
     return 0;
 }
 
-template <int KT>
+template <int KT, int RB>
 int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds) {
 #define P4V_LAUNCH6(E)                                                                                         \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep6<E, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep6<E, KT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep6<E, KT>), grid, dim3(256), lds, c.st, p);                                  \
+        hipLaunchKernelGGL((k_sweep6<E, KT, RB>), grid, dim3(512 / RB), lds, c.st, p);                         \
     } while (0)
     switch (epi) {
         case EPI_SQ_W: P4V_LAUNCH6(EPI_SQ_W); break;
@@ -284,7 +284,12 @@ bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 4 || ktiles 
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 8 * sizeof(float) + (size_t)per * 4 * sizeof(float) + 64 * sizeof(float) + 256;
+    // 32-row blocks per wave: 2 = 4 waves, one per SIMD (default: bound by its own VALU + MFMA issue, LDS-light);
+    // 1 = 8 waves, two per SIMD (A/B variant 32: hides the VALU work but doubles the fragment reads -> LDS-bound;
+    // both measure 3.33 ms per fc1 search round on MI355X)
+    const int rb = (g_variant & 32) ? 1 : 2;
+    const int nw = 8 / rb;
+    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 2 * nw * sizeof(float) + (size_t)per * nw * sizeof(float) + 64 * sizeof(float) + 256;
     dim3 grid(p.stiles * p.ttiles, 1, cgroups);
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
@@ -303,10 +308,16 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
-    int r = p.ktiles == 12 ? launch_sweep6_kt<12>(c, p, epi, grid, lds)
-          : p.ktiles == 8 ? launch_sweep6_kt<8>(c, p, epi, grid, lds)
-          : p.ktiles == 6 ? launch_sweep6_kt<6>(c, p, epi, grid, lds)
-          : p.ktiles == 4 ? launch_sweep6_kt<4>(c, p, epi, grid, lds) : launch_sweep6_kt<3>(c, p, epi, grid, lds);
+    int r;
+#define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds))
+    switch (p.ktiles) {
+        case 12: r = P4V_KT(12); break;
+        case 8: r = P4V_KT(8); break;
+        case 6: r = P4V_KT(6); break;
+        case 4: r = P4V_KT(4); break;
+        default: r = P4V_KT(3); break;
+    }
+#undef P4V_KT
     if (r) return r;
     HIPCHK(hipGetLastError());
 #ifdef P4V_TRACE

@@ -1279,8 +1279,12 @@ __global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
 //     the latency of its first fragment reads.
 // Output tile orientation, scales, bias, partial-sum table and plane layout ([row][candidate][K], c_inner = 1)
 // are those of k_sweep4, so k_pack / k_finish are unchanged.
-template <int EPI, int KT>
-__global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
+// RB = 32-row blocks of the stationary operand per wave: RB = 2 -> 4 waves (one per SIMD, 512 registers each);
+// RB = 1 -> 8 waves (two per SIMD, 256 registers each): half the rows per wave, so one wave's epilogue VALU work and
+// LDS waits hide under the other wave's MFMAs, at twice the fragment reads per MFMA.
+template <int EPI, int KT, int RB>
+__global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Params p) {
+    constexpr int NW = 8 / RB;                           // waves per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P4V_TRACE
     unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
@@ -1297,39 +1301,49 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     const int nwg = p.stiles * p.ttiles;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
-    const int s0 = st * 256 + wid * 64, t0 = tt * 64;
+    const int s0 = st * 256 + wid * (32 * RB), t0 = tt * 64;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
     // ---- streaming operand [row][candidate][K]: wave w moves rows w*16 .. w*16+15 of every k-tile ----------------
-    const int ld_row = wid * 16 + (lane >> 2);
+    // a candidate's tile = 4 * KT pieces of 1 KB (16 rows x 64 B); wave w moves pieces w, w + NW, ...: piece q is
+    // row group q % 4 of k-tile q / 4
+    constexpr int NPC = 4 * KT;                          // pieces per candidate
+    constexpr int PPW = (NPC + NW - 1) / NW;             // pieces per wave
+    const int ld_row = (wid & 3) * 16 + (lane >> 2);
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
     const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
+    const int kt_w = wid >> 2;                           // first k-tile of this wave's pieces (NW = 8: 0 or 1)
+    auto piece = [&](const char* src, int stage_off, int j) __attribute__((always_inline)) {
+        // j-th piece of this wave: k-tile j * (NW / 4) + kt_w
+        const int kt = j * (NW / 4) + kt_w;
+        if (NPC % NW == 0 || NW * j + wid < NPC) glds16(src + kt * SW_BKB, smem + stage_off + kt * KT_TILE + (wid & 3) * 1024);
+    };
     auto issue = [&](int stage_off) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) glds16(curT + kt * SW_BKB, smem + stage_off + kt * KT_TILE + wid * 1024);
+        for (int j = 0; j < PPW; ++j) piece(curT, stage_off, j);
         curT += p.ldk;
     };
     issue(0);
     issue(STG);      // always two candidates ahead (slack behind the plane; stale stages are never consumed)
 
     // ---- stationary operand: 64 rows x K bytes of this wave, MFMA A-fragments, registers for the whole kernel -----
-    v4i sfr[KT][2][2];   // [k-tile][32-row block][32-byte half]
+    v4i sfr[KT][RB][2];   // [k-tile][32-row block][32-byte half]
     {
         const char* gS = (const char*)p.S + (long)(s0 + l31) * p.ldk + g * 16;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     sfr[kt][i][h] = *reinterpret_cast<const v4i*>(gS + (long)i * 32 * p.ldk + kt * SW_BKB + h * 32);
     }
 
     // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming) --
-    float u[2][2][16], w[2][2][16];
+    float u[RB][2][16], w[RB][2][16];
     // activation search: the tile is transposed (stationary rows = output features = the contiguous dimension), so
     // the four rows (r & 3) of one lane are 16 contiguous bytes -> one dwordx4 load instead of four scattered dwords
     const bool vec_ok = p.o_ss == 1 && (p.SR & 3) == 0 && (p.o_ts & 3) == 0 &&
@@ -1346,10 +1360,10 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
         const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
         const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
         const bool t_ok = tr < p.TR;
-        float bs[2][16];
+        float bs[RB][16];
         if (vec_ok) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int src = min(s0 + i * 32 + 8 * q + 4 * g, p.SR - 4);
@@ -1361,7 +1375,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
                 }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int src = min(s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1);
@@ -1372,7 +1386,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
                 }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = t_ok && (s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
@@ -1389,8 +1403,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
     // LDS behind the ring: res [(per + 1) candidates][8] (slot 0 is a dump for the warm-up epilogue), s1tab [per][4],
     // dump [64] (target of the lanes that do not hold the wave sum)
-    float* s1tab = res + (per + 1) * 8;
-    for (int i = lane; i < ncand; i += 64) s1tab[i * 4 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+    float* s1tab = res + (per + 1) * (2 * NW);
+    for (int i = lane; i < ncand; i += 64) s1tab[i * NW + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
     // ---- main loop ----------------------------------------------------------------------------------------------
     // One candidate = 2 phases (column block cb = 0, then 1) of KT steps; a step = 2 fragment reads + 4 MFMAs.  With a
@@ -1407,8 +1421,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     const unsigned tbase0 = lds0 + l31 * 64 + ((g ^ sw0) << 4);          // half 0; column block 1 is +2048
     const unsigned tbase1 = lds0 + l31 * 64 + (((2 + g) ^ sw0) << 4);    // half 1
-    const unsigned s1addr0 = lds0 + 3 * STG + (per + 1) * 32 + wid * 4;   // &s1tab[0 * 4 + wid]
-    float* dump = s1tab + per * 4;
+    const unsigned s1addr0 = lds0 + 3 * STG + (per + 1) * (8 * NW) + wid * 4;   // &s1tab[0 * NW + wid]
+    float* dump = s1tab + per * NW;
 #define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct TF2 { v4i f[2]; };                 // the two 32-byte halves of one column block of one k-tile
     constexpr int PD = ((2 * KT) % 3 == 0) ? 2 : 3;   // fragment reads run PD steps ahead of their MFMAs (2, 3, 5 measured the same)
@@ -1417,10 +1431,12 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     static_assert((2 * KT) % NB == 0 && KT >= 3, "fragment ring needs 2 * KT divisible by the buffer count");
     constexpr int NSTEP = 2 * KT;
     constexpr int NSL = KT - 2;                              // slices that carry element math
-    constexpr int PPS = (16 + NSL - 1) / NSL;                // packed pairs per slice (16 pairs per column block)
-    v16i acc[2][2];
+    constexpr int NPAIR = RB * 8;                            // packed pairs per column block
+    constexpr int PPS = (NPAIR + NSL - 1) / NSL;             // packed pairs per slice
+    v16i acc[RB][2];
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc[0][1] = zero16; acc[1][1] = zero16;                 // consumed by the warm-up epilogue of candidate "-1"
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i][1] = zero16;        // consumed by the warm-up epilogue of candidate "-1"
     v2f esum = {0.0f, 0.0f};
     float ered = 0.0f, es1 = 1.0f, es1_next = 1.0f;
     // epilogue slice `sl` of column block cbE; result goes to res slot `slot` (= candidate + 1)
@@ -1429,7 +1445,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
         if constexpr (sl == 0) esum = v2f{0.0f, 0.0f};
         if constexpr (sl < NSL) {
 #pragma unroll
-            for (int j = sl * PPS; j < (sl + 1) * PPS && j < 16; ++j) {
+            for (int j = sl * PPS; j < (sl + 1) * PPS && j < NPAIR; ++j) {
                 const int i = j >> 3, r = (j & 7) * 2;
                 const v2f a = {(float)acc[i][cbE][r], (float)acc[i][cbE][r + 1]};
                 const v2f uu = {u[i][cbE][r], u[i][cbE][r + 1]};
@@ -1443,7 +1459,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
         } else if constexpr (sl == NSL) {
             ered = wave_sum_dpp(esum.x + esum.y);
         } else {
-            float* dst = (lane == 63) ? res + slot * 8 + wid * 2 + cbE : dump + lane;   // branch-free: every lane stores
+            float* dst = (lane == 63) ? res + slot * (2 * NW) + wid * 2 + cbE : dump + lane;   // branch-free: every lane stores
             *dst = ered;
         }
     };
@@ -1462,7 +1478,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
             P4V_DSR(pre.f[0], adn0, (t - NSTEP) * KT_TILE); P4V_DSR(pre.f[1], adn1, (t - NSTEP) * KT_TILE);
         }
         if constexpr (s == 0) {   // scale of this candidate for the epilogues that start in phase 1
-            asm volatile("ds_read_b32 %0, %1" : "=v"(es1_next) : "v"(s1addr0 + ci * 16));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(es1_next) : "v"(s1addr0 + ci * (4 * NW)));
             __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * PD + 1) << 8));   // the scale read is newer than the fragments of this step
         } else {
             __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * PD) << 8));       // lgkmcnt(2 * PD): the fragments of steps s+1 .. s+PD stay in flight
@@ -1473,14 +1489,14 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
                 acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
-        // the streamed tile of candidate ci+2 trickles in one 1 KB piece per step (a burst of KT pieces right after
-        // the barrier stalls the fragment reads of this single-wave-per-SIMD kernel)
+        // the streamed tile of candidate ci+2 trickles in one 1 KB piece per wave and step (a burst right after the
+        // barrier stalls the fragment reads)
         {
             constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
-            constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index
-            if constexpr (j < KT) glds16(fillT + j * SW_BKB, smem + fill_stage + j * KT_TILE + wid * 1024);
+            constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index of this wave
+            if constexpr (j < PPW) piece(fillT, fill_stage, j);
         }
         // phase 0 carries the epilogue of block 1 of the previous candidate (slot ci), phase 1 that of block 0 of this one
         if constexpr (cb == 0) epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 1>{}, ci);
@@ -1532,9 +1548,12 @@ __global__ __launch_bounds__(256, 1) void k_sweep6(Sweep3Params p) {
     if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
-    for (int i = tid; i < ncand * 8; i += 256) {
-        const int cc = c_lo + i / 8, wv = (i % 8) >> 1, cb = i & 1;
-        p.part[(long)cc * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = res[8 + i];
+    // part[c][64-row slab][32-column group]; with RB = 1 two waves share a slab: fixed-order sum of their results
+    for (int i = tid; i < ncand * 8; i += 64 * NW) {
+        const int ci = i / 8, wv = (i % 8) >> 1, cb = i & 1;
+        const float* r = res + (ci + 1) * (2 * NW);
+        const float v = (RB == 2) ? r[wv * 2 + cb] : r[(2 * wv) * 2 + cb] + r[(2 * wv + 1) * 2 + cb];
+        p.part[(long)(c_lo + ci) * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = v;
     }
 #undef P4V_DSR
 #ifdef P4V_TRACE
