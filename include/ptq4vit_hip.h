@@ -70,7 +70,8 @@ typedef struct p4v_linear_desc {
     int32_t twin_postgelu;
     int32_t init_layerwise;
     int32_t has_bias;
-    int32_t reserved;     /* bit 0: force the generic fp32-operand path; bit 1: disable pass memoisation */
+    int32_t reserved;     /* bit 0: force the generic fp32-operand path; bit 1: disable pass memoisation;
+                             bit 2: p4v_linear_workspace_bytes sizes the workspace for p4v_linear_quant_forward only */
 } p4v_linear_desc;
 
 size_t p4v_linear_workspace_bytes(const p4v_linear_desc* desc);
@@ -104,7 +105,7 @@ typedef struct p4v_matmul_desc {
     int32_t search_round;
     int32_t sos;
     int32_t init_layerwise;
-    int32_t reserved;
+    int32_t reserved;           /* bit 1: disable pass memoisation; bit 2: workspace query for quant_forward only */
 } p4v_matmul_desc;
 
 size_t p4v_matmul_workspace_bytes(const p4v_matmul_desc* desc);
@@ -161,6 +162,25 @@ int p4v_quantize_i8(const float* d_x, int64_t rows, int64_t cols, int64_t cols_p
 /* y = clamp(rint(x / s), lo, hi) * s  (fake quantisation, fp32 in / fp32 out), same scale indexing. */
 int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_scales, int64_t rows_per_scale,
                    int32_t lo, int32_t hi, float* d_y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * quant_forward of a calibrated module as ONE integer GEMM:
+ * Linear (reference linear.py:62-67; post-GELU twin linear.py:601-607 with `twin_postgelu`), MatMul (matmul.py:140-145;
+ * split-of-softmax matmul.py:595-598 with `sos`).  Operands are quantised to int8 grid planes (the twin's two ranges
+ * as two planes), multiplied on the int8 MFMA path and rescaled in the epilogue:
+ *     out = s_a * s_w[block] * (k_x . k_w) + bias              (same arithmetic as the candidate sweeps).
+ * Intervals are INPUTS here (device pointers, layouts as produced by p4v_*_calibrate); the descriptors' search
+ * fields (metric, eq_n, search_round) are ignored.  Workspace: p4v_linear_workspace_bytes / p4v_matmul_workspace_bytes.
+ * Same restrictions as the int8 search path: n_H = n_a = 1 runs on int8, other block layouts on the fp32 MFMA path.
+ * ---------------------------------------------------------------------------------------- */
+int p4v_linear_quant_forward(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                             const float* d_w_interval, const float* d_a_interval, float* d_out, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* d_A_interval: [heads] (sos: [1]); d_B_interval: [heads]; d_split: [1] (sos only); d_out: [batch*heads][M][N] */
+int p4v_matmul_quant_forward(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_A_interval,
+                             const float* d_B_interval, const float* d_split, float* d_out, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* Timing hook used by bench.py: when non-NULL, the named events bracket every launch of the dominant
  * sweep kernel on `stream` so its duration can be measured live with HIP events. */

@@ -50,6 +50,7 @@ EXPORTS = [
     "p4v_linear_workspace_bytes", "p4v_linear_calibrate",
     "p4v_matmul_workspace_bytes", "p4v_matmul_calibrate",
     "p4v_conv_workspace_bytes", "p4v_conv_calibrate",
+    "p4v_linear_quant_forward", "p4v_matmul_quant_forward",
     "p4v_quantize_i8", "p4v_fake_quant",
     "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
 ]
@@ -86,6 +87,10 @@ def load():
     lib.p4v_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     lib.p4v_conv_calibrate.restype = C.c_int
     lib.p4v_conv_calibrate.argtypes = [C.POINTER(ConvDesc), fp, fp, fp, fp, fp, fp, fp, fp, fp, ip, vp, C.c_size_t, vp]
+    lib.p4v_linear_quant_forward.restype = C.c_int
+    lib.p4v_linear_quant_forward.argtypes = [C.POINTER(LinearDesc), fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
+    lib.p4v_matmul_quant_forward.restype = C.c_int
+    lib.p4v_matmul_quant_forward.argtypes = [C.POINTER(MatMulDesc), fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
     lib.p4v_quantize_i8.restype = C.c_int
     lib.p4v_quantize_i8.argtypes = [fp, C.c_int64, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
     lib.p4v_fake_quant.restype = C.c_int

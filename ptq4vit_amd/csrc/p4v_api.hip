@@ -149,6 +149,7 @@ template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams&
         case EPI_ABS: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_ABS>), grid, block, lds, c.st, p); break;
         case EPI_W_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_W_SQ>), grid, block, lds, c.st, p); break;
         case EPI_STORE: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_STORE>), grid, block, lds, c.st, p); break;
+        case EPI_FWD: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_FWD>), grid, block, lds, c.st, p); break;
         default: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_COS>), grid, block, lds, c.st, p); break;
     }
     HIPCHK(hipGetLastError());
@@ -635,7 +636,8 @@ PackParams pack2d(const float* src, long rows, long cols, long ld) {
 // ------------------------------------------------------------------------------------------------
 int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, const float* X, const float* O,
                 const float* G, const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out,
-                Ctx& c) {
+                Ctx& c, float* fwd_out = nullptr) {
+    // fwd_out != nullptr: quant_forward (linear.py:62-67 / 601-607) -- w_iv / a_iv are INPUTS, nothing is searched
     const int M = d->batch * d->tokens, K = d->in_features, N = d->out_features;
     const int nV = d->n_V, nH = d->n_H, nA = d->n_a;
     if (M <= 0 || K <= 0 || N <= 0 || nV <= 0 || nH <= 0 || nA <= 0 || d->eq_n <= 0)
@@ -648,11 +650,11 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
-    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "linear: hessian metric needs raw_grad (linear.py:418)");
-    const bool general = (nH > 1 || nA > 1 || (d->reserved & 1) || (cosm && d->twin_postgelu));
+    if (wt_mode == 1 && !G && !fwd_out) return fail(P4V_ERR_INVALID, "linear: hessian metric needs raw_grad (linear.py:418)");
+    const bool general = (nH > 1 || nA > 1 || (d->reserved & 1) || (cosm && d->twin_postgelu && !fwd_out));
     const bool i8 = !general;
     const bool twin = d->twin_postgelu && i8;
-    if (cosm && (nH > 1 || nA > 1)) return fail(P4V_ERR_UNSUPPORTED, "linear: cosine with n_H>1 / n_a>1 is not implemented on the GPU");
+    if (cosm && !fwd_out && (nH > 1 || nA > 1)) return fail(P4V_ERR_UNSUPPORTED, "linear: cosine with n_H>1 / n_a>1 is not implemented on the GPU");
     const int ncand = d->eq_n + 1;
 
     // ---- interval initialisation (linear.py:380-397 / 576-599) ---------------------------------------
@@ -664,7 +666,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     float* w_mix = c.ws.get<float>((size_t)ncand * nV * nH);   // general path: candidates of block column h only
     float* a_mix = c.ws.get<float>((size_t)ncand * nA);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
-    {
+    if (!fwd_out) {
         const long stw[4] = {0, 0, K, 1};
         CHK(launch_absmax(c, W, stw, 1, 1, N, K, nV, nH, crb_rows, crb_cols, 0, enc_w));
         CHK(launch_interval(c, enc_w, nV * nH, (float)(wq - 0.5), d->init_layerwise, w_iv));
@@ -712,6 +714,23 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         return op;
     };
 
+    if (fwd_out) {
+        // out = Q_a(x) . Q_w(W)^T + bias as ONE integer GEMM: grid indices packed to int8 planes (the twin's two ranges
+        // as two planes), scales s_a * s_w[block] applied to the int32 accumulators in the epilogue
+        Pass fp{};
+        fp.i8 = i8; fp.twin = twin; fp.epi = EPI_FWD; fp.wt_mode = 0; fp.eq_n = 1; fp.K = K;
+        fp.Z = 1; fp.Mrows = M; fp.Ncols = N;
+        fp.row = x_operand(false, a_iv, 0);
+        if (twin) fp.row2 = xneg_operand();
+        fp.col = w_operand(false, w_iv, 0, false);
+        fp.use_s1 = i8; fp.s_cs = nV; fp.sb_mode = 1; fp.sb_div = crb_rows;
+        fp.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_iv, 0, 1, 0.f, 0, 0, nullptr};
+        fp.s2 = ScaleParams{nullptr, 0, 0, a_neg, w_iv, 0, 1, 0.f, 0, 0, nullptr};
+        fp.bias = bias; fp.bias_axis = 0; fp.bias_zs = 0;
+        fp.O = fwd_out; fp.G = nullptr; fp.o_ms = N; fp.o_ns = 1; fp.o_inner = INT_MAX;
+        fp.nj = 1; fp.store_out = fwd_out;
+        return run_pass(c, fp);
+    }
     const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
     std::vector<float> key, val;
@@ -847,7 +866,9 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
 // MatMul
 // ------------------------------------------------------------------------------------------------
 int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const float* O, const float* G,
-                const float* mult, float* A_iv, float* B_iv, float* split, float* scores_out, int32_t* best_out, Ctx& c) {
+                const float* mult, float* A_iv, float* B_iv, float* split, float* scores_out, int32_t* best_out, Ctx& c,
+                float* fwd_out = nullptr) {
+    // fwd_out != nullptr: quant_forward (matmul.py:140-145; sos: matmul.py:595-598) -- intervals / split are INPUTS
     const int H = d->heads, Z = d->batch * d->heads, M = d->M, K = d->K, N = d->N;
     if (Z <= 0 || M <= 0 || K <= 0 || N <= 0 || d->eq_n <= 0) return fail(P4V_ERR_INVALID, "matmul: non-positive dimension");
     if (d->A_bit > 8 || d->B_bit > 8) return fail(P4V_ERR_UNSUPPORTED, "matmul: bit widths <= 8 supported");
@@ -855,7 +876,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
-    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
+    if (wt_mode == 1 && !G && !fwd_out) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
     if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
     const int ncand = d->eq_n + 1;
     const int NSPLIT = 20;  // matmul.py:636
@@ -867,7 +888,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     float* split_cands = c.ws.get<float>(NSPLIT);
     float* A_headwise = c.ws.get<float>(H);   // sos: the inherited head-wise A interval is computed then overwritten (matmul.py:419-440)
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
-    {
+    if (!fwd_out) {
         const long sa[4] = {d->a_stride[0], d->a_stride[1], d->a_stride[2], d->a_stride[3]};
         const long sb[4] = {d->b_stride[0], d->b_stride[1], d->b_stride[2], d->b_stride[3]};
         float* a_dst = d->sos ? A_headwise : A_iv;
@@ -918,6 +939,23 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
                ps.cos_ZB = Z; ps.cos_ZV = 1; }
     };
 
+    if (fwd_out) {
+        Pass fp{};
+        fp.Z = Z; fp.K = K; fp.Mrows = M; fp.Ncols = N;
+        fp.i8 = true; fp.twin = d->sos; fp.epi = EPI_FWD; fp.wt_mode = 0; fp.eq_n = 1;
+        fp.row = d->sos ? A_operand(false, split, 0, PACK_SOS_HI) : A_operand(false, A_iv, 0, PACK_SYM);
+        if (d->sos) fp.row2 = A_operand(false, split, 0, PACK_SOS_LO);
+        fp.col = B_operand(false, B_iv, 0, PACK_SYM);
+        fp.use_s1 = true; fp.s_cs = H; fp.sb_mode = 2; fp.sb_div = H;
+        if (!d->sos) fp.s1 = ScaleParams{A_iv, 0, 1, 0.f, B_iv, 0, 1, 0.f, 0, 0, nullptr};
+        else {
+            fp.s1 = ScaleParams{nullptr, 0, 0, 1.0f / (float)(Aq - 1), B_iv, 0, 1, 0.f, 0, 0, nullptr};
+            fp.s2 = ScaleParams{A_iv, 0, 0, 0.f, B_iv, 0, 1, 0.f, 0, 0, nullptr};
+        }
+        fp.O = fwd_out; fp.G = nullptr; fp.o_zs = (long)M * N; fp.o_ms = N; fp.o_ns = 1; fp.o_inner = INT_MAX;
+        fp.nj = 1; fp.store_out = fwd_out;
+        return run_pass(c, fp);
+    }
     const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_A, memo_B;
     std::vector<float> key, val;
@@ -1147,7 +1185,8 @@ const char* p4v_last_error(void) { return g_err.c_str(); }
 size_t p4v_linear_workspace_bytes(const p4v_linear_desc* desc) {
     if (!desc) return 0;
     Ctx c{nullptr, Arena(nullptr, 0), true};   // dry run of the planner: counts, launches nothing
-    if (linear_impl(desc, nullptr, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, nullptr, nullptr, c) != 0) return 0;
+    float* fwd = (desc->reserved & 4) ? (float*)16 : nullptr;   // bit 2: size the workspace for quant_forward only
+    if (linear_impl(desc, nullptr, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, nullptr, nullptr, c, fwd) != 0) return 0;
     return c.ws.peak + 4096;
 }
 
@@ -1163,11 +1202,34 @@ int p4v_linear_calibrate(const p4v_linear_desc* desc, const float* d_weight, con
                        d_a_interval, d_scores, d_best, c);
 }
 
+int p4v_linear_quant_forward(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                             const float* d_w_interval, const float* d_a_interval, float* d_out, void* d_workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_w_interval || !d_a_interval || !d_out || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_linear_quant_forward: null pointer");
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "p4v_linear_quant_forward: has_bias set but d_bias is null");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return linear_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, nullptr, nullptr, nullptr,
+                       const_cast<float*>(d_w_interval), const_cast<float*>(d_a_interval), nullptr, nullptr, c, d_out);
+}
+
+int p4v_matmul_quant_forward(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_A_interval,
+                             const float* d_B_interval, const float* d_split, float* d_out, void* d_workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (!desc || !d_A || !d_B || !d_A_interval || !d_B_interval || !d_out || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_matmul_quant_forward: null pointer");
+    if (desc->sos && !d_split) return fail(P4V_ERR_INVALID, "p4v_matmul_quant_forward: sos needs d_split");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return matmul_impl(desc, d_A, d_B, nullptr, nullptr, nullptr, const_cast<float*>(d_A_interval),
+                       const_cast<float*>(d_B_interval), const_cast<float*>(d_split), nullptr, nullptr, c, d_out);
+}
+
 size_t p4v_matmul_workspace_bytes(const p4v_matmul_desc* desc) {
     if (!desc) return 0;
     Ctx c{nullptr, Arena(nullptr, 0), true};
     float dummy = 0;
-    if (matmul_impl(desc, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, c) != 0) return 0;
+    float* fwd = (desc->reserved & 4) ? (float*)16 : nullptr;
+    if (matmul_impl(desc, nullptr, nullptr, nullptr, (const float*)1, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, c, fwd) != 0) return 0;
     return c.ws.peak + 4096;
 }
 

@@ -337,6 +337,7 @@ enum EpiMode {
     EPI_COS = 4,   // cosine: per-row dot / norm partials (rows of the MFMA tile = features)
     EPI_STORE = 5  // no metric: store raw_out - bias - scale*acc as an fp32 [M][N] tensor (candidate-invariant
                    // part of a twin operand folded into the target, see linear_impl)
+    ,EPI_FWD = 6   // quant_forward: store scale*acc (+ scale2*acc2) + bias -- the quantised layer's output
 };
 
 struct SweepParams {
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const bool ncol_ok = n < p.N;
     const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
     const float bias_n = (biasz && ncol_ok && p.bias_axis == 0) ? biasz[n] : 0.0f;
-    {
+    if constexpr (EPI != EPI_FWD) {
         // Phase 1: every load of the raw_out / weight tile issued back to back at clamped (always valid) addresses.
         // (A load inside a per-element branch costs one dependent memory round trip per element.)
         const int nc = min(n, p.N - 1);
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
             const int c = p.c0 + it / p.ktiles;
             const float s1 = p.S1 ? p.S1[c * p.s_cs + sb] : 1.0f;
             const float s2 = (TWIN && p.S2) ? p.S2[c * p.s_cs + sb] : 1.0f;
-            if constexpr (EPI == EPI_STORE) {
+            if constexpr (EPI == EPI_STORE || EPI == EPI_FWD) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -545,7 +546,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
                         const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                         float o_sim = (float)acc[i][r] * s1;
                         if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
-                        if (ncol_ok && m < p.M) p.store[(long)z * p.M * p.N + (long)m * p.N + n] = u[i][r] - o_sim;
+                        const float v = (EPI == EPI_FWD) ? o_sim + bias_n : u[i][r] - o_sim;
+                        if (ncol_ok && m < p.M) p.store[(long)z * p.M * p.N + (long)m * p.N + n] = v;
                     }
             } else if constexpr (EPI != EPI_COS) {
                 float colsum = 0.0f;

@@ -105,6 +105,60 @@ def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alp
     return w_iv, a_iv, scores, best
 
 
+def linear_quant_forward(*, weight, bias, x, w_interval, a_interval, w_bit, a_bit, n_V, n_H, n_a, postgelu=False):
+    """quant_forward of a calibrated (post-GELU) Linear as one int8 MFMA GEMM (p4v_linear_quant_forward)."""
+    lib = _lib.load()
+    dev = device_of(x, weight)
+    weight, bias, x = (to_dev(t, dev) for t in (weight, bias, x))
+    x = x.contiguous(); weight = weight.contiguous()
+    batch, K = x.shape[0], x.shape[-1]
+    tokens = x.numel() // (batch * K)
+    N = weight.shape[0]
+    d = _lib.LinearDesc(batch, tokens, K, N, n_V, n_H, n_a, w_bit, a_bit, metric_id("L2_norm"), 1, 1,
+                        int(postgelu), 0, int(bias is not None), 4)
+    need = lib.p4v_linear_workspace_bytes(C.byref(d))
+    if need == 0:
+        _lib.check(-2, "p4v_linear_workspace_bytes")
+    ws = workspace(dev, need)
+    w_iv = to_dev(w_interval, dev).reshape(-1).contiguous()
+    a_iv = to_dev(a_interval, dev).reshape(-1).contiguous()
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.p4v_linear_quant_forward(C.byref(d), ptr(weight), ptr(bias), ptr(x), ptr(w_iv), ptr(a_iv), ptr(out),
+                                          ptr(ws), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "p4v_linear_quant_forward")
+    return out
+
+
+def matmul_quant_forward(*, A, B, A_interval, B_interval, split, A_bit, B_bit, sos=False):
+    """quant_forward of a calibrated MatMul (head-wise intervals; optional split-of-softmax twin on A)."""
+    lib = _lib.load()
+    dev = device_of(A, B)
+    A, B = to_dev(A, dev), to_dev(B, dev)
+    b, H, M, K = A.shape
+    N = B.shape[3]
+    d = _lib.MatMulDesc()
+    d.batch, d.heads, d.M, d.K, d.N = b, H, M, K, N
+    for i in range(4):
+        d.a_stride[i] = A.stride(i)
+        d.b_stride[i] = B.stride(i)
+    d.A_bit, d.B_bit, d.metric, d.eq_n, d.search_round = A_bit, B_bit, metric_id("L2_norm"), 1, 1
+    d.sos, d.init_layerwise, d.reserved = int(sos), 0, 4
+    need = lib.p4v_matmul_workspace_bytes(C.byref(d))
+    if need == 0:
+        _lib.check(-2, "p4v_matmul_workspace_bytes")
+    ws = workspace(dev, need)
+    A_iv = to_dev(A_interval, dev).reshape(-1).contiguous()
+    B_iv = to_dev(B_interval, dev).reshape(-1).contiguous()
+    sp = to_dev(split, dev).reshape(-1).contiguous() if sos else None
+    out = torch.empty(b, H, M, N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.p4v_matmul_quant_forward(C.byref(d), ptr(A), ptr(B), ptr(A_iv), ptr(B_iv), ptr(sp), ptr(out),
+                                          ptr(ws), ws.numel(), stream_ptr(dev))
+    _lib.check(rc, "p4v_matmul_quant_forward")
+    return out
+
+
 def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
                      sos=False, init_layerwise=False, want_scores=False):
     """Run calibration_step2 of a MatMul (head-wise; optional split-of-softmax on A) on the GPU."""

@@ -100,6 +100,29 @@ class PTQSLQuantLinear(MinMaxQuantLinear):
         xg = x.reshape(*x.shape[:-1], self.n_a, self.crb_acts)
         return fake_quant(xg, self.a_interval, -self.a_qmax, self.a_qmax - 1).reshape(x.shape)
 
+    # ---- int8 inference path --------------------------------------------------
+    int8_forward = True   # GPU tensors, no autograd: quant_forward runs as ONE int8 MFMA GEMM (p4v_linear_quant_forward)
+
+    def _positive_a_interval(self):
+        return self.a_interval[0] if isinstance(self.a_interval, (list, tuple)) else self.a_interval
+
+    def quant_forward(self, x):
+        """Reference linear.py:62-67.  out = Q_a(x) . Q_w(W)^T + bias; on the GPU the product is taken on the integer
+        grid indices (exact int32 accumulation) and rescaled by s_a * s_w[block] -- the arithmetic of the candidate
+        sweeps; the fake-quant fp32 formulation below is kept for CPU tensors and whenever autograd is recording."""
+        assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        if (self.int8_forward and x.is_cuda and self.w_bit <= 8 and self.a_bit <= 8
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            try:
+                return engine.linear_quant_forward(
+                    weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=x,
+                    w_interval=self.w_interval, a_interval=self._positive_a_interval(), w_bit=self.w_bit,
+                    a_bit=self.a_bit, n_V=self.n_V, n_H=self.n_H, n_a=self.n_a, postgelu=self._postgelu)
+            except NotImplementedError:
+                pass
+        w_sim, bias_sim = self.quant_weight_bias()
+        return F.linear(self.quant_input(x), w_sim, bias_sim)
+
     # ---- the GPU search ---------------------------------------------------------------------
     def _search_on_gpu(self, x, raw_out, raw_grad):
         """p4v_linear_calibrate: replaces linear.py:536-555 (and :235-260 for the non-batching classes)."""

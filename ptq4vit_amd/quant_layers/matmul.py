@@ -98,8 +98,24 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
     def quant_input_B(self, x):
         return self._quant_blocked(x, "B", self.B_interval, self.B_qmax)
 
+    int8_forward = True   # GPU tensors, no autograd: quant_forward runs as ONE int8 MFMA GEMM (p4v_matmul_quant_forward)
+
     def quant_forward(self, A, B):
+        """Reference matmul.py:140-145 (SoS operand: matmul.py:595-598).  On the GPU the product is taken on the grid
+        indices (head-wise intervals; the split-of-softmax operand as its two range planes) and rescaled in the
+        epilogue; the fake-quant fp32 formulation is kept for CPU tensors, autograd and block layouts other than
+        head-wise."""
         assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        headwise = (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) == (1, 1, 1, 1) and A.dim() == 4 and \
+            self.n_G_B == A.shape[1] and (self._sos or self.n_G_A == A.shape[1])
+        if (self.int8_forward and A.is_cuda and headwise and self.A_bit <= 8 and self.B_bit <= 8
+                and not (torch.is_grad_enabled() and (A.requires_grad or B.requires_grad))):
+            try:
+                return engine.matmul_quant_forward(A=A, B=B, A_interval=self.A_interval, B_interval=self.B_interval,
+                                                   split=self.split if self._sos else None, A_bit=self.A_bit,
+                                                   B_bit=self.B_bit, sos=self._sos)
+            except NotImplementedError:
+                pass
         return self.quant_input_A(A) @ self.quant_input_B(B)
 
     # ---- the GPU search --------------------------------------------------------------------------

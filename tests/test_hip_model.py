@@ -326,3 +326,36 @@ def test_graph_capture_equals_eager_capture(model, side, kw):
     for n in caps[0]:
         for a, b in zip(caps[0][n], caps[1][n]):
             assert a.shape == b.shape and torch.equal(a, b), n
+
+
+def test_int8_quant_forward_matches_fake_quant_forward():
+    """Row f-2: quant_forward on the int8 MFMA path (integer accumulation, scales in the epilogue) against the
+    reference's fake-quant fp32 formulation, for every wrapped module of the calibrated mini ViT.
+    Tolerance: 2e-5 of the output range (fp32 accumulation noise of the fp32 GEMM; the integer path is exact)."""
+    g, net, wrapped = _mini()
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    from ptq4vit_amd.quant_layers.matmul import MinMaxQuantMatMul
+    checked = 0
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            if f"{key}::{a}" in g.files:
+                setattr(m, a, torch.from_numpy(g[f"{key}::{a}"]).cuda())
+        m.calibrated = True
+        if isinstance(m, MinMaxQuantConv2d):
+            continue
+        if isinstance(m, MinMaxQuantMatMul):
+            ins = (torch.from_numpy(g[f"{key}::A"]).cuda(), torch.from_numpy(g[f"{key}::B"]).cuda())
+            m._get_padding_parameters(*ins)
+        else:
+            ins = (torch.from_numpy(g[f"{key}::x"]).cuda(),)
+        with torch.no_grad():
+            m.int8_forward = True
+            y_int = m.quant_forward(*ins)
+            m.int8_forward = False
+            y_ref = m.quant_forward(*ins)
+        assert y_int.shape == y_ref.shape, n
+        err = (y_int - y_ref).abs().max().item()
+        assert err <= 2e-5 * y_ref.abs().max().item() + 1e-7, f"{n}: {err:.3e} vs range {y_ref.abs().max().item():.3e}"
+        checked += 1
+    assert checked == 13
