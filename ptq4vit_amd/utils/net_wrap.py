@@ -1,4 +1,5 @@
 """Swap Linear / Conv2d / MatMul modules of a net for quant modules (reference utils/net_wrap.py:39-81)."""
+import torch
 import torch.nn as nn
 
 from .models import MatMul
@@ -6,6 +7,30 @@ from .models import MatMul
 MODULE_TYPES = {"qkv": "qlinear_qkv", "proj": "qlinear_proj", "fc1": "qlinear_MLP_1", "fc2": "qlinear_MLP_2",
                 "head": "qlinear_classifier", "matmul1": "qmatmul_qk", "matmul2": "qmatmul_scorev",
                 "reduction": "qlinear_reduction"}
+
+
+def _fold_bn(conv_module, bn_module):
+    """(weight, bias) of `conv` followed by `bn` in eval mode as one convolution (reference utils/net_wrap.py:8-28):
+    y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta  ==  conv'(x) with W' = W * k, b' = (b - mean) * k + beta,
+    k = gamma / sqrt(var + eps) per output channel (gamma = 1, beta = 0 when the BatchNorm is not affine)."""
+    std = torch.sqrt(bn_module.running_var + bn_module.eps)
+    gamma = bn_module.weight if bn_module.affine else torch.ones_like(std)
+    beta = bn_module.bias if bn_module.affine else torch.zeros_like(std)
+    k = gamma / std
+    weight = conv_module.weight.data * k.view(conv_module.out_channels, 1, 1, 1)
+    b0 = conv_module.bias if conv_module.bias is not None else torch.zeros_like(std)
+    bias = (b0 - bn_module.running_mean) * k + beta
+    return weight, bias
+
+
+def fold_bn_into_conv(conv_module, bn_module):
+    """In-place version (reference utils/net_wrap.py:30-36); creates the conv bias if it had none."""
+    w, b = _fold_bn(conv_module, bn_module)
+    if conv_module.bias is None:
+        conv_module.bias = nn.Parameter(b.data)
+    else:
+        conv_module.bias.data = b.data
+    conv_module.weight.data = w.data
 
 
 def _parent_and_leaf(net, name):

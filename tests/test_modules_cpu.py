@@ -170,3 +170,24 @@ def test_one_pass_capture_equals_reference_capture(budget):
             np.testing.assert_array_equal(ri.numpy(), g[f"{key}::x"])
         np.testing.assert_array_equal(ro.numpy(), g[f"{key}::out"])
         np.testing.assert_array_equal(rg.numpy(), g[f"{key}::grad"])
+
+
+def test_fold_bn_into_conv_matches_conv_then_bn():
+    """utils/net_wrap.fold_bn_into_conv (reference net_wrap.py:8-36): conv' == bn(conv), affine or not, bias or not."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 9, 9, generator=g)
+    for affine in (True, False):
+        for bias in (True, False):
+            conv = torch.nn.Conv2d(3, 5, 3, bias=bias)
+            bn = torch.nn.BatchNorm2d(5, affine=affine).eval()
+            bn.running_mean.copy_(torch.randn(5, generator=g))
+            bn.running_var.copy_(torch.rand(5, generator=g) + 0.5)
+            if affine:
+                bn.weight.data.copy_(torch.randn(5, generator=g))
+                bn.bias.data.copy_(torch.randn(5, generator=g))
+            with torch.no_grad():
+                want = bn(conv(x))
+                net_wrap.fold_bn_into_conv(conv, bn)
+                got = conv(x)
+            assert conv.bias is not None
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
