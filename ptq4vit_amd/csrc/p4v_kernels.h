@@ -648,11 +648,19 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int wr = wid >> 2, wc = wid & 3;
     const int g = lane >> 5, l31 = lane & 31;
 
-    // tile order: workgroups that share the tile of the candidate-EXPANDED operand are adjacent (same XCD L2)
+    // Tile order.  The ~32 workgroups that run concurrently on one XCD (consecutive t after xcd_remap) should touch as
+    // few DISTINCT operand tiles as possible: every k-tile step they pull (distinct A tiles) x 8 KB (x 2 planes for the
+    // twin) + (distinct B tiles) x 8 KB through their L2, and what misses comes from the Infinity Cache / HBM.  Grouped
+    // ordering (GM rows of tiles, all columns, then the next GM rows): 32 workgroups cover ~GM x (32 / GM) tiles
+    // instead of 32 x 1.  (fc2 weight search, twin: 32 x 2 + 1 = 65 tiles per step with m-fastest order vs 5 x 2 + 6 = 16
+    // grouped: the A planes were re-streamed from the Infinity Cache once per workgroup and candidate.)
     const int nwg = p.mtiles * p.ntiles;
     const int t = xcd_remap(blockIdx.x, nwg);
-    int mt, nt;
-    if (p.a_cs != 0) { nt = t % p.ntiles; mt = t / p.ntiles; } else { mt = t % p.mtiles; nt = t / p.mtiles; }
+    constexpr int GM = 4;
+    const int per_group = GM * p.ntiles;
+    const int first_m = (t / per_group) * GM;
+    const int gsz = min(p.mtiles - first_m, GM);
+    const int mt = first_m + (t % per_group) % gsz, nt = (t % per_group) / gsz;
     const int z = blockIdx.y;
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
