@@ -171,9 +171,10 @@ class HessianQuantCalibrator(QuantCalibrator):
                 raw_pred_softmax = F.softmax(raw_pred, dim=-1).detach()
         return raw_pred_softmax
 
-    def _capture(self, names, raw_pred_softmax, with_grad):
+    def _capture(self, names, raw_pred_softmax, with_grad, stride=None):
         """Forward (+ backward of the KL loss, reference :333-339) over the calibration set in sub-batches,
-        with hooks on `names` only."""
+        with hooks on `names` only.  `stride = (r, w)`: run only the sub-batches i with i % w == r and leave the
+        per-sub-batch pieces on the modules as lists (sub-batch sharded capture, shard.exchange_captures)."""
         dev = _dev_of(self.net)
         bs = getattr(self, "batch_size", None) or self.calib_loader.batch_size
         hooks = []
@@ -196,7 +197,10 @@ class HessianQuantCalibrator(QuantCalibrator):
                     frozen.append(wt)
         try:
             done = False
-            if with_grad and dev.type == "cuda" and not self.sequential:
+            if stride is not None:
+                self._capture_passes(dev, bs, raw_pred_softmax, with_grad, stride)
+                done = True
+            if not done and with_grad and dev.type == "cuda" and not self.sequential:
                 # recording + instantiating the graph costs about five eager passes: worth it from ~24 sub-batches on
                 # (use_graph = True / False forces the choice)
                 n_sub = sum(-(-inp.shape[0] // bs) for inp, _ in self.calib_loader)
@@ -210,6 +214,8 @@ class HessianQuantCalibrator(QuantCalibrator):
                 wt.requires_grad_(True)
         for h in hooks:
             h.remove()
+        if stride is not None:
+            return
         for n in names:
             m = self.wrapped_modules[n]
             _concat(m, with_grad and hasattr(m, "metric"))
@@ -289,10 +295,14 @@ class HessianQuantCalibrator(QuantCalibrator):
             torch._foreach_copy_([d[i * s.shape[0]:(i + 1) * s.shape[0]] for d, s in zip(flat_dsts, srcs)], srcs)
         return True
 
-    def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad):
+    def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad, stride=None):
+        i = -1
         for inp, _ in self.calib_loader:
             total = inp.shape[0]
             for st in range(0, total, bs):
+                i += 1
+                if stride is not None and i % stride[1] != stride[0]:
+                    continue
                 inp_ = inp[st:st + bs].to(dev)
                 if with_grad:
                     self.net.zero_grad()
@@ -410,9 +420,21 @@ class HessianQuantCalibrator(QuantCalibrator):
             if cur:
                 groups.append(cur)
         t_cap = t_cal = 0.0
+        # Sub-batch sharded capture (world > 1): every rank runs 1/world of the sub-batch passes hooking ALL modules
+        # and the pieces are gathered onto the owners -- instead of every rank repeating all passes for its own
+        # modules.  Needs every rank to see at least one sub-batch and the whole cache to fit the budget.
+        bs_ = getattr(self, "batch_size", None) or self.calib_loader.batch_size
+        n_sub = sum(-(-inp.shape[0] // bs_) for inp, _ in self.calib_loader)
+        shard_cap = (world > 1 and not self.sequential and getattr(self, "shard_capture", True) and n_sub >= world
+                     and len(groups) == 1 and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
         for grp in groups:
             t1 = time.time()
-            self._capture(grp, raw_pred_softmax, with_grad)
+            if shard_cap:
+                self._capture(names, raw_pred_softmax, with_grad, stride=(rank, world))
+                grad_names = {n for n in names if with_grad and hasattr(self.wrapped_modules[n], "metric")}
+                shard.exchange_captures(self.wrapped_modules, owner, n_sub, grad_names)
+            else:
+                self._capture(grp, raw_pred_softmax, with_grad)
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()

@@ -127,3 +127,86 @@ def exchange_intervals(wrapped_modules, owner):
                 except AttributeError:
                     pass
     return total
+
+
+# ---- sub-batch sharded capture ---------------------------------------------------------------------------------
+def _module_pieces(module, with_grad):
+    """The per-sub-batch tensor lists a capture leaves on a module, in a fixed order: inputs, out, (grad)."""
+    ri = module.raw_input
+    lists = list(ri) if (isinstance(ri, list) and ri and isinstance(ri[0], list)) else [ri]
+    lists = lists + [module.raw_out]
+    if with_grad:
+        lists.append(module.raw_grad)
+    return lists
+
+
+def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
+    """Every rank ran the capture passes of the sub-batches i with i % world == rank, hooking ALL modules; afterwards
+    each module's pieces travel to its owner: one `gather` per owner rank (RCCL over xGMI; gloo in the tests), payload =
+    that owner's modules x the sender's sub-batches, padded to a common slot count so that all senders agree on the
+    layout.  The owner reassembles the full tensors in sub-batch order -- bit-identical to a capture of all sub-batches
+    on one GPU (each sub-batch pass is the same computation wherever it runs).  Non-owners drop their pieces.
+
+    Traffic per GPU: (its modules' cache) x (world - 1) / world -- for ViT-B/224 x 32 images on 8 GPUs about 1 GB in,
+    against 7/8 of the forward/backward passes saved.
+    """
+    rank, world = rank_world()
+    names = list(wrapped_modules)
+    slots = -(-n_sub // world)                       # sub-batches per rank, padded
+    data_dev = None
+    for n in names:
+        lists = _module_pieces(wrapped_modules[n], n in grad_names)
+        if lists[0]:
+            data_dev = lists[0][0].device
+            break
+    # RCCL moves device buffers; gloo (CPU tests, or several ranks sharing one GPU) needs host buffers
+    backend_dev = data_dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    for dst in range(world):
+        mine = [n for n in names if owner[n] == dst]
+        layout = []                                   # (name, list index, piece shape)
+        chunks = []
+        for n in mine:
+            for li, lst in enumerate(_module_pieces(wrapped_modules[n], n in grad_names)):
+                shp = tuple(lst[0].shape)
+                layout.append((n, li, shp))
+                for k in range(slots):
+                    if k < len(lst):
+                        chunks.append(lst[k].reshape(-1).to(device=backend_dev, dtype=torch.float32))
+                    else:
+                        chunks.append(torch.zeros(lst[0].numel(), dtype=torch.float32, device=backend_dev))
+        send = torch.cat(chunks) if chunks else torch.zeros(1, dtype=torch.float32, device=backend_dev)
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst)
+        if rank == dst:
+            full = {}
+            off = 0
+            for (n, li, shp) in layout:
+                per = 1
+                for d in shp:
+                    per *= d
+                t = torch.empty((n_sub * shp[0],) + shp[1:], dtype=torch.float32, device=data_dev)
+                for k in range(slots):
+                    for src in range(world):
+                        i = src + k * world                   # global sub-batch index of (sender, slot)
+                        if i < n_sub:
+                            t[i * shp[0]:(i + 1) * shp[0]].copy_(recv[src][off + k * per: off + (k + 1) * per].reshape(shp))
+                off += slots * per
+                full[(n, li)] = t
+            for n in mine:
+                m = wrapped_modules[n]
+                with_g = n in grad_names
+                nl = len(_module_pieces(m, with_g))
+                ts = [full[(n, li)] for li in range(nl)]
+                n_in = nl - 1 - (1 if with_g else 0)
+                m.raw_input = ts[0] if n_in == 1 else ts[:n_in]
+                m.raw_out = ts[n_in]
+                if with_g:
+                    m.raw_grad = ts[n_in + 1]
+            del recv
+        del send, chunks
+    for n in names:                                   # pieces of modules this rank does not own are no longer needed
+        if owner[n] != rank:
+            m = wrapped_modules[n]
+            m.raw_input = m.raw_out = None
+            if n in grad_names:
+                m.raw_grad = None

@@ -102,3 +102,83 @@ def test_interval_exchange_world2_gloo():
         p.join(30)
     assert all(ok for _, ok, _, _ in res), res
     assert res[0][2] == res[1][2] > 0 and res[0][3] == [0, 1]
+
+
+# ---- sub-batch sharded capture: the real calibrator on the mini ViT, CPU, 2 and 3 ranks ----------------------------
+def _capture_worker(rank, world, port, q):
+    import contextlib, io, json
+    import numpy as np
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap, quant_calib
+    g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = models.get_net("vit_tiny_patch16_224", seed=0, device="cpu", **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.from_numpy(g["images"])
+
+    class Loader:
+        batch_size = images.shape[0]
+
+        def __iter__(self):
+            yield images, None
+
+    seen = {}
+    for n, m in wrapped.items():
+        def rec(_m=m, _n=n):     # stand-in for the GPU search: record what this rank would have calibrated from
+            ri = _m.raw_input
+            seen[_n] = ([t.clone() for t in ri] if isinstance(ri, list) else [ri.clone()]) + [_m.raw_out.clone(), _m.raw_grad.clone()]
+            _m.calibrated = True
+            _m.w_interval = torch.zeros(1)
+        m.calibration_step2 = rec
+    cal = quant_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2)   # 4 sub-batches
+    with contextlib.redirect_stdout(io.StringIO()):
+        cal.batching_quant_calib()
+    ok, nmine = True, 0
+    for n, ts in seen.items():
+        assert cal.owner[n] == rank
+        nmine += 1
+        key = n.replace(".", "__")
+        want = ([g[f"{key}::A"], g[f"{key}::B"]] if f"{key}::A" in g.files else [g[f"{key}::x"]]) + [g[f"{key}::out"], g[f"{key}::grad"]]
+        for t, w in zip(ts, want):
+            ok &= tuple(t.shape) == tuple(w.shape)
+    q.put((rank, ok, nmine, {n: [t.numpy() for t in ts] for n, ts in seen.items()}))
+    dist.destroy_process_group()
+
+
+def _run_capture(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_capture_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_sharded_capture_reassembles_the_single_process_capture():
+    """Each rank runs 1/world of the sub-batch passes for ALL modules; after the per-owner gather every owner holds
+    exactly (bit for bit) the tensors a single process captures from all sub-batches."""
+    import numpy as np
+    single = _run_capture(1)[0]
+    assert single[1] and single[2] == 14
+    for world in (2, 3):
+        res = _run_capture(world)
+        assert all(ok for _, ok, _, _ in res)
+        assert sum(nm for _, _, nm, _ in res) == 14
+        merged = {}
+        for _, _, _, d in res:
+            merged.update(d)
+        assert set(merged) == set(single[3])
+        for n, ts in merged.items():
+            for a, b in zip(ts, single[3][n]):
+                np.testing.assert_array_equal(a, b, err_msg=n)
