@@ -400,16 +400,23 @@ class HessianQuantCalibrator(QuantCalibrator):
         print(f"prepare parallel calibration for {names}")
         print("start hessian calibration")
         rank, world = shard.rank_world()
-        owner = shard.assign_modules(self.wrapped_modules, world) if (world > 1 and not self.sequential) else {n: rank for n in names}
+        t0 = time.time()
+        if world > 1 and not self.sequential:
+            # balance by predicted search time (needs every module's captured size: one single-image probe forward)
+            all_sizes = self._estimate_cache_bytes(names)
+            costs = {n: shard.module_cost_ms(self.wrapped_modules[n], all_sizes.get(n, 0)) for n in names}
+            owner = shard.assign_modules(self.wrapped_modules, world, costs)
+        else:
+            all_sizes = None
+            owner = {n: rank for n in names}
         mine = [n for n in names if owner[n] == rank]
         self.owner = owner
-        t0 = time.time()
         raw_pred_softmax = self._raw_pred_softmax() if with_grad else None
 
         if self.sequential:
             groups = [[n] for n in mine]  # predecessors must already run quantised: one capture per module
         else:
-            sizes = self._estimate_cache_bytes(mine)
+            sizes = all_sizes if all_sizes is not None else self._estimate_cache_bytes(mine)
             groups, cur, acc = [], [], 0
             for n in mine:
                 if cur and acc + sizes.get(n, 0) > self.cache_budget_bytes:

@@ -32,6 +32,27 @@ def module_cost(module):
     return float(w.numel())
 
 
+def module_cost_ms(module, cache_bytes):
+    """Predicted search time (ms, one MI355X, single stream) of one module from its captured size; constants fitted to
+    the per-layer measurements of ViT-B/224 x 32 (tools/bench_layer.py: qkv 2.7, proj 1.3, fc1 3.3, fc2 7.3, q.k 1.9,
+    attn.v 3.8 ms per search round; patch embedding 13 ms).  Only the RATIOS matter (LPT balance)."""
+    w = getattr(module, "weight", None)
+    cls = type(module).__name__
+    if w is None:                                       # matmul: cache = A + B + 2 * out (fp32)
+        per_mac = 7.2e-9 if cls.startswith("SoS") else 2.3e-9
+        # cache_bytes / 4 = Z (M K + K N + 2 M N); the sweeps cost ~ Z M N K; approximate with (cache / 4)^(3/2) / sqrt(Z)
+        # being overkill, use the dominant square score matrix: out elements ~ cache / 16, K ~ 64
+        return 0.4 + per_mac * (cache_bytes / 16.0) * 64.0
+    if w.dim() == 4:                                    # patch embedding: fp32-operand MFMA path
+        k = w[0].numel()
+        rows = cache_bytes / 4.0 / max(1.0, 2.0 * w.shape[0] + k)
+        return 0.5 + 3.5e-9 * rows * k * w.shape[0]
+    n_out, k = w.shape
+    rows = cache_bytes / 4.0 / (k + 2.0 * n_out)        # cache = x + out + grad
+    t = 0.45 + 1.25e-6 * k * n_out * rows / 6304.0
+    return t * (2.2 if cls.startswith("PostGelu") else 1.0)
+
+
 def assign_modules(wrapped_modules, world, costs=None):
     """LPT: heaviest module first onto the currently lightest rank.  Deterministic -> identical on every rank."""
     names = list(wrapped_modules)
