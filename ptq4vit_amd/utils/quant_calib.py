@@ -184,17 +184,16 @@ class HessianQuantCalibrator(QuantCalibrator):
             if hasattr(m, "metric"):
                 m.raw_grad = None   # step 2 deletes the caches (reference linear.py:554): re-create for re-calibration
             hooks += _register(m, with_grad and hasattr(m, "metric"))
-        # Only gradients w.r.t. ACTIVATIONS are captured (grad_hook): the weight-gradient GEMMs of the wrapped
-        # Linear / Conv modules -- a third of the backward pass -- are never looked at.  Their matrices stop requiring
-        # grad for the duration of the capture; biases, norms and embeddings keep the graph connected, so every
-        # hooked output still receives exactly the same grad_output.
+        # Only gradients w.r.t. ACTIVATIONS are captured (grad_hook): no parameter gradient is ever looked at.  For the
+        # duration of the capture NO parameter requires grad (no weight-gradient GEMMs -- a third of the backward pass --
+        # no bias / LayerNorm reductions, no .grad accumulation); the graph hangs off the input images instead, which
+        # are marked as requiring grad, so every hooked output still receives exactly the same grad_output.
         frozen = []
         if with_grad:
-            for m in self.wrapped_modules.values():
-                wt = getattr(m, "weight", None)
-                if isinstance(wt, torch.nn.Parameter) and wt.requires_grad and wt.dim() >= 2 and getattr(m, "bias", None) is not None:
-                    wt.requires_grad_(False)
-                    frozen.append(wt)
+            for prm in self.net.parameters():
+                if prm.requires_grad:
+                    prm.requires_grad_(False)
+                    frozen.append(prm)
         try:
             done = False
             if stride is not None:
@@ -246,13 +245,13 @@ class HessianQuantCalibrator(QuantCalibrator):
                     m.raw_grad = None
 
         def one_pass(x, tgt):
-            self.net.zero_grad(set_to_none=True)
+            x.grad = None
             pred = self.net(x)
             loss = F.kl_div(F.log_softmax(pred, dim=-1), tgt, reduction="batchmean")
             loss.backward()
 
         try:
-            static_in = inp[:bs].to(dev).clone()
+            static_in = inp[:bs].to(dev).clone().requires_grad_(True)
             static_tgt = raw_pred_softmax[:bs].clone()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -289,7 +288,8 @@ class HessianQuantCalibrator(QuantCalibrator):
             dsts.append(full)
         flat_dsts = [t for f in dsts for t in f]
         for i, st in enumerate(range(0, total, bs)):
-            static_in.copy_(inp[st:st + bs])
+            with torch.no_grad():
+                static_in.copy_(inp[st:st + bs])
             static_tgt.copy_(raw_pred_softmax[st:st + bs])
             graph.replay()
             torch._foreach_copy_([d[i * s.shape[0]:(i + 1) * s.shape[0]] for d, s in zip(flat_dsts, srcs)], srcs)
@@ -305,7 +305,7 @@ class HessianQuantCalibrator(QuantCalibrator):
                     continue
                 inp_ = inp[st:st + bs].to(dev)
                 if with_grad:
-                    self.net.zero_grad()
+                    inp_ = inp_.detach().requires_grad_(True)     # root of the autograd graph (parameters are frozen)
                     pred = self.net(inp_)
                     loss = F.kl_div(F.log_softmax(pred, dim=-1), raw_pred_softmax[st:st + bs], reduction="batchmean")
                     loss.backward()
