@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define P4V_VERSION 100 /* 0.1.0 */
+#define P4V_VERSION 110 /* 0.1.1: + quant_forward entry points, stats fields */
 
 /* similarity metrics: reference quant_layers/linear.py:399-424 */
 enum p4v_metric {

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version(lib):
-    assert lib.p4v_version() == 100
+    assert lib.p4v_version() == 110
 
 
 def test_workspace_planning_matches_shapes(lib):
