@@ -9,9 +9,12 @@
  * Conventions
  *   - plain C symbols, POD descriptors, no torch / C++ types in any signature;
  *   - every pointer named d_* is DEVICE memory owned by the caller (a torch tensor's data_ptr());
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises,
- *     nothing allocates: scratch comes from the caller-provided workspace
- *     (size from the matching *_workspace_bytes());
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing allocates: scratch comes
+ *     from the caller-provided workspace (size from the matching *_workspace_bytes()).  The *_calibrate entry points
+ *     read the interval selected by each search pass back to the host (pass memoisation: a pass whose input
+ *     interval was already evaluated is skipped) and therefore synchronise `stream` after every pass; setting
+ *     desc.reserved bit 1 (or requesting score tables) disables that and makes the call fully asynchronous.
+ *     *_quant_forward, p4v_quantize_i8 and p4v_fake_quant never synchronise;
  *   - return value 0 = ok, <0 = error; p4v_last_error() returns a per-thread message;
  *   - safe to call concurrently on different devices / streams (no global mutable state).
  *
