@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--calib", type=int, default=32)
+    ap.add_argument("--bits", type=int, default=8, help="W/A bit width of every wrapped module (8 = headline W8A8; 6 = the W6A6 config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -117,6 +118,11 @@ def main():
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
 
     net = models.get_net(args.model, seed=0, device=dev)
+    if args.bits != 8:      # what the reference's drivers do to the config module (example/test_all.py:53-78)
+        PTQ4ViT.bit = args.bits
+        for tab in (PTQ4ViT.w_bit, PTQ4ViT.a_bit, PTQ4ViT.A_bit, PTQ4ViT.B_bit):
+            for k in tab:
+                tab[k] = args.bits
     wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
     img = models.input_size(args.model)
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -202,12 +208,12 @@ def main():
     if rank == 0:
         t = cals[-1].timings
         line = {
-            "metric": "calibration throughput (wrapped modules calibrated per second), ViT-B/224 W8A8, 32 calibration images",
+            "metric": "calibration throughput (wrapped modules calibrated per second), ViT-B/224 W8A8, 32 calibration images" if (args.model == "vit_base_patch16_224" and args.bits == 8 and args.calib == 32) else f"calibration throughput (wrapped modules calibrated per second), {args.model} W{args.bits}A{args.bits}, {args.calib} calibration images",
             "value": value, "unit": "layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "calibration_wall_clock_s": elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
             "data": "synthetic (seeded N(0,1) images, trunc-normal weights)",
-            "config": {"workload": f"{args.model} PTQ4ViT W8A8, {args.calib} calibration images, {n_mod} wrapped modules, "
+            "config": {"workload": f"{args.model} PTQ4ViT W{args.bits}A{args.bits}, {args.calib} calibration images, {n_mod} wrapped modules, "
                                    "HessianQuantCalibrator.batching_quant_calib (capture + search)",
                        "global_batch": args.calib, "parallelism": f"layers sharded over {world} GPU(s)"},
             "breakdown": {"capture_s": t["capture_s"], "search_s": t["search_s"]},
