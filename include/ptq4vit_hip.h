@@ -196,6 +196,10 @@ typedef struct p4v_kernel_stats {
     double sweep_f32_macs;
     double sweep_i8_alg_macs;  /* MACs of the reference GEMMs those launches stand for (unpadded, one plane) */
     double sweep_f32_alg_macs;
+    double sweep6_ms;          /* the register-stationary sweep k_sweep6 alone (also included in sweep_i8_*) */
+    int64_t sweep6_launches;
+    double sweep6_macs;
+    double sweep6_alg_macs;
     int64_t memo_hits;      /* search passes skipped because their input interval had already been evaluated */
     int64_t memo_misses;    /* search passes executed (with memoisation enabled)                            */
 } p4v_kernel_stats;

@@ -42,6 +42,7 @@ class KernelStats(C.Structure):
     _fields_ = [("sweep_i8_ms", C.c_double), ("sweep_i8_launches", C.c_int64), ("sweep_i8_macs", C.c_double),
                 ("sweep_f32_ms", C.c_double), ("sweep_f32_launches", C.c_int64), ("sweep_f32_macs", C.c_double),
                 ("sweep_i8_alg_macs", C.c_double), ("sweep_f32_alg_macs", C.c_double),
+                ("sweep6_ms", C.c_double), ("sweep6_launches", C.c_int64), ("sweep6_macs", C.c_double), ("sweep6_alg_macs", C.c_double),
                 ("memo_hits", C.c_int64), ("memo_misses", C.c_int64)]
 
 

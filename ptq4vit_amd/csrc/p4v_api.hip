@@ -304,7 +304,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 0;
+        rec.kind = 2;
         rec.macs = (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
         rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
@@ -1296,8 +1296,9 @@ static int stats_drain_locked() {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        if (r.kind == 0) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
-        else { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
+        if (r.kind == 0 || r.kind == 2) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
+        if (r.kind == 1) { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }
