@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                         w[q] = acc;
                     }
                 }
-                *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + o) = v4i{w[0], w[1], w[2], w[3]};
+                // streaming store: the plane is far larger than the L2 and is read back by a different kernel
+                __builtin_nontemporal_store(v4i{w[0], w[1], w[2], w[3]}, reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + o));
             } else {
                 float* d = reinterpret_cast<float*>(p.dst) + o;
 #pragma unroll
