@@ -156,6 +156,36 @@ template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams&
     return 0;
 }
 
+// k_sweep2g: large K, column operand expanded, row operand invariant (weight search): two candidates per pass
+bool sweep2g_ok(const SweepParams& p) {
+    return p.b_cs != 0 && p.a_cs == 0 && p.ktiles >= 16 && (p.c1 - p.c0) >= 2 && p.o_bs == 0 && p.o_nbs == 0 &&
+           !(g_variant & 256);
+}
+
+template <bool TWIN> int launch_sweep2g_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+    const int per = 2 * cdiv(p.c1 - p.c0, 2 * cgroups);
+    const size_t lds = (size_t)SW2_NS * (TWIN ? 4 : 3) * SW2_TILE + (size_t)per * 8 * sizeof(float) * (TWIN ? 3 : 2);
+    dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
+#define P4V_LAUNCH2G(E)                                                                                        \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep2g<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep2g<TWIN, E>), grid, block, lds, c.st, p);                                   \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH2G(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH2G(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH2G(EPI_ABS); break;
+        default: P4V_LAUNCH2G(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH2G
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
     const size_t lds = (size_t)SW2_NS * (TWIN ? 3 : 2) * SW2_TILE + (size_t)per * 8 * sizeof(float) * (TWIN ? 3 : 2);
@@ -350,7 +380,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
-    if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
+    if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
+    else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
     else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi) : launch_sweep_epi<int8_t, false>(c, p, epi);
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi) : launch_sweep_epi<float, false>(c, p, epi);
     if (timed) {

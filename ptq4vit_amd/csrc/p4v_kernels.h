@@ -849,6 +849,199 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sweep2g: k_sweep2 for LARGE K with two candidates per pass (weight search of fc2-like layers)
+// ------------------------------------------------------------------------------------------
+// PMC (profiles/r1_pmc_fc2_sweep2.txt): at K = 3072 k_sweep2 moves 16 KB (24 KB twin) per k-tile from L2 into LDS for
+// 128 x 128 x 64 MACs and runs at the L2->CU bandwidth (~18.6 TB/s of the ~20 the LDS-DMA micro-benchmark reaches),
+// the matrix pipe 39 % busy.  In the weight search the ROW operand (activations; two planes for the post-GELU twin)
+// is candidate-invariant: this kernel feeds TWO candidates of the column operand from one pass over the row planes --
+// 16 + 2 x 8 = 32 KB per k-tile for twice the MACs (-33 % L2 bytes per MAC, -40 % fragment reads per MFMA).
+// Four accumulator sets (2 candidates x 2 planes) leave no registers for the raw_out / raw_grad tile, so that tile is
+// re-read once per candidate PAIR in the epilogue: 128 KB against 1.5 MB of operands per pair at K = 3072 (+8 %).
+// Requirements (host): column operand expanded (b_cs != 0), row operand invariant (a_cs == 0), p.Z == 1 or z handled
+// by blockIdx.y as in k_sweep2.  An odd candidate count runs its last candidate twice (second result dropped).
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = TWIN ? 4 : 3;                    // planes: A, (A2), B(c), B(c+1)
+    constexpr int PLANE = SW2_NS * SW2_TILE;
+    float* res = reinterpret_cast<float*>(smem + NPL * PLANE);   // [per][8 waves]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    constexpr int GM = 4;
+    const int per_group = GM * p.ntiles;
+    const int first_m = (t / per_group) * GM;
+    const int gsz = min(p.mtiles - first_m, GM);
+    const int mt = first_m + (t % per_group) % gsz, nt = (t % per_group) / gsz;
+    const int z = blockIdx.y;
+    const int m0 = mt * SW_BM, n0 = nt * SW_BN;
+    const int per = 2 * ((p.c1 - p.c0 + 2 * gridDim.z - 1) / (2 * gridDim.z));   // even: groups start on a pair
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo, npairs = (ncand + 1) >> 1;
+
+    const int n = n0 + wc * 32 + l31;
+    const bool ncol_ok = n < p.N;
+    const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
+    const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
+    // plain [M][N] output layout only (host: o_bs == o_nbs == 0): element (m, n) at z*o_zs + m*o_ms + n*o_ns
+    const int nc = min(n, p.N - 1);
+    const int mlane = m0 + wr * 64 + 4 * g;               // row of element (i = 0, r = 0) of this lane
+    const float* Obase = p.O + (long)z * p.o_zs + (long)nc * p.o_ns;
+    const float* Wbase = p.Wt + (long)z * p.o_zs + (long)nc * p.o_ns;
+    const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
+    const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
+    const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
+
+    const int nw0 = n0 + wc * 32;
+    const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
+    float* s1tab = res + per * 8;
+    float* s2tab = s1tab + per * 8;
+    for (int i = lane; i < per; i += 64) {
+        const int cc = min(c_lo + i, c_hi - 1);
+        s1tab[i * 8 + wid] = p.S1 ? p.S1[cc * p.s_cs + sb] : 1.0f;
+        if (TWIN) s2tab[i * 8 + wid] = p.S2 ? p.S2[cc * p.s_cs + sb] : 1.0f;
+    }
+
+    // ---- LDS-DMA: wave `wid` fills rows [16*wid, 16*wid+16) of every plane ------------------------------------------
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    const unsigned voff = (unsigned)(ld_row * p.ldk + ld_chunk * 16);
+    const char* curA = (const char*)p.A + (long)z * p.a_zs + (long)m0 * p.ldk;
+    const char* curA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)m0 * p.ldk : nullptr;
+    const char* curB0 = (const char*)p.B + (long)z * p.b_zs + (long)n0 * p.ldk + (long)c_lo * p.b_cs;
+    long b1_off = (c_lo + 1 < c_hi) ? p.b_cs : 0;         // second candidate of the pair (the last odd one: itself)
+    const int ktiles = p.ktiles;
+    const long krow = (long)ktiles * SW_BKB;
+    const int lds_wave = wid * 1024;
+    const int total = npairs * ktiles;
+    int ikt = 0, ipair = 0;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        char* s = smem + stage * SW2_TILE + lds_wave;
+        glds16(curA + voff, s);
+        if (TWIN) glds16(curA2 + voff, s + PLANE);
+        glds16(curB0 + voff, s + (NPL - 2) * PLANE);
+        glds16(curB0 + b1_off + voff, s + (NPL - 1) * PLANE);
+        curA += SW_BKB; curB0 += SW_BKB;
+        if (TWIN) curA2 += SW_BKB;
+        if (++ikt == ktiles) {                            // next pair: rewind the invariant planes, advance two candidates
+            ikt = 0; ++ipair;
+            curA -= krow; if (TWIN) curA2 -= krow;
+            curB0 += 2 * p.b_cs - krow;
+            b1_off = (c_lo + 2 * ipair + 1 < c_hi) ? p.b_cs : 0;
+        }
+    };
+
+    v16i acc[2][2], acc2[2][2];                           // [candidate of the pair][32-row half]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][i][r] = 0; if (TWIN) acc2[j][i][r] = 0; }
+
+    const int ra0 = wr * 64 + l31, ra1 = ra0 + 32, rb = wc * 32 + l31;
+    const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sbz = (rb >> 2) & 3;
+    const char* fA0 = smem + ra0 * 64;
+    const char* fA1 = smem + ra1 * 64;
+    const char* fB = smem + (NPL - 2) * PLANE + rb * 64;
+    const int oa00 = (g ^ sa0) << 4, oa01 = ((2 + g) ^ sa0) << 4;
+    const int oa10 = (g ^ sa1) << 4, oa11 = ((2 + g) ^ sa1) << 4;
+    const int ob0 = (g ^ sbz) << 4, ob1 = ((2 + g) ^ sbz) << 4;
+
+    const int npre = min(SW2_NS - 1, total);
+    for (int i = 0; i < npre; ++i) issue(i);
+
+    int kt = 0, pr = 0;
+    auto tile = [&](int it, auto stage_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr int SO = ST * SW2_TILE;
+        if (it + 2 < total) wait_vmcnt<2 * NPL>(); else if (it + 1 < total) wait_vmcnt<NPL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // tile `it` is in LDS for everyone; stage (it-1)%NS is free for everyone
+        if (it + SW2_NS - 1 < total) issue((ST + SW2_NS - 1) % SW2_NS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oa0 = h ? oa01 : oa00, oa1 = h ? oa11 : oa10, ob = h ? ob1 : ob0;
+            const v4i a0 = *reinterpret_cast<const v4i*>(fA0 + SO + oa0);
+            const v4i a1 = *reinterpret_cast<const v4i*>(fA1 + SO + oa1);
+            const v4i b0 = *reinterpret_cast<const v4i*>(fB + SO + ob);
+            const v4i b1 = *reinterpret_cast<const v4i*>(fB + PLANE + SO + ob);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            if (TWIN) {
+                const v4i c0 = *reinterpret_cast<const v4i*>(fA0 + PLANE + SO + oa0);
+                const v4i c1 = *reinterpret_cast<const v4i*>(fA1 + PLANE + SO + oa1);
+                acc2[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c0, b0, acc2[0][0], 0, 0, 0);
+                acc2[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c1, b0, acc2[0][1], 0, 0, 0);
+                acc2[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c0, b1, acc2[1][0], 0, 0, 0);
+                acc2[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(c1, b1, acc2[1][1], 0, 0, 0);
+            }
+        }
+        if (++kt == ktiles) {
+            // ---- epilogue of the candidate pair: the raw_out / weight tile is streamed in, shared by both candidates
+            const int ci = 2 * pr;
+            const float s1a = s1tab[ci * 8 + wid], s1b = s1tab[(ci + 1) * 8 + wid];
+            const float s2a = TWIN ? s2tab[ci * 8 + wid] : 1.0f, s2b = TWIN ? s2tab[(ci + 1) * 8 + wid] : 1.0f;
+            float suma = 0.0f, sumb = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                    // 8 elements at a time: all loads first, then the math
+                    float uo[8], gw[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = q * 8 + e;
+                        const int mc = min(mlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1);
+                        const long idx = (long)mc * p.o_ms;
+                        uo[e] = Obase[idx];
+                        gw[e] = Wbase[idx];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = q * 8 + e;
+                        const bool ok = ncol_ok && (mlane + i * 32 + (r & 3) + 8 * (r >> 2)) < p.M;
+                        const unsigned wbits = (__builtin_bit_cast(unsigned, gw[e]) & m_g) | (__builtin_bit_cast(unsigned, uo[e]) & m_o) | m_1;
+                        const float uu = ok ? uo[e] - bias_n : 0.0f;
+                        const float ww = ok ? __builtin_bit_cast(float, wbits) : 0.0f;
+                        float da = uu - (float)acc[0][i][r] * s1a, db = uu - (float)acc[1][i][r] * s1b;
+                        if (TWIN) { da -= (float)acc2[0][i][r] * s2a; db -= (float)acc2[1][i][r] * s2b; }
+                        if (EPI == EPI_SQ_W) { const float ta = ww * da, tb = ww * db; suma = fmaf(ta, ta, suma); sumb = fmaf(tb, tb, sumb); }
+                        else if (EPI == EPI_SQ) { suma = fmaf(da, da, suma); sumb = fmaf(db, db, sumb); }
+                        else if (EPI == EPI_ABS) { suma += fabsf(da); sumb += fabsf(db); }
+                        else { suma = fmaf(ww * da, da, suma); sumb = fmaf(ww * db, db, sumb); }
+                        acc[0][i][r] = 0; acc[1][i][r] = 0;
+                        if (TWIN) { acc2[0][i][r] = 0; acc2[1][i][r] = 0; }
+                    }
+                }
+            suma = wave_sum_dpp(suma);
+            sumb = wave_sum_dpp(sumb);
+            if (lane == 63) { res[ci * 8 + wid] = suma; res[(ci + 1) * 8 + wid] = sumb; }
+            kt = 0;
+            ++pr;
+        }
+    };
+    for (int it = 0; it < total; it += SW2_NS) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < total) tile(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < total) tile(it + 2, std::integral_constant<int, 2>{});
+        if (it + 3 < total) tile(it + 3, std::integral_constant<int, 3>{});
+    }
+    __syncthreads();
+    for (int i = tid; i < ncand * 8; i += 512) {
+        const int cc = c_lo + i / 8, wv = i % 8;
+        p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Stationary-operand int8 sweep (k_sweep4 below): parameter block
 // ------------------------------------------------------------------------------------------
 // The candidate-invariant operand (activations in the weight search, weights in the activation search) is

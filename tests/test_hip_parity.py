@@ -160,13 +160,19 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=2, T=70, K=768, N=192, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
     dict(b=3, T=49, K=256, N=128, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False),        # KT = 4 (Swin)
     dict(b=3, T=49, K=512, N=192, n_V=3, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),        # KT = 8 (Swin)
+    # K >= 1024: weight search on k_sweep2g (two candidates per pass, epilogue operands streamed), twin and plain,
+    # odd candidate count (last pair runs its candidate twice)
+    dict(b=2, T=70, K=1024, N=200, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),
+    dict(b=2, T=70, K=1024, N=192, n_V=3, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),
+    dict(b=2, T=70, K=1088, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True, eq_n=37),
+    dict(b=2, T=70, K=1024, N=256, n_V=2, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=False, eq_n=51),
 ], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-K{c['K']}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
     cfg = dict(cfg)
     b, T, K, N, postgelu = (cfg.pop(k) for k in ("b", "T", "K", "N", "postgelu"))
     w, bias, x, out, grad = _mk_linear(7, b, T, K, N, postgelu)
-    hp = dict(eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    hp = dict(eq_alpha=0.01, eq_beta=1.2, eq_n=cfg.pop("eq_n", 100), search_round=2)
     o = LinearOracle(w, bias, postgelu=postgelu, **cfg, **hp)
     o.calibration_step2(x, out, grad)
     w_iv, a_iv, scores, best = eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad),
