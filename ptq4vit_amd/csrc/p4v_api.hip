@@ -75,7 +75,13 @@ std::mutex g_stat_mu;
 bool g_stat_on = false;
 std::vector<StatRec> g_stat_recs;
 p4v_kernel_stats g_stats = {};
-int g_variant = 0;         // tuning A/B switches (bit 0: two k-tiles per barrier in k_sweep2)
+// Tuning A/B switches, set through p4v_stats_enable(enable) bits 2.. (tools/bench_layer.py --variant V):
+//   4   no stationary-operand sweeps (everything on k_sweep2)      8   k_sweep4 instead of k_sweep5 (one candidate per pass)
+//   16  no k_sweep6 (stationary operand in LDS instead of registers)  32  k_sweep6 with 8 waves (two per SIMD)
+//   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
+//   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
+//   1, 2: kernel debug flags (SweepParams::dbg)
+int g_variant = 0;
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
 
 struct Ctx {
