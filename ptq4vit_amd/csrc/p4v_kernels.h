@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
 #pragma unroll
         for (int j = 0; j < PACK_CG; ++j)
             sc[j] = (p.scales && cbeg + j < cend) ? p.scales[(cbeg + j) * p.sc_cs + blk0] : p.neg_scale;
-#pragma unroll
-        for (int j = 0; j < PACK_CG; ++j) {
+        for (int j = 0; j < PACK_CG; ++j) {     // not unrolled: one candidate's body is already ~150 instructions
             const int c = cbeg + j;
             if (c >= cend) break;
             const long o = p.c_inner == 2 ? ((((long)z * p.Rp + r) * ((p.C + 1) & ~1) + (c & ~1)) * p.Kp + (long)(kc >> 2) * 128 + (c & 1) * 64 + (kc & 3) * 16)
