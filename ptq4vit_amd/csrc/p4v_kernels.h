@@ -613,6 +613,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// Same with an immediate offset OFF (0 <= OFF < 4096) applied by the instruction to BOTH addresses: loads g + OFF into
+// l + OFF -- saves the 64-bit VALU add of a compile-time k-tile offset.
+template <int OFF> __device__ __forceinline__ void glds16_imm(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, OFF, 0);
+}
 
 // Wave-wide fp32 sum on the VALU (DPP), result valid in lane 63.  __shfl_xor lowers to ds_bpermute_b32: six LDS
 // round trips with a full lgkmcnt(0) each -- about 0.4 us per reduction when nothing else runs on the SIMD.
@@ -1519,14 +1525,20 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
     const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
     const int kt_w = wid >> 2;                           // first k-tile of this wave's pieces (NW = 8: 0 or 1)
-    auto piece = [&](const char* src, int stage_off, int j) __attribute__((always_inline)) {
-        // j-th piece of this wave: k-tile j * (NW / 4) + kt_w
+    curT += kt_w * SW_BKB;                               // (NW = 8: the odd waves start one k-tile in)
+    auto piece = [&](const char* src, int stage_off, auto j_c) __attribute__((always_inline)) {
+        // j-th piece of this wave: k-tile j * (NW / 4) + kt_w; the compile-time part of the k offset rides in the
+        // instruction (it is added to the LDS address as well, hence the "- OFF" on the destination)
+        constexpr int j = decltype(j_c)::value;
+        constexpr int OFF = j * (NW / 4) * SW_BKB;
         const int kt = j * (NW / 4) + kt_w;
-        if (NPC % NW == 0 || NW * j + wid < NPC) glds16(src + kt * SW_BKB, smem + stage_off + kt * KT_TILE + (wid & 3) * 1024);
+        if (NPC % NW == 0 || NW * j + wid < NPC)
+            glds16_imm<OFF>(src, smem + stage_off + kt * KT_TILE + (wid & 3) * 1024 - OFF);
     };
     auto issue = [&](int stage_off) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) piece(curT, stage_off, j);
+        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+            (piece(curT, stage_off, std::integral_constant<int, J>{}), ...);
+        }(std::make_integer_sequence<int, PPW>{});
         curT += p.ldk;
     };
     issue(0);
@@ -1699,7 +1711,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
         {
             constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
             constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index of this wave
-            if constexpr (j < PPW) piece(fillT, fill_stage, j);
+            if constexpr (j < PPW) piece(fillT, fill_stage, std::integral_constant<int, j>{});
         }
         // phase 0 carries the epilogue of block 1 of the previous candidate (slot ci), phase 1 that of block 0 of this one
         if constexpr (cb == 0) epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 1>{}, ci);
