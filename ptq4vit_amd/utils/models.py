@@ -291,6 +291,12 @@ _ZOO = {
     "vit_small_patch16_224": (224, 16, 384, 12, 6),
     "vit_base_patch16_224": (224, 16, 768, 12, 12),
     "vit_base_patch16_384": (384, 16, 768, 12, 12),
+    "vit_base_patch32_224": (224, 32, 768, 12, 12),
+    "vit_base_patch32_384": (384, 32, 768, 12, 12),
+    "vit_large_patch16_224": (224, 16, 1024, 24, 16),
+    "vit_large_patch16_384": (384, 16, 1024, 24, 16),
+    "vit_large_patch32_224": (224, 32, 1024, 24, 16),
+    "vit_large_patch32_384": (384, 32, 1024, 24, 16),
     "deit_tiny_patch16_224": (224, 16, 192, 12, 3),
     "deit_small_patch16_224": (224, 16, 384, 12, 6),
     "deit_base_patch16_224": (224, 16, 768, 12, 12),
