@@ -160,6 +160,9 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=2, T=70, K=768, N=192, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
     dict(b=3, T=49, K=256, N=128, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False),        # KT = 4 (Swin)
     dict(b=3, T=49, K=512, N=192, n_V=3, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),        # KT = 8 (Swin)
+    dict(b=3, T=50, K=384, N=200, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False, eq_n=3),     # k_sweep6, tiny candidate sets
+    dict(b=3, T=50, K=768, N=192, n_V=3, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False, eq_n=37),
+    dict(b=3, T=50, K=192, N=96, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False, eq_n=1),
     # K >= 1024: weight search on k_sweep2g (two candidates per pass, epilogue operands streamed), twin and plain,
     # odd candidate count (last pair runs its candidate twice)
     dict(b=2, T=70, K=1024, N=200, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),
