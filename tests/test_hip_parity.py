@@ -169,6 +169,7 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=2, T=70, K=1024, N=192, n_V=3, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),
     dict(b=2, T=70, K=1088, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True, eq_n=37),
     dict(b=2, T=70, K=1024, N=256, n_V=2, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=False, eq_n=51),
+    dict(b=2, T=197, K=3072, N=768, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),          # ViT-B fc2 at 2 images
 ], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-K{c['K']}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
