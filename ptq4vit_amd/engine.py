@@ -50,6 +50,18 @@ def release_workspace():
     _workspace.clear()
 
 
+_side_streams = {}
+
+
+def side_streams(dev, n):
+    """`n` persistent side streams of `dev` (the calibrator searches several modules at a time).  Persistent because
+    the scratch buffers are keyed by stream: fresh streams per calibration would strand one scratch buffer each."""
+    lst = _side_streams.setdefault(dev, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
 def candidate_multipliers(eq_alpha, eq_beta, eq_n, dev):
     """Reference quant_layers/linear.py:544: python-float grid rounded to fp32 (eq_n+1 entries)."""
     key = (float(eq_alpha), float(eq_beta), int(eq_n), str(dev))

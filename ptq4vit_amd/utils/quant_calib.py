@@ -325,7 +325,8 @@ class HessianQuantCalibrator(QuantCalibrator):
         import threading
         dev = _dev_of(self.net)
         main = torch.cuda.current_stream(dev)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        from .. import engine
+        streams = engine.side_streams(dev, n_streams)
         for s in streams:
             s.wait_stream(main)                       # the captured tensors were produced on the current stream
         # the caches are freed by calibration_step2 (reference linear.py:554) while the other stream may still be

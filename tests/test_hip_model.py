@@ -359,3 +359,26 @@ def test_int8_quant_forward_matches_fake_quant_forward():
         assert err <= 2e-5 * y_ref.abs().max().item() + 1e-7, f"{n}: {err:.3e} vs range {y_ref.abs().max().item():.3e}"
         checked += 1
     assert checked == 13
+
+
+def test_repeated_calibration_does_not_grow_memory():
+    """Scratch buffers are per (device, stream): the calibrator must reuse its side streams, not strand a buffer set
+    per calibration."""
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    g, net, wrapped = _mini()
+    images = torch.from_numpy(g["images"]).cuda()
+
+    class Loader:
+        batch_size = images.shape[0]
+
+        def __iter__(self):
+            yield images, None
+
+    used = []
+    for _ in range(4):
+        for m in wrapped.values():
+            m.mode = "raw"
+        HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
+        torch.cuda.synchronize()
+        used.append(torch.cuda.memory_allocated())
+    assert used[3] <= used[1] + (1 << 20), used
