@@ -148,8 +148,12 @@ class QuantCalibrator:
         self.calibrated = True
 
     def batching_quant_calib(self):
-        """Cached-tensor calibration without gradients (reference :95-171); any non-hessian metric."""
-        HessianQuantCalibrator.batching_quant_calib(self, with_grad=False)
+        """Cached-tensor calibration without gradients (reference :95-171); any non-hessian metric.  One forward pass
+        over the loader's own batches fills the caches, then every module runs calibration_step2()."""
+        h = HessianQuantCalibrator(self.net, self.wrapped_modules, self.calib_loader, sequential=self.sequential,
+                                   batch_size=getattr(self.calib_loader, "batch_size", None) or 1)
+        h._calibrate(batching=True, with_grad=False)
+        self.calibrated = True
 
 
 class HessianQuantCalibrator(QuantCalibrator):

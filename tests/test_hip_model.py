@@ -382,3 +382,70 @@ def test_repeated_calibration_does_not_grow_memory():
         torch.cuda.synchronize()
         used.append(torch.cuda.memory_allocated())
     assert used[3] <= used[1] + (1 << 20), used
+
+
+@pytest.mark.parametrize("mode", ["sequential", "ragged_cpu_loader", "quant_calibrator_nograd", "hessian_quant_calib"])
+def test_calibrator_variants_run(mode):
+    """Less-travelled entry points of the reference's calibrators (quant_calib.py:28-93, 95-171, 216-298) run through
+    the GPU engine: sequential capture (predecessors quantised), a calibration set that is not a multiple of the
+    sub-batch and lives on the host, the gradient-free QuantCalibrator.batching_quant_calib, the non-batching
+    HessianQuantCalibrator.quant_calib."""
+    import contextlib, io
+    from ptq4vit_amd.configs import BasePTQ, PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator, QuantCalibrator
+    cfg = BasePTQ if mode == "quant_calibrator_nograd" else PTQ4ViT
+    net = models.get_net("vit_tiny_patch16_224", seed=1, device="cuda", img_size=32, patch_size=8, embed_dim=48, depth=2,
+                         num_heads=3, num_classes=10)
+    if mode == "hessian_quant_calib":
+        # quant_calib() feeds calibration_step2(x): the non-batching classes (reference linear.py:94-347, matmul.py:75-388)
+        from ptq4vit_amd.quant_layers.linear import PostGeluPTQSLQuantLinear, PTQSLQuantLinear
+        from ptq4vit_amd.quant_layers.matmul import PTQSLQuantMatMul, SoSPTQSLQuantMatMul
+
+        class cfg:  # noqa: N801
+            hp = dict(metric="hessian", search_round=2, eq_alpha=0.01, eq_beta=1.2, eq_n=100)
+
+            @staticmethod
+            def get_module(kind, *a, **k):
+                if kind == "qlinear_MLP_2":
+                    return PostGeluPTQSLQuantLinear(*a, **k, **cfg.hp)
+                if kind.startswith("qlinear"):
+                    return PTQSLQuantLinear(*a, **k, n_V=3 if kind == "qlinear_qkv" else 1, **cfg.hp)
+                return (SoSPTQSLQuantMatMul if kind == "qmatmul_scorev" else PTQSLQuantMatMul)(**cfg.hp)
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            wrapped = net_wrap.wrap_certain_modules_in_net(net, cfg, [0, 1], ["qkv", "proj", "fc1", "fc2", "matmul1", "matmul2", "head"])
+        assert len(wrapped) == 13
+    else:
+        with contextlib.redirect_stdout(io.StringIO()):
+            wrapped = net_wrap.wrap_modules_in_net(net, cfg)
+    n_img = 10 if mode == "ragged_cpu_loader" else 8
+    images = torch.randn(n_img, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    if mode != "ragged_cpu_loader":
+        images = images.cuda()
+
+    class Loader:
+        batch_size = n_img
+
+        def __iter__(self):
+            yield images, torch.zeros(n_img, dtype=torch.long)
+
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        if mode == "sequential":
+            HessianQuantCalibrator(net, wrapped, Loader(), sequential=True, batch_size=4).batching_quant_calib()
+        elif mode == "ragged_cpu_loader":
+            HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
+        elif mode == "quant_calibrator_nograd":
+            QuantCalibrator(net, wrapped, Loader(), sequential=False).batching_quant_calib()
+        else:
+            HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).quant_calib()
+    assert all(m.mode == "quant_forward" and m.calibrated for m in wrapped.values())
+    with torch.no_grad():
+        out = net(images.cuda())
+    assert torch.isfinite(out).all()
+    for m in wrapped.values():
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval"):
+            v = getattr(m, a, None)
+            if v is not None:
+                v = v[0] if isinstance(v, (list, tuple)) else v
+                assert torch.isfinite(torch.as_tensor(v)).all() and (torch.as_tensor(v) > 0).all()
