@@ -384,7 +384,8 @@ def test_repeated_calibration_does_not_grow_memory():
     assert used[3] <= used[1] + (1 << 20), used
 
 
-@pytest.mark.parametrize("mode", ["sequential", "ragged_cpu_loader", "quant_calibrator_nograd", "hessian_quant_calib"])
+@pytest.mark.parametrize("mode", ["sequential", "ragged_cpu_loader", "quant_calibrator_nograd", "hessian_quant_calib",
+                                  "forward_mode_sequential", "forward_mode_parallel"])
 def test_calibrator_variants_run(mode):
     """Less-travelled entry points of the reference's calibrators (quant_calib.py:28-93, 95-171, 216-298) run through
     the GPU engine: sequential capture (predecessors quantised), a calibration set that is not a multiple of the
@@ -397,13 +398,14 @@ def test_calibrator_variants_run(mode):
     cfg = BasePTQ if mode == "quant_calibrator_nograd" else PTQ4ViT
     net = models.get_net("vit_tiny_patch16_224", seed=1, device="cuda", img_size=32, patch_size=8, embed_dim=48, depth=2,
                          num_heads=3, num_classes=10)
-    if mode == "hessian_quant_calib":
+    if mode in ("hessian_quant_calib", "forward_mode_sequential", "forward_mode_parallel"):
         # quant_calib() feeds calibration_step2(x): the non-batching classes (reference linear.py:94-347, matmul.py:75-388)
         from ptq4vit_amd.quant_layers.linear import PostGeluPTQSLQuantLinear, PTQSLQuantLinear
         from ptq4vit_amd.quant_layers.matmul import PTQSLQuantMatMul, SoSPTQSLQuantMatMul
 
         class cfg:  # noqa: N801
-            hp = dict(metric="hessian", search_round=2, eq_alpha=0.01, eq_beta=1.2, eq_n=100)
+            hp = dict(metric="hessian" if mode == "hessian_quant_calib" else "L2_norm", search_round=2, eq_alpha=0.01,
+                      eq_beta=1.2, eq_n=100)
 
             @staticmethod
             def get_module(kind, *a, **k):
@@ -437,8 +439,10 @@ def test_calibrator_variants_run(mode):
             HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
         elif mode == "quant_calibrator_nograd":
             QuantCalibrator(net, wrapped, Loader(), sequential=False).batching_quant_calib()
-        else:
+        elif mode == "hessian_quant_calib":
             HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).quant_calib()
+        else:   # forward-mode calibration: modes calibration_step1 / calibration_step2 (reference quant_calib.py:28-93)
+            QuantCalibrator(net, wrapped, Loader(), sequential=(mode == "forward_mode_sequential")).quant_calib()
     assert all(m.mode == "quant_forward" and m.calibrated for m in wrapped.values())
     with torch.no_grad():
         out = net(images.cuda())
