@@ -453,3 +453,36 @@ def test_calibrator_variants_run(mode):
             if v is not None:
                 v = v[0] if isinstance(v, (list, tuple)) else v
                 assert torch.isfinite(torch.as_tensor(v)).all() and (torch.as_tensor(v) > 0).all()
+
+
+def test_full_size_proj_layer_against_the_oracle():
+    """BASELINE size, no reduction: ViT-B/224 `proj` (32 x 197 x 768 -> 768, W8A8, Hessian metric, 3 rounds x 100
+    candidates, gradients of the magnitude the reference's KL loss produces) -- every score table of the HIP path
+    against the numpy oracle, and the calibrated intervals (tie-aware)."""
+    from oracle.ptq4vit_oracle import LinearOracle
+    from ptq4vit_amd import engine
+    from tests.helpers import assert_argmax_tie_aware, assert_scores_close
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(32, 197, 768, generator=g)
+    w = torch.randn(768, 768, generator=g) * 0.02
+    b = torch.randn(768, generator=g) * 0.02
+    out = torch.nn.functional.linear(x, w, b)
+    grad = torch.randn(out.shape, generator=g) * 1e-10
+    hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, n_V=1)
+    o = LinearOracle(w.numpy(), b.numpy(), **hp)
+    want = o.calibration_step2(x.numpy(), out.numpy(), grad.numpy())
+    w_iv, a_iv, scores, best = engine.linear_calibrate(weight=w.cuda(), bias=b.cuda(), x=x.cuda(), out=out.cuda(),
+                                                       grad=grad.cuda(), n_H=1, n_a=1, want_scores=True, **hp)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    flips = 0
+    for r in range(3):
+        for k, (tab, idx) in enumerate(((scores[r, 0], best[r, 0]), (scores[r, 1][:, :1], best[r, 1][:1]))):
+            ref = o.trace[2 * r + k][1].reshape(tab.shape)
+            if flips == 0:      # after a tie flip the two searches continue from different intervals
+                assert_scores_close(tab, ref, what=f"round {r} {'wa'[k]}")
+                flips += int(not np.array_equal(idx, np.argmax(ref, axis=0)))
+                assert_argmax_tie_aware(idx, ref, what=f"round {r} {'wa'[k]}")
+    if flips == 0:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), want["w_interval"].reshape(-1))
+        np.testing.assert_array_equal(a_iv.cpu().numpy(), want["a_interval"].reshape(-1))
