@@ -16,6 +16,8 @@ def main():
     g = torch.Generator().manual_seed(1)
     loader = Loader(torch.randn(32, 3, 224, 224, generator=g).to(dev))
     cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4)
+    if os.environ.get("P4V_USE_GRAPH"):
+        cal.use_graph = True
     names = list(wrapped)
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.time()
