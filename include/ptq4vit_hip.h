@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define P4V_VERSION 110 /* 0.1.1: + quant_forward entry points, stats fields */
+#define P4V_VERSION 120 /* 0.1.2: + granular entry points (amax_init / search_* / score_argmax_gather) */
 
 /* similarity metrics: reference quant_layers/linear.py:399-424 */
 enum p4v_metric {
@@ -151,6 +151,87 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
                        const float* d_out, const float* d_grad, const float* d_mult, float* d_w_interval,
                        float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Granular entry points: ONE part of calibration_step2 per call, for callers that drive the
+ * alternation themselves the way the reference's methods are called one by one.  Same kernels as the fused
+ * p4v_*_calibrate entry points, so a granular sequence (init, then search_round x {first, second operand}) gives
+ * bit-identical intervals; no memoisation, no host synchronisation.  Candidate tables are INPUTS here:
+ * [eq_n+1][blocks] fp32, row i = multiplier_i * initial interval (linear.py:544-545); rows 0..eq_n-1 are searched.
+ * Workspace: the p4v_*_workspace_bytes of the same descriptor.  d_scores / d_best (optional) receive the ONE table
+ * of the call, [eq_n][blocks] / [blocks].
+ * ---------------------------------------------------------------------------------------- */
+
+/* PTQSLBatchingQuantLinear._initialize_intervals (linear.py:380-397; post-GELU twin linear.py:576-599):
+ * d_w_interval [n_V*n_H], d_a_interval [n_a] out. */
+int p4v_amax_init_linear(const p4v_linear_desc* desc, const float* d_weight, const float* d_x, float* d_w_interval,
+                         float* d_a_interval, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* PTQSLBatchingQuantLinear._search_best_w_interval (linear.py:455-495): all n_H column blocks, argmax per V block.
+ * d_w_cands [eq_n+1][n_V*n_H]; d_w_interval in/out; d_a_interval in (the current counterpart, linear.py:476). */
+int p4v_linear_search_w(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                        const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                        const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* PTQSLBatchingQuantLinear._search_best_a_interval (linear.py:497-533; twin linear.py:609-642 with `twin_postgelu`).
+ * d_a_cands [eq_n+1][n_a]; d_w_interval in; d_a_interval in/out. */
+int p4v_linear_search_a(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                        const float* d_out, const float* d_grad, const float* d_a_cands, const float* d_w_interval,
+                        float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* PTQSLBatchingQuantMatMul._initialize_intervals (matmul.py:419-440): head-wise d_A_interval / d_B_interval [heads].
+ * With `sos` the head-wise A interval is computed and dropped (the split search overwrites it, matmul.py:633-644):
+ * d_A_interval is left untouched. */
+int p4v_amax_init_matmul(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, float* d_A_interval,
+                         float* d_B_interval, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* PTQSLBatchingQuantMatMul._search_best_A_interval (matmul.py:483-522). d_A_cands [eq_n+1][heads]. */
+int p4v_matmul_search_A(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                        const float* d_grad, const float* d_A_cands, float* d_A_interval, const float* d_B_interval,
+                        float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* SoSPTQSLBatchingQuantMatMul._search_best_A_interval (matmul.py:600-631): the 20 splits 2^-i against the RAW B.
+ * d_split [1] out, d_A_interval [1] out (= split/(qmax-1)); d_scores [20][1] optional. */
+int p4v_sos_search_split(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                         const float* d_grad, float* d_split, float* d_A_interval, float* d_scores, int32_t* d_best,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* PTQSLBatchingQuantMatMul._search_best_B_interval (matmul.py:524-563); with `sos`, A is the two-range operand
+ * (matmul.py:595-598) described by d_split / d_A_interval. d_B_cands [eq_n+1][heads]. */
+int p4v_matmul_search_B(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                        const float* d_grad, const float* d_B_cands, const float* d_A_interval, const float* d_split,
+                        float* d_B_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ChannelwiseBatchingQuantConv2d / BatchingEasyQuantConv2d._initialize_intervals (conv.py:482-496 / 312-320). */
+int p4v_amax_init_conv(const p4v_conv_desc* desc, const float* d_weight, const float* d_x, float* d_w_interval,
+                       float* d_a_interval, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ChannelwiseBatchingQuantConv2d._search_best_w_interval (conv.py:526-557): d_w_cands [eq_n+1][oc], argmax per oc. */
+int p4v_conv_search_w_channelwise(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                                  const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                                  const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                                  size_t workspace_bytes, void* stream);
+
+/* BatchingEasyQuantConv2d._search_best_w_interval (conv.py:365-396): d_w_cands [eq_n+1][1]. */
+int p4v_conv_search_w_layerwise(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                                const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                                const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* ChannelwiseBatchingQuantConv2d._search_best_a_interval (conv.py:559-589), a_bit < 32 only. d_a_cands [eq_n+1][1]. */
+int p4v_conv_search_a(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                      const float* d_out, const float* d_grad, const float* d_a_cands, const float* d_w_interval,
+                      float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* The selection every search ends with (linear.py:493-494): best[j] = argmax_i d_scores[i][j] (first index on ties,
+ * NaN counts as the maximum, like torch.argmax), d_interval[j] = d_cands[best[j]][j].  d_scores [eq_n][n_blocks],
+ * d_cands [>= eq_n][n_blocks], d_best optional [n_blocks]. */
+int p4v_score_argmax_gather(const float* d_scores, int32_t eq_n, int32_t n_blocks, const float* d_cands,
+                            float* d_interval, int32_t* d_best, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks exported for parity tests (bit-exact integer planes) and for the

@@ -52,6 +52,10 @@ EXPORTS = [
     "p4v_matmul_workspace_bytes", "p4v_matmul_calibrate",
     "p4v_conv_workspace_bytes", "p4v_conv_calibrate",
     "p4v_linear_quant_forward", "p4v_matmul_quant_forward",
+    "p4v_amax_init_linear", "p4v_linear_search_w", "p4v_linear_search_a",
+    "p4v_amax_init_matmul", "p4v_matmul_search_A", "p4v_sos_search_split", "p4v_matmul_search_B",
+    "p4v_amax_init_conv", "p4v_conv_search_w_channelwise", "p4v_conv_search_w_layerwise", "p4v_conv_search_a",
+    "p4v_score_argmax_gather",
     "p4v_quantize_i8", "p4v_fake_quant",
     "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
 ]
@@ -92,6 +96,26 @@ def load():
     lib.p4v_linear_quant_forward.argtypes = [C.POINTER(LinearDesc), fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
     lib.p4v_matmul_quant_forward.restype = C.c_int
     lib.p4v_matmul_quant_forward.argtypes = [C.POINTER(MatMulDesc), fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
+    # granular entry points: (desc, tensors..., workspace, bytes, stream)
+    LD, MD, CD = C.POINTER(LinearDesc), C.POINTER(MatMulDesc), C.POINTER(ConvDesc)
+    tail = [vp, C.c_size_t, vp]
+    for name, args in (
+            ("p4v_amax_init_linear", [LD] + [fp] * 4),
+            ("p4v_linear_search_w", [LD] + [fp] * 9 + [ip]),
+            ("p4v_linear_search_a", [LD] + [fp] * 9 + [ip]),
+            ("p4v_amax_init_matmul", [MD] + [fp] * 4),
+            ("p4v_matmul_search_A", [MD] + [fp] * 8 + [ip]),
+            ("p4v_sos_search_split", [MD] + [fp] * 7 + [ip]),
+            ("p4v_matmul_search_B", [MD] + [fp] * 9 + [ip]),
+            ("p4v_amax_init_conv", [CD] + [fp] * 4),
+            ("p4v_conv_search_w_channelwise", [CD] + [fp] * 9 + [ip]),
+            ("p4v_conv_search_w_layerwise", [CD] + [fp] * 9 + [ip]),
+            ("p4v_conv_search_a", [CD] + [fp] * 9 + [ip])):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args + tail
+    lib.p4v_score_argmax_gather.restype = C.c_int
+    lib.p4v_score_argmax_gather.argtypes = [fp, C.c_int32, C.c_int32, fp, fp, ip, vp]
     lib.p4v_quantize_i8.restype = C.c_int
     lib.p4v_quantize_i8.argtypes = [fp, C.c_int64, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
     lib.p4v_fake_quant.restype = C.c_int

@@ -661,6 +661,19 @@ int write_dev(Ctx& c, float* d, const std::vector<float>& h) {
 
 std::atomic<long> g_memo_hits{0}, g_memo_misses{0};
 
+// Which parts of calibration_step2 one call runs.  The fused entry points run everything (ST_ALL: initialisation, then
+// search_round x {first operand, second operand} with memoisation); the granular entry points of the C ABI
+// (p4v_amax_init_*, p4v_*_search_*) run ONE part with the candidate table supplied by the caller, the way the reference's
+// _initialize_intervals / _search_best_*_interval methods are called one by one (linear.py:380-397,455-533).
+enum { ST_INIT = 1, ST_S1 = 2, ST_S2 = 4, ST_ALL = 7 };
+struct Stage {
+    int mask = ST_ALL;
+    const float* cands1 = nullptr;   // caller's candidate table of the first operand  (w / A), used when ST_INIT is not set
+    const float* cands2 = nullptr;   // ... of the second operand (a / B)
+    bool full() const { return mask == ST_ALL; }
+    bool searches() const { return (mask & (ST_S1 | ST_S2)) != 0; }
+};
+
 PackParams pack2d(const float* src, long rows, long cols, long ld) {
     PackParams p{};
     p.src = src; p.s_z = 0; p.s_r = ld; p.s_k = 1; p.Z = 1; p.R = (int)rows; p.K = (int)cols;
@@ -673,7 +686,7 @@ PackParams pack2d(const float* src, long rows, long cols, long ld) {
 // ------------------------------------------------------------------------------------------------
 int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, const float* X, const float* O,
                 const float* G, const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out,
-                Ctx& c, float* fwd_out = nullptr) {
+                Ctx& c, float* fwd_out = nullptr, const Stage& sg = Stage{}) {
     // fwd_out != nullptr: quant_forward (linear.py:62-67 / 601-607) -- w_iv / a_iv are INPUTS, nothing is searched
     const int M = d->batch * d->tokens, K = d->in_features, N = d->out_features;
     const int nV = d->n_V, nH = d->n_H, nA = d->n_a;
@@ -687,7 +700,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
-    if (wt_mode == 1 && !G && !fwd_out) return fail(P4V_ERR_INVALID, "linear: hessian metric needs raw_grad (linear.py:418)");
+    if (wt_mode == 1 && !G && !fwd_out && sg.searches()) return fail(P4V_ERR_INVALID, "linear: hessian metric needs raw_grad (linear.py:418)");
     const bool general = (nH > 1 || nA > 1 || (d->reserved & 1) || (cosm && d->twin_postgelu && !fwd_out));
     const bool i8 = !general;
     const bool twin = d->twin_postgelu && i8;
@@ -697,21 +710,26 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     // ---- interval initialisation (linear.py:380-397 / 576-599) ---------------------------------------
     unsigned* enc_w = c.ws.get<unsigned>((size_t)nV * nH);
     unsigned* enc_a = c.ws.get<unsigned>((size_t)nA);
-    float* w_cands = c.ws.get<float>((size_t)ncand * nV * nH);
-    float* a_cands = c.ws.get<float>((size_t)ncand * nA);
+    float* w_cands_ws = c.ws.get<float>((size_t)ncand * nV * nH);
+    float* a_cands_ws = c.ws.get<float>((size_t)ncand * nA);
+    const float* w_cands = (sg.mask & ST_INIT) ? w_cands_ws : sg.cands1;
+    const float* a_cands = (sg.mask & ST_INIT) ? a_cands_ws : sg.cands2;
     float* Ufold = twin ? c.ws.get<float>((size_t)M * N) : nullptr;   // twin activation search: folded target
     float* w_mix = c.ws.get<float>((size_t)ncand * nV * nH);   // general path: candidates of block column h only
     float* a_mix = c.ws.get<float>((size_t)ncand * nA);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
-    if (!fwd_out) {
+    if (!fwd_out && (sg.mask & ST_INIT)) {
         const long stw[4] = {0, 0, K, 1};
         CHK(launch_absmax(c, W, stw, 1, 1, N, K, nV, nH, crb_rows, crb_cols, 0, enc_w));
         CHK(launch_interval(c, enc_w, nV * nH, (float)(wq - 0.5), d->init_layerwise, w_iv));
         CHK(launch_absmax(c, X, stw, 1, 1, M, K, 1, nA, M, crb_acts, d->twin_postgelu ? 1 : 0, enc_a));
         CHK(launch_interval(c, enc_a, nA, (float)(aq - 0.5), d->init_layerwise, a_iv));
-        CHK(launch_cands(c, mult, w_iv, ncand, nV * nH, w_cands));
-        CHK(launch_cands(c, mult, a_iv, ncand, nA, a_cands));
+        if (sg.searches()) {
+            CHK(launch_cands(c, mult, w_iv, ncand, nV * nH, w_cands_ws));
+            CHK(launch_cands(c, mult, a_iv, ncand, nA, a_cands_ws));
+        }
     }
+    if (!fwd_out && !sg.searches()) return 0;
 
     auto x_operand = [&](bool expanded, const float* scales, int sc_cs) {
         Operand op{};
@@ -768,17 +786,19 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         fp.nj = 1; fp.store_out = fwd_out;
         return run_pass(c, fp);
     }
-    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
     std::vector<float> key, val;
-    for (int round = 0; round < d->search_round; ++round) {
+    const int n_rounds = sg.full() ? d->search_round : 1;
+    auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
+    for (int round = 0; round < n_rounds; ++round) {
         // ================= weight search (linear.py:455-495) =================
         bool skip_w = false;
         if (memo_on) {
             CHK(read_dev(c, a_iv, nA, key));
             if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
         }
-        for (int h = 0; h < nH && !skip_w; ++h) {
+        for (int h = 0; h < nH && !skip_w && (sg.mask & ST_S1); ++h) {
             Pass ps{};
             ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
             const float* wc = w_cands;
@@ -797,9 +817,9 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
             ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
-            ps.scores_out = scores_out ? scores_out + ((long)(round * 2 + 0) * d->eq_n) * nV : nullptr;
+            ps.scores_out = scores_out ? scores_out + ((long)slot(round, 0) * d->eq_n) * nV : nullptr;
             ps.scores_out_ld = nV;
-            ps.best_out = best_out ? best_out + (long)(round * 2 + 0) * nV : nullptr;
+            ps.best_out = best_out ? best_out + (long)slot(round, 0) * nV : nullptr;
             if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
             if (!cosm) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
@@ -835,7 +855,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             CHK(read_dev(c, w_iv, nV * nH, key));
             if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
         }
-        for (int a = 0; a < nA && !skip_a; ++a) {
+        for (int a = 0; a < nA && !skip_a && (sg.mask & ST_S2); ++a) {
             Pass ps{};
             ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
             const float* ac = a_cands;
@@ -851,9 +871,9 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             ps.nj = 1; ps.cands = a_cands; ps.cand_cs = nA; ps.cand_js = 0; ps.cand_off = a;
             ps.interval = a_iv; ps.out_js = 0; ps.out_off = a;
-            ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)(round * 2 + 1) * d->eq_n) * nV : nullptr;
+            ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)slot(round, 1) * d->eq_n) * nV : nullptr;
             ps.scores_out_ld = nV;
-            ps.best_out = (best_out && a == 0) ? best_out + (long)(round * 2 + 1) * nV : nullptr;
+            ps.best_out = (best_out && a == 0) ? best_out + (long)slot(round, 1) * nV : nullptr;
             if (!cosm) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
                 ps.row = x_operand(true, ac, nA);
@@ -904,7 +924,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
 // ------------------------------------------------------------------------------------------------
 int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const float* O, const float* G,
                 const float* mult, float* A_iv, float* B_iv, float* split, float* scores_out, int32_t* best_out, Ctx& c,
-                float* fwd_out = nullptr) {
+                float* fwd_out = nullptr, const Stage& sg = Stage{}) {
     // fwd_out != nullptr: quant_forward (matmul.py:140-145; sos: matmul.py:595-598) -- intervals / split are INPUTS
     const int H = d->heads, Z = d->batch * d->heads, M = d->M, K = d->K, N = d->N;
     if (Z <= 0 || M <= 0 || K <= 0 || N <= 0 || d->eq_n <= 0) return fail(P4V_ERR_INVALID, "matmul: non-positive dimension");
@@ -913,19 +933,21 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
-    if (wt_mode == 1 && !G && !fwd_out) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
+    if (wt_mode == 1 && !G && !fwd_out && sg.searches()) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
     if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
     const int ncand = d->eq_n + 1;
     const int NSPLIT = 20;  // matmul.py:636
 
     unsigned* enc_A = c.ws.get<unsigned>(H);
     unsigned* enc_B = c.ws.get<unsigned>(H);
-    float* A_cands = c.ws.get<float>((size_t)ncand * H);
-    float* B_cands = c.ws.get<float>((size_t)ncand * H);
+    float* A_cands_ws = c.ws.get<float>((size_t)ncand * H);
+    float* B_cands_ws = c.ws.get<float>((size_t)ncand * H);
+    const float* A_cands = (sg.mask & ST_INIT) ? A_cands_ws : sg.cands1;
+    const float* B_cands = (sg.mask & ST_INIT) ? B_cands_ws : sg.cands2;
     float* split_cands = c.ws.get<float>(NSPLIT);
     float* A_headwise = c.ws.get<float>(H);   // sos: the inherited head-wise A interval is computed then overwritten (matmul.py:419-440)
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
-    if (!fwd_out) {
+    if (!fwd_out && (sg.mask & ST_INIT)) {
         const long sa[4] = {d->a_stride[0], d->a_stride[1], d->a_stride[2], d->a_stride[3]};
         const long sb[4] = {d->b_stride[0], d->b_stride[1], d->b_stride[2], d->b_stride[3]};
         float* a_dst = d->sos ? A_headwise : A_iv;
@@ -933,8 +955,13 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
         CHK(launch_interval(c, enc_A, H, (float)(Aq - 0.5), d->init_layerwise, a_dst));
         CHK(launch_absmax(c, B, sb, d->batch, H, K, N, 1, 1, K, N, 0, enc_B));
         CHK(launch_interval(c, enc_B, H, (float)(Bq - 0.5), d->init_layerwise, B_iv));
-        if (!d->sos) CHK(launch_cands(c, mult, A_iv, ncand, H, A_cands));
-        CHK(launch_cands(c, mult, B_iv, ncand, H, B_cands));
+        if (sg.searches()) {
+            if (!d->sos) CHK(launch_cands(c, mult, A_iv, ncand, H, A_cands_ws));
+            CHK(launch_cands(c, mult, B_iv, ncand, H, B_cands_ws));
+        }
+    }
+    if (!fwd_out && !sg.searches()) return 0;
+    if (!fwd_out && (sg.mask & ST_S1)) {
         if (d->sos && !c.dry) {
             float sc[NSPLIT];
             for (int i = 0; i < NSPLIT; ++i) sc[i] = (float)std::ldexp(1.0, -i);  // 2**(-i), exact in fp32
@@ -993,13 +1020,17 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
         fp.nj = 1; fp.store_out = fwd_out;
         return run_pass(c, fp);
     }
-    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_A, memo_B;
     std::vector<float> key, val;
     const int nAiv = d->sos ? 1 : H;
-    for (int round = 0; round < d->search_round; ++round) {
+    const int n_rounds = sg.full() ? d->search_round : 1;
+    for (int round = 0; round < n_rounds; ++round) {
         float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * H : nullptr;
         int32_t* bo = best_out ? best_out + (long)(round * 2) * H : nullptr;
+        // granular call: the one table of this call starts at offset 0 (the B pass below adds eq_n*H / H otherwise)
+        float* so_B = so ? (sg.full() ? so + (long)d->eq_n * H : so) : nullptr;
+        int32_t* bo_B = bo ? (sg.full() ? bo + H : bo) : nullptr;
         // the A search (or, with sos, the split search against the RAW B: a function of nothing -> always a hit after round 1)
         bool skip_A = false;
         if (memo_on) {
@@ -1010,7 +1041,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
                 skip_A = true; g_memo_hits++;
             }
         }
-        if (skip_A) {
+        if (skip_A || !(sg.mask & ST_S1)) {
         } else if (!d->sos) {
             // ---- A search, B fixed at its current head-wise interval (matmul.py:483-522) ----
             Pass ps{};
@@ -1040,7 +1071,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.scores_out = (d->eq_n >= NSPLIT) ? so : nullptr; ps.scores_out_ld = H; ps.best_out = bo;
             CHK(run_pass(c, ps));
         }
-        if (memo_on && !skip_A) {
+        if (memo_on && !skip_A) {   // (memo_on implies a full run)
             if (d->sos) { std::vector<float> sp, ai; CHK(read_dev(c, split, 1, sp)); CHK(read_dev(c, A_iv, 1, ai)); val = {sp[0], ai[0]}; }
             else CHK(read_dev(c, A_iv, nAiv, val));
             memo_A.entries.push_back({key, val}); g_memo_misses++;
@@ -1050,7 +1081,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             CHK(read_dev(c, A_iv, nAiv, key));
             if (const auto* hit = memo_B.find(key)) { CHK(write_dev(c, B_iv, *hit)); skip_B = true; g_memo_hits++; }
         }
-        if (!skip_B) {
+        if (!skip_B && (sg.mask & ST_S2)) {
             // ---- B search, A fixed (matmul.py:524-563); with sos, A is the two-range twin (matmul.py:595-598) ----
             Pass ps{};
             common(ps);
@@ -1072,8 +1103,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.j_mode = 2; ps.j_div = H; ps.nj = H; ps.cos_j_mode = 2; ps.cos_j_div = H;
             ps.norm = cosm ? 1.0 / (double)M : 1.0 / ((double)M * N);
             ps.cands = B_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = B_iv; ps.out_js = 1;
-            ps.scores_out = so ? so + (long)d->eq_n * H : nullptr; ps.scores_out_ld = H;
-            ps.best_out = bo ? bo + H : nullptr;
+            ps.scores_out = so_B; ps.scores_out_ld = H;
+            ps.best_out = bo_B;
             CHK(run_pass(c, ps));
             if (memo_on) { CHK(read_dev(c, B_iv, H, val)); memo_B.entries.push_back({key, val}); g_memo_misses++; }
         }
@@ -1085,7 +1116,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
 // Conv2d (patch embedding): fp32 operands (the input stays unquantised with a_bit >= 32, conv.py:544)
 // ------------------------------------------------------------------------------------------------
 int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const float* X, const float* O, const float* G,
-              const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out, Ctx& c) {
+              const float* mult, float* w_iv, float* a_iv, float* scores_out, int32_t* best_out, Ctx& c,
+              const Stage& sg = Stage{}) {
     const int b = d->batch, ic = d->in_channels, H = d->height, Wd = d->width, oc = d->out_channels;
     const int kh = d->kernel_h, kw = d->kernel_w;
     const int fh = (H + 2 * d->pad_h - d->dil_h * (kh - 1) - 1) / d->stride_h + 1;
@@ -1100,26 +1132,31 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
-    if (wt_mode == 1 && !G) return fail(P4V_ERR_INVALID, "conv: hessian metric needs raw_grad");
+    if (wt_mode == 1 && !G && sg.searches()) return fail(P4V_ERR_INVALID, "conv: hessian metric needs raw_grad");
     if (cosm && aquant) return fail(P4V_ERR_UNSUPPORTED, "conv: cosine does not support the activation search (reference conv.py:505-506)");
     const int nw = d->channelwise ? oc : 1;
     const int ncand = d->eq_n + 1;
 
     unsigned* enc_w = c.ws.get<unsigned>(nw);
     unsigned* enc_a = c.ws.get<unsigned>(1);
-    float* w_cands = c.ws.get<float>((size_t)ncand * nw);
-    float* a_cands = c.ws.get<float>(ncand);
+    float* w_cands_ws = c.ws.get<float>((size_t)ncand * nw);
+    float* a_cands_ws = c.ws.get<float>(ncand);
+    const float* w_cands = (sg.mask & ST_INIT) ? w_cands_ws : sg.cands1;
+    const float* a_cands = (sg.mask & ST_INIT) ? a_cands_ws : sg.cands2;
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
-    {
+    if (sg.mask & ST_INIT) {
         const long stw[4] = {0, 0, K, 1};
         CHK(launch_absmax(c, W, stw, 1, 1, oc, K, nw, 1, d->channelwise ? 1 : oc, K, 0, enc_w));
         CHK(launch_interval(c, enc_w, nw, (float)(wq - 0.5), d->init_layerwise, w_iv));
         const long stx[4] = {0, 0, (long)ic * H * Wd, 1};
         CHK(launch_absmax(c, X, stx, 1, 1, b, ic * H * Wd, 1, 1, b, ic * H * Wd, 0, enc_a));
         CHK(launch_interval(c, enc_a, 1, aquant ? (float)(aq - 0.5) : (float)(std::ldexp(1.0, d->a_bit - 1) - 0.5), 0, a_iv));
-        CHK(launch_cands(c, mult, w_iv, ncand, nw, w_cands));
-        CHK(launch_cands(c, mult, a_iv, ncand, 1, a_cands));
+        if (sg.searches()) {
+            CHK(launch_cands(c, mult, w_iv, ncand, nw, w_cands_ws));
+            CHK(launch_cands(c, mult, a_iv, ncand, 1, a_cands_ws));
+        }
     }
+    if (!sg.searches()) return 0;
     // x as im2col rows.  per_image: Z = batch, rows = pixels of one image (channel-wise cosine reduces over pixels)
     auto x_operand = [&](bool expanded, const float* scales, int sc_cs, bool per_image) {
         Operand op{};
@@ -1168,19 +1205,22 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
         }
     };
 
-    const bool memo_on = !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
+    const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
     std::vector<float> key, val;
-    for (int round = 0; round < d->search_round; ++round) {
+    const int n_rounds = sg.full() ? d->search_round : 1;
+    for (int round = 0; round < n_rounds; ++round) {
         float* so = scores_out ? scores_out + ((long)(round * 2) * d->eq_n) * nw : nullptr;
         int32_t* bo = best_out ? best_out + (long)(round * 2) * nw : nullptr;
+        float* so_a = so ? (sg.full() ? so + (long)d->eq_n * nw : so) : nullptr;
+        int32_t* bo_a = bo ? (sg.full() ? bo + nw : bo) : nullptr;
         bool skip_w = false;
         if (memo_on) {
             // with a_bit >= 32 the input is never quantised: the weight search depends on nothing (conv.py:544)
             if (aquant) CHK(read_dev(c, a_iv, 1, key)); else key.assign(1, 0.0f);
             if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
         }
-        if (!skip_w) {   // ---- weight search (conv.py:526-557 / 365-396) ----
+        if (!skip_w && (sg.mask & ST_S1)) {   // ---- weight search (conv.py:526-557 / 365-396) ----
             Pass ps{};
             setup(ps, true);
             ps.nj = nw;
@@ -1197,13 +1237,13 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             CHK(read_dev(c, w_iv, nw, key));
             if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
         }
-        if (aquant && !skip_a) {  // ---- activation search (conv.py:559-589), channel-wise class only ----
+        if (aquant && !skip_a && (sg.mask & ST_S2)) {  // ---- activation search (conv.py:559-589), channel-wise class only ----
             Pass ps{};
             setup(ps, false);
             ps.nj = 1; ps.j_mode = 0; ps.norm = 1.0 / ((double)L * oc);
             ps.cands = a_cands; ps.cand_cs = 1; ps.cand_js = 0; ps.interval = a_iv; ps.out_js = 0;
-            ps.scores_out = so ? so + (long)d->eq_n * nw : nullptr; ps.scores_out_ld = nw;
-            ps.best_out = bo ? bo + nw : nullptr;
+            ps.scores_out = so_a; ps.scores_out_ld = nw;
+            ps.best_out = bo_a;
             CHK(run_pass(c, ps));
             if (memo_on) { CHK(read_dev(c, a_iv, 1, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
         }
@@ -1295,6 +1335,142 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
     Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
     return conv_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, d_mult, d_w_interval, d_a_interval,
                      d_scores, d_best, c);
+}
+
+// ---- granular entry points: one part of calibration_step2 per call ----------
+int p4v_amax_init_linear(const p4v_linear_desc* desc, const float* d_weight, const float* d_x, float* d_w_interval,
+                         float* d_a_interval, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_amax_init_linear: null pointer");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return linear_impl(desc, d_weight, nullptr, d_x, nullptr, nullptr, nullptr, d_w_interval, d_a_interval, nullptr, nullptr, c,
+                       nullptr, Stage{ST_INIT, nullptr, nullptr});
+}
+
+int p4v_linear_search_w(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                        const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                        const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_out || !d_w_cands || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_linear_search_w: null pointer");
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "p4v_linear_search_w: has_bias set but d_bias is NULL");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return linear_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, nullptr, d_w_interval,
+                       const_cast<float*>(d_a_interval), d_scores, d_best, c, nullptr, Stage{ST_S1, d_w_cands, nullptr});
+}
+
+int p4v_linear_search_a(const p4v_linear_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                        const float* d_out, const float* d_grad, const float* d_a_cands, const float* d_w_interval,
+                        float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                        void* stream) {
+    if (!desc || !d_weight || !d_x || !d_out || !d_a_cands || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_linear_search_a: null pointer");
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "p4v_linear_search_a: has_bias set but d_bias is NULL");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return linear_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, nullptr,
+                       const_cast<float*>(d_w_interval), d_a_interval, d_scores, d_best, c, nullptr,
+                       Stage{ST_S2, nullptr, d_a_cands});
+}
+
+int p4v_amax_init_matmul(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, float* d_A_interval,
+                         float* d_B_interval, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_A || !d_B || !d_A_interval || !d_B_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_amax_init_matmul: null pointer");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    float dummy_split = 0;   // only checked for presence
+    return matmul_impl(desc, d_A, d_B, nullptr, nullptr, nullptr, d_A_interval, d_B_interval, &dummy_split, nullptr, nullptr, c,
+                       nullptr, Stage{ST_INIT, nullptr, nullptr});
+}
+
+int p4v_matmul_search_A(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                        const float* d_grad, const float* d_A_cands, float* d_A_interval, const float* d_B_interval,
+                        float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_A || !d_B || !d_out || !d_A_cands || !d_A_interval || !d_B_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_matmul_search_A: null pointer");
+    if (desc->sos) return fail(P4V_ERR_INVALID, "p4v_matmul_search_A: the split-of-softmax class searches its split (p4v_sos_search_split)");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return matmul_impl(desc, d_A, d_B, d_out, d_grad, nullptr, d_A_interval, const_cast<float*>(d_B_interval), nullptr,
+                       d_scores, d_best, c, nullptr, Stage{ST_S1, d_A_cands, nullptr});
+}
+
+int p4v_sos_search_split(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                         const float* d_grad, float* d_split, float* d_A_interval, float* d_scores, int32_t* d_best,
+                         void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_A || !d_B || !d_out || !d_split || !d_A_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_sos_search_split: null pointer");
+    if (!desc->sos) return fail(P4V_ERR_INVALID, "p4v_sos_search_split: descriptor is not a split-of-softmax matmul");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return matmul_impl(desc, d_A, d_B, d_out, d_grad, nullptr, d_A_interval, nullptr, d_split, d_scores, d_best, c, nullptr,
+                       Stage{ST_S1, nullptr, nullptr});
+}
+
+int p4v_matmul_search_B(const p4v_matmul_desc* desc, const float* d_A, const float* d_B, const float* d_out,
+                        const float* d_grad, const float* d_B_cands, const float* d_A_interval, const float* d_split,
+                        float* d_B_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                        void* stream) {
+    if (!desc || !d_A || !d_B || !d_out || !d_B_cands || !d_A_interval || !d_B_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_matmul_search_B: null pointer");
+    if (desc->sos && !d_split) return fail(P4V_ERR_INVALID, "p4v_matmul_search_B: sos needs d_split");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return matmul_impl(desc, d_A, d_B, d_out, d_grad, nullptr, const_cast<float*>(d_A_interval), d_B_interval,
+                       const_cast<float*>(d_split), d_scores, d_best, c, nullptr, Stage{ST_S2, nullptr, d_B_cands});
+}
+
+int p4v_amax_init_conv(const p4v_conv_desc* desc, const float* d_weight, const float* d_x, float* d_w_interval,
+                       float* d_a_interval, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "p4v_amax_init_conv: null pointer");
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return conv_impl(desc, d_weight, nullptr, d_x, nullptr, nullptr, nullptr, d_w_interval, d_a_interval, nullptr, nullptr, c,
+                     Stage{ST_INIT, nullptr, nullptr});
+}
+
+static int conv_search(const char* who, int want_channelwise, int stage, const p4v_conv_desc* desc, const float* d_weight,
+                       const float* d_bias, const float* d_x, const float* d_out, const float* d_grad, const float* d_cands,
+                       float* d_w_interval, float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!desc || !d_weight || !d_x || !d_out || !d_cands || !d_w_interval || !d_a_interval || !d_workspace)
+        return fail(P4V_ERR_INVALID, "%s: null pointer", who);
+    if (desc->has_bias && !d_bias) return fail(P4V_ERR_INVALID, "%s: has_bias set but d_bias is NULL", who);
+    if (want_channelwise >= 0 && (desc->channelwise != 0) != (want_channelwise != 0))
+        return fail(P4V_ERR_INVALID, "%s: descriptor.channelwise does not match the entry point", who);
+    Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
+    return conv_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, nullptr, d_w_interval, d_a_interval,
+                     d_scores, d_best, c, stage == ST_S1 ? Stage{ST_S1, d_cands, nullptr} : Stage{ST_S2, nullptr, d_cands});
+}
+
+int p4v_conv_search_w_channelwise(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                                  const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                                  const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return conv_search("p4v_conv_search_w_channelwise", 1, ST_S1, desc, d_weight, d_bias, d_x, d_out, d_grad, d_w_cands,
+                       d_w_interval, const_cast<float*>(d_a_interval), d_scores, d_best, d_workspace, workspace_bytes, stream);
+}
+
+int p4v_conv_search_w_layerwise(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                                const float* d_out, const float* d_grad, const float* d_w_cands, float* d_w_interval,
+                                const float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
+                                size_t workspace_bytes, void* stream) {
+    return conv_search("p4v_conv_search_w_layerwise", 0, ST_S1, desc, d_weight, d_bias, d_x, d_out, d_grad, d_w_cands,
+                       d_w_interval, const_cast<float*>(d_a_interval), d_scores, d_best, d_workspace, workspace_bytes, stream);
+}
+
+int p4v_conv_search_a(const p4v_conv_desc* desc, const float* d_weight, const float* d_bias, const float* d_x,
+                      const float* d_out, const float* d_grad, const float* d_a_cands, const float* d_w_interval,
+                      float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (desc && desc->a_bit >= 32) return fail(P4V_ERR_INVALID, "p4v_conv_search_a: a_bit >= 32 leaves the input unquantised (conv.py:600)");
+    return conv_search("p4v_conv_search_a", -1, ST_S2, desc, d_weight, d_bias, d_x, d_out, d_grad, d_a_cands,
+                       const_cast<float*>(d_w_interval), d_a_interval, d_scores, d_best, d_workspace, workspace_bytes, stream);
+}
+
+int p4v_score_argmax_gather(const float* d_scores, int32_t eq_n, int32_t n_blocks, const float* d_cands, float* d_interval,
+                            int32_t* d_best, void* stream) {
+    if (!d_scores || !d_cands || !d_interval || eq_n <= 0 || n_blocks <= 0)
+        return fail(P4V_ERR_INVALID, "p4v_score_argmax_gather: bad argument");
+    Ctx c{(hipStream_t)stream, Arena(nullptr, 0), false};
+    SelectParams sl{d_scores, eq_n, n_blocks, d_cands, n_blocks, 1, 0, d_interval, 1, 0, nullptr, 0.0f, nullptr, 0, d_best};
+    return launch_select(c, sl);
 }
 
 int p4v_quantize_i8(const float* d_x, int64_t rows, int64_t cols, int64_t cols_padded, const float* d_scales,

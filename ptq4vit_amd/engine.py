@@ -235,6 +235,184 @@ def conv_calibrate(*, weight, bias, x, out, grad, stride, padding, dilation, w_b
     return w_iv, a_iv, scores, best
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# Granular passes: one part of calibration_step2 per call (C ABI p4v_amax_init_* / p4v_*_search_*), for callers that
+# drive the alternation themselves like the reference's _initialize_intervals / _search_best_*_interval methods.
+# ----------------------------------------------------------------------------------------------------------------
+def _flat(t, dev, rows=None):
+    t = to_dev(t, dev).contiguous()
+    return t.reshape(rows, -1) if rows is not None else t.reshape(-1)
+
+
+class _Stepper:
+    """Tensors + descriptor + scratch of one module, shared by the granular calls on it."""
+
+    def _call(self, name, *args):
+        with torch.cuda.device(self.dev):
+            rc = getattr(self.lib, name)(C.byref(self.d), *[ptr(a) for a in args], ptr(self.ws), self.ws.numel(),
+                                         stream_ptr(self.dev))
+        _lib.check(rc, name)
+
+    def _tables(self, want, blocks, eq_n=None):
+        eq_n = self.d.eq_n if eq_n is None else eq_n
+        if not want:
+            return None, None
+        return (torch.zeros(eq_n, blocks, dtype=torch.float32, device=self.dev),
+                torch.zeros(blocks, dtype=torch.int32, device=self.dev))
+
+
+class LinearStepper(_Stepper):
+    def __init__(self, *, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_n, n_V, n_H, n_a, init_layerwise=False,
+                 postgelu=False, force_f32=False):
+        self.lib = _lib.load()
+        self.dev = dev = device_of(x, weight)
+        self.weight, self.bias, self.x, self.out, self.grad = (
+            (to_dev(t, dev).contiguous() if t is not None else None) for t in (weight, bias, x, out, grad))
+        batch, K = self.x.shape[0], self.x.shape[-1]
+        self.blocks_w, self.blocks_a, self.n_V = n_V * n_H, n_a, n_V
+        self.d = _lib.LinearDesc(batch, self.x.numel() // (batch * K), K, self.weight.shape[0], n_V, n_H, n_a, w_bit, a_bit,
+                                 metric_id(metric), eq_n, 1, int(postgelu), int(init_layerwise), int(bias is not None),
+                                 int(force_f32))
+        need = self.lib.p4v_linear_workspace_bytes(C.byref(self.d))
+        if need == 0:
+            _lib.check(-2, "p4v_linear_workspace_bytes")
+        self.ws = workspace(dev, need)
+
+    def init_intervals(self):
+        w_iv = torch.empty(self.blocks_w, dtype=torch.float32, device=self.dev)
+        a_iv = torch.empty(self.blocks_a, dtype=torch.float32, device=self.dev)
+        self._call("p4v_amax_init_linear", self.weight, self.x, w_iv, a_iv)
+        return w_iv, a_iv
+
+    def search_w(self, w_cands, w_interval, a_interval, want_scores=False):
+        """Returns (new w_interval [n_V*n_H], scores [eq_n][n_V] | None, best [n_V] | None)."""
+        w_iv = _flat(w_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.n_V)
+        self._call("p4v_linear_search_w", self.weight, self.bias, self.x, self.out, self.grad,
+                   _flat(w_cands, self.dev, self.d.eq_n + 1), w_iv, _flat(a_interval, self.dev), scores, best)
+        return w_iv, scores, best
+
+    def search_a(self, a_cands, w_interval, a_interval, want_scores=False):
+        a_iv = _flat(a_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.n_V)
+        self._call("p4v_linear_search_a", self.weight, self.bias, self.x, self.out, self.grad,
+                   _flat(a_cands, self.dev, self.d.eq_n + 1), _flat(w_interval, self.dev), a_iv, scores, best)
+        return a_iv, scores, best
+
+
+class MatMulStepper(_Stepper):
+    def __init__(self, *, A, B, out, grad, A_bit, B_bit, metric, eq_n, sos=False, init_layerwise=False):
+        self.lib = _lib.load()
+        self.dev = dev = device_of(A, B)
+        self.A, self.B = to_dev(A, dev), to_dev(B, dev)
+        self.out = to_dev(out, dev).contiguous() if out is not None else None
+        self.grad = to_dev(grad, dev).contiguous() if grad is not None else None
+        b, H, M, K = self.A.shape
+        self.H, self.sos = H, bool(sos)
+        d = self.d = _lib.MatMulDesc()
+        d.batch, d.heads, d.M, d.K, d.N = b, H, M, K, self.B.shape[3]
+        for i in range(4):
+            d.a_stride[i] = self.A.stride(i)
+            d.b_stride[i] = self.B.stride(i)
+        d.A_bit, d.B_bit, d.metric, d.eq_n, d.search_round = A_bit, B_bit, metric_id(metric), eq_n, 1
+        d.sos, d.init_layerwise, d.reserved = int(sos), int(init_layerwise), 0
+        need = self.lib.p4v_matmul_workspace_bytes(C.byref(d))
+        if need == 0:
+            _lib.check(-2, "p4v_matmul_workspace_bytes")
+        self.ws = workspace(dev, need)
+
+    def init_intervals(self):
+        """(A_interval [heads] -- None for the split-of-softmax class, whose split search sets it -- , B_interval [heads])"""
+        A_iv = torch.empty(self.H, dtype=torch.float32, device=self.dev)
+        B_iv = torch.empty(self.H, dtype=torch.float32, device=self.dev)
+        self._call("p4v_amax_init_matmul", self.A, self.B, A_iv, B_iv)
+        return (None if self.sos else A_iv), B_iv
+
+    def search_A(self, A_cands, A_interval, B_interval, want_scores=False):
+        A_iv = _flat(A_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.H)
+        self._call("p4v_matmul_search_A", self.A, self.B, self.out, self.grad, _flat(A_cands, self.dev, self.d.eq_n + 1),
+                   A_iv, _flat(B_interval, self.dev), scores, best)
+        return A_iv, scores, best
+
+    def search_split(self, want_scores=False):
+        """SoS: (split [1], A_interval [1] = split/(qmax-1), scores [20][1] | None, best [1] | None)."""
+        split = torch.empty(1, dtype=torch.float32, device=self.dev)
+        A_iv = torch.empty(1, dtype=torch.float32, device=self.dev)
+        scores = best = None
+        if want_scores:
+            if self.d.eq_n < 20:
+                raise ValueError("the split score table has 20 rows: eq_n >= 20 needed to return it")
+            scores, best = self._tables(True, self.H)
+        self._call("p4v_sos_search_split", self.A, self.B, self.out, self.grad, split, A_iv, scores, best)
+        return split, A_iv, (scores[:20, :1] if scores is not None else None), (best[:1] if best is not None else None)
+
+    def search_B(self, B_cands, A_interval, B_interval, split=None, want_scores=False):
+        B_iv = _flat(B_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.H)
+        self._call("p4v_matmul_search_B", self.A, self.B, self.out, self.grad, _flat(B_cands, self.dev, self.d.eq_n + 1),
+                   _flat(A_interval, self.dev), (_flat(split, self.dev) if self.sos else None), B_iv, scores, best)
+        return B_iv, scores, best
+
+
+class ConvStepper(_Stepper):
+    def __init__(self, *, weight, bias, x, out, grad, stride, padding, dilation, w_bit, a_bit, metric, eq_n,
+                 channelwise=True, init_layerwise=False):
+        self.lib = _lib.load()
+        self.dev = dev = device_of(x, weight)
+        self.weight, self.bias, self.x, self.out, self.grad = (
+            (to_dev(t, dev).contiguous() if t is not None else None) for t in (weight, bias, x, out, grad))
+        b, ic, H, W = self.x.shape
+        oc, _, kh, kw = self.weight.shape
+        self.nw, self.channelwise = (oc if channelwise else 1), bool(channelwise)
+        self.d = _lib.ConvDesc(b, ic, H, W, oc, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0],
+                               dilation[1], w_bit, a_bit, metric_id(metric), eq_n, 1, int(channelwise),
+                               int(init_layerwise), int(bias is not None), 0)
+        need = self.lib.p4v_conv_workspace_bytes(C.byref(self.d))
+        if need == 0:
+            _lib.check(-2, "p4v_conv_workspace_bytes")
+        self.ws = workspace(dev, need)
+
+    def init_intervals(self):
+        w_iv = torch.empty(self.nw, dtype=torch.float32, device=self.dev)
+        a_iv = torch.empty(1, dtype=torch.float32, device=self.dev)
+        self._call("p4v_amax_init_conv", self.weight, self.x, w_iv, a_iv)
+        return w_iv, a_iv
+
+    def search_w(self, w_cands, w_interval, a_interval, want_scores=False):
+        w_iv = _flat(w_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.nw)
+        name = "p4v_conv_search_w_channelwise" if self.channelwise else "p4v_conv_search_w_layerwise"
+        self._call(name, self.weight, self.bias, self.x, self.out, self.grad, _flat(w_cands, self.dev, self.d.eq_n + 1),
+                   w_iv, _flat(a_interval, self.dev), scores, best)
+        return w_iv, scores, best
+
+    def search_a(self, a_cands, w_interval, a_interval, want_scores=False):
+        a_iv = _flat(a_interval, self.dev).clone()
+        scores, best = self._tables(want_scores, self.nw)
+        self._call("p4v_conv_search_a", self.weight, self.bias, self.x, self.out, self.grad,
+                   _flat(a_cands, self.dev, self.d.eq_n + 1), _flat(w_interval, self.dev), a_iv, scores, best)
+        return a_iv, scores, best
+
+
+def score_argmax_gather(scores, cands):
+    """(interval [blocks], best [blocks]): first-maximum argmax over the candidate axis, NaN counts as the maximum."""
+    lib = _lib.load()
+    _require_cuda(scores, "scores")
+    dev = scores.device
+    scores = scores.float().contiguous()
+    eq_n, blocks = scores.shape
+    cands = to_dev(cands, dev).contiguous().reshape(-1, blocks)
+    if cands.shape[0] < eq_n:
+        raise ValueError("candidate table shorter than the score table")
+    iv = torch.empty(blocks, dtype=torch.float32, device=dev)
+    best = torch.empty(blocks, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.p4v_score_argmax_gather(ptr(scores), eq_n, blocks, ptr(cands), ptr(iv), ptr(best), stream_ptr(dev))
+    _lib.check(rc, "p4v_score_argmax_gather")
+    return iv, best
+
+
 def quantize_i8(x2d, scales, rows_per_scale, lo, hi):
     """int8 grid indices clamp(rint(x/s), lo, hi) of a 2-D fp32 tensor (K padded to 64 with zeros)."""
     lib = _lib.load()

@@ -38,3 +38,25 @@ def calib_parameters(numel_per_calib, calib_size, budget_gib=3):
         else:
             break
     return calib_batch_size, parallel_eq_n, need_batching
+
+
+def similarity(tensor_raw, tensor_sim, metric, raw_grad=None, dim=-1):
+    """Element-wise similarity of the reference's `_get_similarity` (linear.py:399-424, matmul.py:442-481,
+    conv.py:322-363): cosine reduces over `dim`; the difference metrics return one value per element and the caller
+    takes the means.  Plain torch on whatever device the tensors live on -- a public helper of the module classes;
+    the GPU search does NOT go through it (the metric is fused into the sweep epilogue)."""
+    if metric == "cosine":
+        return torch.nn.functional.cosine_similarity(tensor_raw, tensor_sim, dim=dim)
+    diff = tensor_raw - tensor_sim
+    if metric == "L1_norm":
+        return -diff.abs()
+    if metric == "L2_norm":
+        return -diff.pow(2)
+    if metric == "linear_weighted_L2_norm":
+        return -tensor_raw.abs() * diff.pow(2)
+    if metric == "square_weighted_L2_norm":
+        return -(tensor_raw * diff).pow(2)
+    if metric == "hessian":
+        assert raw_grad is not None, "raw_grad is None in _get_similarity!"
+        return -(raw_grad.reshape_as(tensor_raw) * diff).pow(2)
+    raise NotImplementedError(f"metric {metric} not implemented!")

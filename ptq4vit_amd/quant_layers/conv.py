@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import engine
-from ._common import calib_parameters, dispatch, fake_quant
+from ._common import calib_parameters, dispatch, fake_quant, similarity
 
 
 class MinMaxQuantConv2d(nn.Conv2d):
@@ -141,6 +141,36 @@ class _BatchingConv(PTQSLQuantConv2d):
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
 
+    # ---- the reference's per-pass methods, ONE GPU pass each (C ABI p4v_amax_init_conv,
+    # p4v_conv_search_w_channelwise / _layerwise, p4v_conv_search_a).  calibration_step2 runs them fused in one call. ----
+    def _stepper(self):
+        if self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("ptq4vit_amd: grouped / non-zero-padded convolutions are not implemented on the GPU")
+        return engine.ConvStepper(
+            weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=self.raw_input,
+            out=self.raw_out, grad=self.raw_grad if self.metric == "hessian" else None, stride=self.stride,
+            padding=self.padding, dilation=self.dilation, w_bit=self.w_bit, a_bit=self.a_bit, metric=self.metric,
+            eq_n=self.eq_n, channelwise=self._channelwise, init_layerwise=self.init_layerwise)
+
+    def _w_shape(self, w_iv):
+        return w_iv.view(-1, 1, 1, 1) if self._channelwise else w_iv.reshape(1, 1, 1, 1)
+
+    def _initialize_intervals(self):
+        """Reference conv.py:482-496 (channel-wise) / 312-320 (layer-wise)."""
+        w_iv, a_iv = self._stepper().init_intervals()
+        self.w_interval = self._w_shape(w_iv)
+        self.a_interval = a_iv if self.a_bit >= 32 else a_iv.reshape(())
+
+    def _search_best_w_interval(self, weight_interval_candidates):
+        """Reference conv.py:526-557 (candidates (eq_n+1, oc, 1, 1, 1)) / 365-396 (layer-wise)."""
+        w_iv, _, _ = self._stepper().search_w(weight_interval_candidates, self.w_interval, self.a_interval)
+        self.w_interval = self._w_shape(w_iv)
+
+    def _search_best_a_interval(self, input_interval_candidates):
+        """Reference conv.py:559-589 (channel-wise class with a_bit < 32 only)."""
+        a_iv, _, _ = self._stepper().search_a(input_interval_candidates, self.w_interval, self.a_interval)
+        self.a_interval = a_iv.reshape(())
+
 
 class BatchingEasyQuantConv2d(_BatchingConv):
     """Reference conv.py:279-441: layer-wise EasyQuant (BasePTQ config)."""
@@ -152,6 +182,12 @@ class BatchingEasyQuantConv2d(_BatchingConv):
         self.n_V = 1
         self.n_H = 1
 
+    def _get_similarity(self, tensor_raw, tensor_sim, metric=None, dim=-1, raw_grad=None):
+        """Reference conv.py:322-351: cosine over `dim`; difference metrics averaged over `dim`."""
+        metric = metric or self.metric
+        sim = similarity(tensor_raw, tensor_sim, metric, raw_grad=raw_grad, dim=dim)
+        return sim if metric == "cosine" else sim.mean(dim=dim)
+
 
 class ChannelwiseBatchingQuantConv2d(_BatchingConv):
     """Reference conv.py:444-614: one weight interval per output channel (PTQ4ViT config)."""
@@ -162,6 +198,15 @@ class ChannelwiseBatchingQuantConv2d(_BatchingConv):
         super().__init__(*args, **kwargs)
         self.n_V = self.out_channels
         self.n_H = 1
+
+    def _get_similarity(self, tensor_raw, tensor_sim, metric=None, raw_grad=None):
+        """Reference conv.py:498-524: tensors (b, p, oc, fh, fw); cosine over the pixels of one (image, channel),
+        the difference metrics element-wise (the caller takes the pixel mean)."""
+        metric = metric or self.metric
+        if metric == "cosine":
+            b, p, oc = tensor_sim.shape[:3]
+            return similarity(tensor_raw.reshape(b, 1, oc, -1), tensor_sim.reshape(b, p, oc, -1), metric).view(b, p, oc, 1, 1)
+        return similarity(tensor_raw, tensor_sim, metric, raw_grad=raw_grad)
 
 
 class QuantileQuantConv2d(MinMaxQuantConv2d):

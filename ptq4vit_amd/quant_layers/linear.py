@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import engine
-from ._common import POSTGELU_NEG_RANGE, calib_parameters, dispatch, fake_quant
+from ._common import POSTGELU_NEG_RANGE, calib_parameters, dispatch, fake_quant, similarity
 
 
 class MinMaxQuantLinear(nn.Linear):
@@ -184,6 +184,37 @@ class PTQSLBatchingQuantLinear(PTQSLQuantLinear):
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
         return None
+
+    # ---- the reference's per-pass methods, ONE GPU pass each (C ABI p4v_amax_init_linear /
+    # p4v_linear_search_w / p4v_linear_search_a).  calibration_step2 above runs the same kernels fused in one call. ----
+    def _stepper(self):
+        return engine.LinearStepper(
+            weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=self.raw_input,
+            out=self.raw_out, grad=self.raw_grad if self.metric == "hessian" else None, w_bit=self.w_bit,
+            a_bit=self.a_bit, metric=self.metric, eq_n=self.eq_n, n_V=self.n_V, n_H=self.n_H, n_a=self.n_a,
+            init_layerwise=self.init_layerwise, postgelu=self._postgelu)
+
+    def _initialize_intervals(self):
+        """Reference linear.py:380-397 (twin: 576-599): min-max intervals from the cached raw_input."""
+        w_iv, a_iv = self._stepper().init_intervals()
+        self.w_interval = w_iv.view(self.n_V, 1, self.n_H, 1)
+        self._set_a_interval(a_iv.view(self.n_a, 1))
+
+    def _search_best_w_interval(self, weight_interval_candidates):
+        """Reference linear.py:455-495; candidates (eq_n+1, n_V, 1, n_H, 1)."""
+        w_iv, _, _ = self._stepper().search_w(weight_interval_candidates, self.w_interval, self._positive_a_interval())
+        self.w_interval = w_iv.view(self.n_V, 1, self.n_H, 1)
+
+    def _search_best_a_interval(self, input_interval_candidates):
+        """Reference linear.py:497-533 (twin: 609-642); candidates (eq_n+1, n_a, 1)."""
+        a_iv, _, _ = self._stepper().search_a(input_interval_candidates, self.w_interval, self._positive_a_interval())
+        self._set_a_interval(a_iv.view(self.n_a, 1))
+
+    def _get_similarity(self, tensor_raw, tensor_sim, metric=None, raw_grad=None):
+        """Reference linear.py:399-424: per-element similarity, mean over the last dim for the difference metrics."""
+        metric = metric or self.metric
+        sim = similarity(tensor_raw, tensor_sim, metric, raw_grad=raw_grad, dim=-1)
+        return sim if metric == "cosine" else sim.mean(dim=-1)
 
 
 class PostGeluPTQSLBatchingQuantLinear(PTQSLBatchingQuantLinear):

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import engine
-from ._common import dispatch, fake_quant
+from ._common import dispatch, fake_quant, similarity
 
 
 class MinMaxQuantMatMul(nn.Module):
@@ -189,6 +189,44 @@ class PTQSLBatchingQuantMatMul(PTQSLQuantMatMul):
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
 
+    # ---- the reference's per-pass methods, ONE GPU pass each (C ABI p4v_amax_init_matmul,
+    # p4v_matmul_search_A / _B, p4v_sos_search_split).  calibration_step2 runs the same kernels fused in one call. ----
+    def _stepper(self):
+        A, B = self.raw_input
+        if (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) != (1, 1, 1, 1):
+            raise NotImplementedError("ptq4vit_amd: MatMul row/column sub-blocks (n_V, n_H > 1) are not implemented on the GPU")
+        self._get_padding_parameters(A, B)
+        return engine.MatMulStepper(A=A, B=B, out=self.raw_out, grad=self.raw_grad if self.metric == "hessian" else None,
+                                    A_bit=self.A_bit, B_bit=self.B_bit, metric=self.metric, eq_n=self.eq_n,
+                                    sos=self._sos, init_layerwise=self.init_layerwise)
+
+    def _initialize_intervals(self):
+        """Reference matmul.py:419-440: head-wise min-max intervals (1, heads, 1, 1, 1, 1, 1)."""
+        st = self._stepper()
+        A_iv, B_iv = st.init_intervals()
+        self.B_interval = B_iv.view(1, st.H, 1, 1, 1, 1, 1)
+        if A_iv is not None:
+            self.A_interval = A_iv.view(1, st.H, 1, 1, 1, 1, 1)
+
+    def _search_best_A_interval(self, A_interval_candidates):
+        """Reference matmul.py:483-522; candidates (eq_n+1, 1, heads, 1, 1, 1, 1, 1)."""
+        st = self._stepper()
+        A_iv, _, _ = st.search_A(A_interval_candidates, self.A_interval, self.B_interval)
+        self.A_interval = A_iv.view(1, st.H, 1, 1, 1, 1, 1)
+
+    def _search_best_B_interval(self, B_interval_candidates):
+        """Reference matmul.py:524-563 (the split-of-softmax class inherits it with its own quant_input_A)."""
+        st = self._stepper()
+        B_iv, _, _ = st.search_B(B_interval_candidates, self.A_interval, self.B_interval,
+                                 split=self.split if self._sos else None)
+        self.B_interval = B_iv.view(1, st.H, 1, 1, 1, 1, 1)
+
+    def _get_similarity(self, tensor_raw, tensor_sim, metric=None, dim=-1, raw_grad=None):
+        """Reference matmul.py:442-481: per-element similarity, mean over `dim` for the difference metrics."""
+        metric = metric or self.metric
+        sim = similarity(tensor_raw, tensor_sim, metric, raw_grad=raw_grad, dim=dim)
+        return sim if metric == "cosine" else sim.mean(dim=dim)
+
 
 class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
     """Reference matmul.py:578-644."""
@@ -204,6 +242,17 @@ class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
             self.A_interval = self.split / (self.A_qmax - 1)
 
     quant_input_A = SoSPTQSLQuantMatMul.quant_input_A
+
+    def _search_best_A_interval(self, split_candidates=None):
+        """Reference matmul.py:600-631: the split search against the unquantised B.  The engine evaluates the
+        reference's own grid 2^-i, i = 0..19 (matmul.py:636); any other `split_candidates` is refused."""
+        if split_candidates is not None:
+            grid = torch.tensor([2.0 ** (-i) for i in range(20)])
+            if split_candidates.numel() != 20 or not torch.equal(split_candidates.detach().float().cpu().reshape(-1), grid):
+                raise NotImplementedError("ptq4vit_amd: the split search evaluates the grid 2^-i, i = 0..19 (matmul.py:636)")
+        split, A_iv, _, _ = self._stepper().search_split()
+        self.split = split.reshape(())
+        self.A_interval = A_iv.reshape(())
 
     def calibration_step2(self):
         # the reference keeps raw_input / raw_out / raw_grad alive on this class (matmul.py:633-644 has no `del`)

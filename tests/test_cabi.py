@@ -19,7 +19,7 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "ptq4vit_hip.h")).read()
-    declared = set(re.findall(r"\b(p4v_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(p4v_[A-Za-z0-9_]+)\s*\(", hdr))
     assert {"p4v_linear_calibrate", "p4v_matmul_calibrate", "p4v_conv_calibrate", "p4v_version"} <= declared
     from ptq4vit_amd import _lib
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version(lib):
-    assert lib.p4v_version() == 110
+    assert lib.p4v_version() == 120
 
 
 def test_workspace_planning_matches_shapes(lib):
@@ -55,6 +55,33 @@ def test_invalid_arguments_are_reported_not_crashed(lib):
     bad = _lib.LinearDesc(32, 197, 768, 2304, 5, 1, 1, 8, 8, 4, 100, 3, 0, 0, 1, 0)   # 2304 % 5 != 0
     assert lib.p4v_linear_workspace_bytes(C.byref(bad)) == 0
     assert b"must divide" in lib.p4v_last_error()
+
+
+def test_granular_entry_points_validate_arguments(lib):
+    """the per-pass entry points exist and refuse bad arguments without touching a GPU."""
+    from ptq4vit_amd import _lib
+    null = C.c_void_p(0)
+    d = _lib.LinearDesc(32, 197, 768, 2304, 3, 1, 1, 8, 8, 4, 100, 3, 0, 0, 1, 0)
+    assert lib.p4v_amax_init_linear(C.byref(d), null, null, null, null, null, 0, null) == -1
+    assert b"p4v_amax_init_linear" in lib.p4v_last_error()
+    for fn in (lib.p4v_linear_search_w, lib.p4v_linear_search_a):
+        assert fn(C.byref(d), *([null] * 10), null, 0, null) == -1
+    m = _lib.MatMulDesc()
+    m.batch, m.heads, m.M, m.K, m.N = 2, 3, 8, 4, 8
+    m.A_bit = m.B_bit = 8
+    m.metric, m.eq_n, m.search_round, m.sos = 4, 20, 1, 1
+    one = C.c_void_p(64)   # never dereferenced: the sos / non-sos mismatch is refused first
+    assert lib.p4v_matmul_search_A(C.byref(m), *([one] * 9), one, 64, null) == -1
+    assert b"p4v_sos_search_split" in lib.p4v_last_error()
+    m.sos = 0
+    assert lib.p4v_sos_search_split(C.byref(m), *([one] * 8), one, 64, null) == -1
+    assert b"not a split-of-softmax" in lib.p4v_last_error()
+    c = _lib.ConvDesc(2, 3, 32, 32, 8, 16, 16, 16, 16, 0, 0, 1, 1, 8, 32, 4, 100, 3, 1, 0, 1, 0)
+    assert lib.p4v_conv_search_w_layerwise(C.byref(c), *([one] * 10), one, 64, null) == -1
+    assert b"channelwise does not match" in lib.p4v_last_error()
+    assert lib.p4v_conv_search_a(C.byref(c), *([one] * 10), one, 64, null) == -1
+    assert b"a_bit >= 32" in lib.p4v_last_error()
+    assert lib.p4v_score_argmax_gather(null, 0, 0, null, null, null, null) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

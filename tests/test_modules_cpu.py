@@ -191,3 +191,32 @@ def test_fold_bn_into_conv_matches_conv_then_bn():
                 got = conv(x)
             assert conv.bias is not None
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("metric", ["L1_norm", "L2_norm", "linear_weighted_L2_norm", "square_weighted_L2_norm",
+                                    "hessian", "cosine"])
+def test_get_similarity_matches_the_oracle(metric):
+    """the public `_get_similarity` helper of the module classes (reference linear.py:399-424,
+    matmul.py:442-481, conv.py:322-351 / 498-524) against the oracle's restatement."""
+    from oracle import ptq4vit_oracle as orc
+    g = torch.Generator().manual_seed(3)
+    raw = torch.randn(2, 5, 1, 3, 8, generator=g)
+    sim = raw + 0.05 * torch.randn(2, 5, 4, 3, 8, generator=g)
+    grad = 1e-3 * torch.randn(2, 5, 1, 3, 8, generator=g)
+    want = orc.similarity_lastdim(raw.numpy(), sim.numpy(), metric, grad.numpy())
+    lin = PTQSLBatchingQuantLinear(8, 24, metric=metric)
+    np.testing.assert_allclose(lin._get_similarity(raw, sim, metric, raw_grad=grad).numpy(), want, rtol=2e-6, atol=1e-9)
+    mm = PTQSLBatchingQuantMatMul(metric=metric)
+    np.testing.assert_allclose(mm._get_similarity(raw, sim, metric, dim=-1, raw_grad=grad).numpy(), want, rtol=2e-6, atol=1e-9)
+    easy = BatchingEasyQuantConv2d(3, 8, 4, metric=metric)
+    np.testing.assert_allclose(easy._get_similarity(raw, sim, metric, dim=-1, raw_grad=grad).numpy(), want, rtol=2e-6, atol=1e-9)
+    # channel-wise conv: tensors (b, p, oc, fh, fw); cosine over the pixels of one (image, channel), else element-wise
+    raw_c, sim_c, grad_c = raw[:, 0].unsqueeze(1)[:, :, 0], sim[:, 0], grad[:, 0].unsqueeze(1)[:, :, 0]   # (2,1,3,8)->5-D below
+    raw_c = raw_c.reshape(2, 1, 3, 2, 4); sim_c = sim_c.reshape(2, 4, 3, 2, 4); grad_c = grad_c.reshape(2, 1, 3, 2, 4)
+    cw = ChannelwiseBatchingQuantConv2d(3, 3, 4, metric=metric)
+    got = cw._get_similarity(raw_c, sim_c, metric, raw_grad=grad_c).numpy()
+    if metric == "cosine":
+        want_c = orc._cosine(raw_c.reshape(2, 1, 3, 8).numpy(), sim_c.reshape(2, 4, 3, 8).numpy(), -1).reshape(2, 4, 3, 1, 1)
+    else:
+        want_c = orc.elementwise_similarity(raw_c.numpy(), sim_c.numpy(), metric, grad_c.numpy())
+    np.testing.assert_allclose(got, want_c, rtol=2e-6, atol=1e-9)
