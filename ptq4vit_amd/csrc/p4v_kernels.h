@@ -1627,9 +1627,12 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     //   * fragment reads run two steps ahead of their MFMAs (three fragment buffers, counted lgkmcnt(4) waits;
     //     inline-asm ds_reads, because the compiler's own wait insertion falls back to lgkmcnt(0) whenever an
     //     LDS-DMA is pending) -- also across the candidate boundary, which therefore has no bubble;
-    //   * the epilogue of a column block (cvt, packed fma, DPP wave sum, one LDS store) is cut into KT slices that
-    //     ride in the VALU slots between the MFMAs of the OTHER column block: block 0 of candidate c during phase 1
-    //     of c, block 1 during phase 0 of c+1;
+    //   * the epilogue of a column block (cvt, fma, DPP wave sum, one LDS store) is cut into KT slices that ride in
+    //     the VALU slots between the MFMAs of the OTHER column block: block 0 of candidate c during phase 1 of c,
+    //     block 1 during phase 0 of c+1.  Element granularity, scalar ops: KT-1 slices of ceil(32 / (KT-1)) elements
+    //     and one slice for the reduction, so that every MFMA gap carries about the same 3..5 filler instructions
+    //     (one wave per SIMD hides at most ~5 single-issue instructions per 32x32x32 MFMA; packed f32 VALU beside
+    //     MFMAs costs more than two scalar ops -- MI355X_MICROARCH.md, instruction table);
     //   * the ring barrier sits in the middle of phase 1: every wave's pieces of candidate c+1 have landed (issued
     //     one candidate earlier), and the stage of candidate c-1 is refilled with c+2.
     const int sw0 = (l31 >> 2) & 3;
@@ -1645,35 +1648,34 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     TF2 tf[NB];
     static_assert((2 * KT) % NB == 0 && KT >= 3, "fragment ring needs 2 * KT divisible by the buffer count");
     constexpr int NSTEP = 2 * KT;
-    constexpr int NSL = KT - 2;                              // slices that carry element math
-    constexpr int NPAIR = RB * 8;                            // packed pairs per column block
-    constexpr int PPS = (NPAIR + NSL - 1) / NSL;             // packed pairs per slice
+    constexpr int NEL = RB * 16;                             // accumulator elements per lane and column block
+    constexpr int NSL = KT - 1;                              // slices that carry element math (the last one reduces)
+    constexpr int EPS = (NEL + NSL - 1) / NSL;               // elements per slice
     v16i acc[RB][2];
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < RB; ++i) acc[i][1] = zero16;        // consumed by the warm-up epilogue of candidate "-1"
-    v2f esum = {0.0f, 0.0f};
+    float esum0 = 0.0f, esum1 = 0.0f;                        // even / odd accumulator registers (fixed order)
     float ered = 0.0f, es1 = 1.0f, es1_next = 1.0f;
     // epilogue slice `sl` of column block cbE; result goes to res slot `slot` (= candidate + 1)
     auto epi_slice = [&](auto sl_c, auto cb_c, int slot) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_c)::value, cbE = decltype(cb_c)::value;
-        if constexpr (sl == 0) esum = v2f{0.0f, 0.0f};
+        if constexpr (sl == 0) { esum0 = 0.0f; esum1 = 0.0f; }
         if constexpr (sl < NSL) {
 #pragma unroll
-            for (int j = sl * PPS; j < (sl + 1) * PPS && j < NPAIR; ++j) {
-                const int i = j >> 3, r = (j & 7) * 2;
-                const v2f a = {(float)acc[i][cbE][r], (float)acc[i][cbE][r + 1]};
-                const v2f uu = {u[i][cbE][r], u[i][cbE][r + 1]};
-                const v2f ww = {w[i][cbE][r], w[i][cbE][r + 1]};
-                const v2f d = uu - a * es1;
-                if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; esum = t2 * t2 + esum; }
-                else if (EPI == EPI_SQ) esum = d * d + esum;
-                else if (EPI == EPI_ABS) esum += v2f{fabsf(d.x), fabsf(d.y)};
-                else esum = (ww * d) * d + esum;
+            for (int e = sl * EPS; e < (sl + 1) * EPS && e < NEL; ++e) {
+                const int i = e >> 4, r = e & 15;
+                const float a = (float)acc[i][cbE][r];
+                const float d = u[i][cbE][r] - a * es1;
+                const float ww = w[i][cbE][r];
+                float& es = (r & 1) ? esum1 : esum0;
+                if (EPI == EPI_SQ_W) { const float t2 = ww * d; es = t2 * t2 + es; }
+                else if (EPI == EPI_SQ) es = d * d + es;
+                else if (EPI == EPI_ABS) es += fabsf(d);
+                else es = (ww * d) * d + es;
             }
-        } else if constexpr (sl == NSL) {
-            ered = wave_sum_dpp(esum.x + esum.y);
         } else {
+            ered = wave_sum_dpp(esum0 + esum1);
             float* dst = (lane == 63) ? res + slot * (2 * NW) + wid * 2 + cbE : dump + lane;   // branch-free: every lane stores
             *dst = ered;
         }

@@ -21,7 +21,7 @@ SHAPES = {  # name: (K, N, n_V, postgelu)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--layer", default="fc1")
+    ap.add_argument("--layer", default="fc1", help="one layer or a comma-separated list")
     ap.add_argument("--rounds", type=int, default=1)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
@@ -29,6 +29,15 @@ def main():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="bits 1.. of p4v_stats_enable (kernel A/B switches)")
     a = ap.parse_args()
+    if "," in a.layer:
+        for name in a.layer.split(","):
+            a.layer = name
+            one(a)
+    else:
+        one(a)
+
+
+def one(a):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
@@ -69,6 +78,9 @@ def main():
         run()
     torch.cuda.synchronize()
     dt = (time.time() - t) / a.reps
+    res = run()
+    digest = "/".join(r.double().sum().item().hex() for r in res[:2] if r is not None)   # A/B builds must agree bit for bit
+    print(f"{a.layer}: intervals {digest}")
     print(f"{a.layer}: {dt * 1e3:.2f} ms per calibration ({a.rounds} round(s)); {2 * macs / dt / 1e12:.1f} TOP/s algorithmic incl. pack/finish")
 
 
