@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=197)
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="bits 1.. of p4v_stats_enable (kernel A/B switches)")
+    ap.add_argument("--kernel-stats", action="store_true", help="per-launch time of the sweep kernels (HIP events)")
     a = ap.parse_args()
     if "," in a.layer:
         for name in a.layer.split(","):
@@ -41,8 +42,8 @@ def one(a):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
-    if a.variant:
-        engine.stats_enable(a.variant << 2)
+    if a.variant or a.kernel_stats:
+        engine.stats_enable((a.variant << 2) | int(a.kernel_stats))
     if a.layer in SHAPES:
         K, N, nV, gelu = SHAPES[a.layer]
         x = torch.randn(a.batch, a.tokens, K, generator=g)
@@ -73,11 +74,20 @@ def one(a):
         raise SystemExit("unknown layer")
     run()
     torch.cuda.synchronize()
+    if a.kernel_stats:
+        engine.stats_reset()
     t = time.time()
     for _ in range(a.reps):
         run()
     torch.cuda.synchronize()
     dt = (time.time() - t) / a.reps
+    if a.kernel_stats:
+        st = engine.stats_get()
+        for k in ("sweep6", "sweep_i8", "sweep_f32"):
+            n = st[k + "_launches"]
+            if n:
+                print(f"{a.layer}: {k}: {n} launches, {st[k + '_ms'] / n * 1e3:.1f} us each, "
+                      f"{2 * st[k + '_alg_macs'] / (st[k + '_ms'] * 1e-3) / 1e12:.0f} TOP/s algorithmic")
     res = run()
     digest = "/".join(r.double().sum().item().hex() for r in res[:2] if r is not None)   # A/B builds must agree bit for bit
     print(f"{a.layer}: intervals {digest}")
