@@ -56,16 +56,23 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct Arena {
     char* base;
     size_t cap, off, peak;
+    size_t top;   // bytes taken from the END of the buffer: live for the whole call (candidate-plane cache), while the
+                  // bump region [0, off) is rewound after every pass
     bool dry;
-    Arena(void* b, size_t c) : base((char*)b), cap(c), off(0), peak(0), dry(b == nullptr) {}
+    Arena(void* b, size_t c) : base((char*)b), cap(c & ~(size_t)255), off(0), peak(0), top(0), dry(b == nullptr) {}
     template <typename T> T* get(size_t n) {
         off = (size_t)rup((long)off, 256);
         T* p = dry ? nullptr : (T*)(base + off);
         off += n * sizeof(T);
-        if (off > peak) peak = off;
+        if (off + top > peak) peak = off + top;
         return p;
     }
-    bool ok() const { return dry || off <= cap; }
+    char* get_top(size_t bytes) {
+        top += (size_t)rup((long)bytes, 256);
+        if (off + top > peak) peak = off + top;
+        return (dry || top > cap) ? nullptr : base + cap - top;
+    }
+    bool ok() const { return dry || off + top <= cap; }
 };
 
 // ---- optional per-launch timing of the sweep kernels (bench.py roofline) -----------------------
@@ -80,6 +87,7 @@ p4v_kernel_stats g_stats = {};
 //   16  no k_sweep6 (stationary operand in LDS instead of registers)  32  k_sweep6 with 8 waves (two per SIMD)
 //   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
 //   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
+//   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
 //   1, 2: kernel debug flags (SweepParams::dbg)
 int g_variant = 0;
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
@@ -425,6 +433,15 @@ int launch_select(Ctx& c, const SelectParams& p) {
 // candidate per score block.  The GEMM is D[rows][cols] = rowop . colop^T; in the plain orientation rows
 // are samples (activations / matmul A) and columns are output features (weights / matmul B); the cosine
 // metric runs swapped so that the feature axis it reduces over lies on the MFMA rows.
+// The candidate-expanded plane of one search (weights x 100 scales, ...) depends on the operand and on the candidate
+// table only -- both fixed for the whole calibration_step2 (the table is built once from the INITIAL interval,
+// reference linear.py:544-545) -- so rounds 2..R find it already packed.  One object per (module, searched operand),
+// owned by the *_impl call; the buffer lives at the top of the workspace.
+struct PlaneCache {
+    char* buf = nullptr;
+    bool assigned = false, valid = false;
+};
+
 struct Operand {
     PackParams pk;        // src/strides/sizes/scales/mode filled by the caller (dst, C, Rp, Kp set by run_pass)
     bool expanded;        // true: one plane per candidate
@@ -457,6 +474,7 @@ struct Pass {
     float* scores_out; int scores_out_ld;
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
+    PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
 };
 
 static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
@@ -502,9 +520,15 @@ int run_pass(Ctx& c, Pass& ps) {
     const size_t slack = stat_ok ? 4096 : 0;   // k_sweep4's ring keeps issuing a few tiles past the last candidate
     if (pairs && chunk > 1) chunk &= ~1;                  // chunks start on a candidate pair
     const int chunk_al = pairs ? ((chunk + 1) & ~1) : chunk;   // an odd count is padded to a whole pair
-    char* rowbuf = c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
+    PlaneCache* pc = (ps.cache && chunk >= ps.eq_n && !ps.store_out && ps.row.expanded != ps.col.expanded &&
+                      !(ps.twin && ps.row2.expanded) && !(g_variant & 1024)) ? ps.cache : nullptr;
+    if (pc && !pc->assigned) {
+        pc->buf = c.ws.get_top((size_t)exp_plane * chunk_al + slack);
+        pc->assigned = true; pc->valid = false;
+    }
+    char* rowbuf = (pc && ps.row.expanded) ? pc->buf : c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
-    char* colbuf = c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk_al : 1) + slack);
+    char* colbuf = (pc && ps.col.expanded) ? pc->buf : c.ws.get<char>((size_t)col_plane1 * (ps.col.expanded ? chunk_al : 1) + slack);
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
@@ -547,9 +571,11 @@ int run_pass(Ctx& c, Pass& ps) {
 
     for (int c0 = 0; c0 < ps.eq_n; c0 += chunk) {
         const int nc = std::min(chunk, ps.eq_n - c0);
-        if (ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
+        const bool packed = pc && pc->valid;   // (a cached plane is never chunked: one iteration)
+        if (ps.row.expanded && !packed) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
-        if (ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
+        if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
+        if (pc) pc->valid = true;
         if (stat_ok) {
             Sweep3Params q{};
             q.S = a_search ? colbuf : rowbuf; q.s_zs = 0;
@@ -788,6 +814,8 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     }
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
+    PlaneCache plane_w, plane_a;
+    const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int n_rounds = sg.full() ? d->search_round : 1;
     auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
@@ -815,6 +843,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 }
                 wc = w_mix;
             }
+            ps.cache = (keep_planes && nH == 1) ? &plane_w : nullptr;   // (n_H > 1: the table mixes in the current interval)
             ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
             ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
             ps.scores_out = scores_out ? scores_out + ((long)slot(round, 0) * d->eq_n) * nV : nullptr;
@@ -869,6 +898,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 }
                 ac = a_mix;
             }
+            ps.cache = (keep_planes && nA == 1) ? &plane_a : nullptr;
             ps.nj = 1; ps.cands = a_cands; ps.cand_cs = nA; ps.cand_js = 0; ps.cand_off = a;
             ps.interval = a_iv; ps.out_js = 0; ps.out_off = a;
             ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)slot(round, 1) * d->eq_n) * nV : nullptr;
@@ -894,7 +924,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     fp.twin = false; fp.epi = EPI_STORE; fp.wt_mode = 0; fp.eq_n = 1;
                     fp.row = xneg_operand(); fp.row2 = Operand{};
                     fp.s1 = ps.s2;
-                    fp.store_out = Ufold;
+                    fp.store_out = Ufold; fp.cache = nullptr;
                     fp.scores_out = nullptr; fp.best_out = nullptr;
                     CHK(run_pass(c, fp));
                     ps.twin = false; ps.row2 = Operand{};
@@ -1022,6 +1052,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     }
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_A, memo_B;
+    PlaneCache plane_A, plane_B;
+    const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int nAiv = d->sos ? 1 : H;
     const int n_rounds = sg.full() ? d->search_round : 1;
@@ -1054,6 +1086,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.j_mode = 2; ps.j_div = H; ps.nj = H; ps.cos_j_mode = 2; ps.cos_j_div = H;
             ps.norm = cosm ? 1.0 / (double)M : 1.0 / ((double)M * N);
             ps.cands = A_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = A_iv; ps.out_js = 1;
+            ps.cache = keep_planes ? &plane_A : nullptr;
             ps.scores_out = so; ps.scores_out_ld = H; ps.best_out = bo;
             CHK(run_pass(c, ps));
         } else {
@@ -1103,6 +1136,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.j_mode = 2; ps.j_div = H; ps.nj = H; ps.cos_j_mode = 2; ps.cos_j_div = H;
             ps.norm = cosm ? 1.0 / (double)M : 1.0 / ((double)M * N);
             ps.cands = B_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = B_iv; ps.out_js = 1;
+            ps.cache = keep_planes ? &plane_B : nullptr;
             ps.scores_out = so_B; ps.scores_out_ld = H;
             ps.best_out = bo_B;
             CHK(run_pass(c, ps));
@@ -1207,6 +1241,8 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
 
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
+    PlaneCache plane_w, plane_a;
+    const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int n_rounds = sg.full() ? d->search_round : 1;
     for (int round = 0; round < n_rounds; ++round) {
@@ -1228,6 +1264,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             else if (d->channelwise) { ps.cos_j_mode = 3; ps.norm = 1.0; }
             else { ps.cos_j_mode = 0; ps.norm = 1.0 / (double)L; }
             ps.cands = w_cands; ps.cand_cs = nw; ps.cand_js = 1; ps.interval = w_iv; ps.out_js = 1;
+            ps.cache = keep_planes ? &plane_w : nullptr;
             ps.scores_out = so; ps.scores_out_ld = nw; ps.best_out = bo;
             CHK(run_pass(c, ps));
             if (memo_on) { CHK(read_dev(c, w_iv, nw, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
@@ -1242,6 +1279,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             setup(ps, false);
             ps.nj = 1; ps.j_mode = 0; ps.norm = 1.0 / ((double)L * oc);
             ps.cands = a_cands; ps.cand_cs = 1; ps.cand_js = 0; ps.interval = a_iv; ps.out_js = 0;
+            ps.cache = keep_planes ? &plane_a : nullptr;
             ps.scores_out = so_a; ps.scores_out_ld = nw;
             ps.best_out = bo_a;
             CHK(run_pass(c, ps));
