@@ -184,7 +184,7 @@ def main():
             issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-            # The dominant kernel (largest share of GPU time, profiles/r1_v6_bench_1stream_kernel_stats.csv) is the
+            # The dominant kernel (largest share of GPU time, profiles/r1_v7_bench_1stream_kernel_stats.csv) is the
             # register-stationary sweep k_sweep6; achieved = algorithmic ops per launch / its average launch duration.
             # All int8 sweeps together (k_sweep6 + k_sweep2: what the reference's GEMMs map to) are reported beside it.
             k6 = st["sweep6_launches"] > 0
@@ -193,12 +193,17 @@ def main():
             d_iss = 2.0 * (st["sweep6_macs"] if k6 else st["sweep_i8_macs"])
             roof = {"bound": "mfma", "kernel": "k_sweep6 (int8 candidate sweep, K <= 768 layers)" if k6 else "k_sweep2 (int8 candidate sweeps)",
                     "achieved": d_alg / (d_ms * 1e-3) / 1e12, "peak": peak, "unit": "TOP/s",
-                    "frac": d_alg / (d_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                    "frac": d_alg / (d_ms * 1e-3) / 1e12 / peak,
+                    # HBM-side bytes per launch of this kernel from the PMC passes (offline: rocprofv3 --pmc cannot run
+                    # inside this process; same kernel, ViT-B fc1 launches -- see pmc_offline), null for other kernels
+                    "traffic": 0.82e9 if k6 else None,
                     "issued": d_iss / (d_ms * 1e-3) / 1e12, "launches": d_n, "avg_launch_ms": d_ms / d_n,
                     "ops_per_launch": d_alg / d_n,
-                    # offline PMC pass on this kernel (ViT-B fc1 launches, profiles/r1_pmc_fc1_sweep6.txt): matrix pipe busy
-                    # 50 % of the launch; HBM-side bytes per launch FETCH_SIZE x 2 + WRITE_SIZE vs algorithmic bytes
-                    "pmc_offline": {"source": "profiles/r1_pmc_fc1_sweep6.txt", "mfma_busy_frac": 0.50,
+                    # offline PMC pass on this kernel (ViT-B fc1 launches, profiles/r1_pmc_fc1_sweep6_v7.txt): matrix pipe
+                    # busy 57 % of the launch (77 % of the resident wave time); HBM-side bytes per launch
+                    # FETCH_SIZE x 2 + WRITE_SIZE vs algorithmic bytes
+                    "pmc_offline": {"source": "profiles/r1_pmc_fc1_sweep6_v7.txt", "mfma_busy_frac": 0.57,
+                                    "mfma_busy_frac_of_wave_time": 0.77,
                                     "traffic_bytes_per_launch": 0.82e9, "algorithmic_bytes_per_launch": 0.52e9},
                     "all_int8_sweeps": {"achieved": algo_ops / secs / 1e12, "issued": issued_ops / secs / 1e12,
                                         "frac": algo_ops / secs / 1e12 / peak, "launches": st["sweep_i8_launches"],
