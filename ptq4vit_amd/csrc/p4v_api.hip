@@ -478,6 +478,7 @@ struct Pass {
 };
 
 static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
+static const long PLANE_CACHE_MAX = 3L << 30;   // largest candidate-expanded plane kept across the rounds of one call
 
 // How many candidate groups (gridDim.z) to split a sweep into.  Splitting raises the workgroup count (fills the
 // 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary
@@ -520,8 +521,11 @@ int run_pass(Ctx& c, Pass& ps) {
     const size_t slack = stat_ok ? 4096 : 0;   // k_sweep4's ring keeps issuing a few tiles past the last candidate
     if (pairs && chunk > 1) chunk &= ~1;                  // chunks start on a candidate pair
     const int chunk_al = pairs ? ((chunk + 1) & ~1) : chunk;   // an odd count is padded to a whole pair
+    // (planes above PLANE_CACHE_MAX are re-packed every pass: with three search streams and two searched operands per
+    // module the cache would otherwise add up to 6 x PLANE_BUDGET of workspace on the 128-image configurations)
     PlaneCache* pc = (ps.cache && chunk >= ps.eq_n && !ps.store_out && ps.row.expanded != ps.col.expanded &&
-                      !(ps.twin && ps.row2.expanded) && !(g_variant & 1024)) ? ps.cache : nullptr;
+                      !(ps.twin && ps.row2.expanded) && exp_plane * (long)ps.eq_n <= PLANE_CACHE_MAX &&
+                      !(g_variant & 1024)) ? ps.cache : nullptr;
     if (pc && !pc->assigned) {
         pc->buf = c.ws.get_top((size_t)exp_plane * chunk_al + slack);
         pc->assigned = true; pc->valid = false;
