@@ -88,6 +88,7 @@ p4v_kernel_stats g_stats = {};
 //   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
 //   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
 //   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
+//   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
 //   1, 2: kernel debug flags (SweepParams::dbg)
 int g_variant = 0;
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
@@ -217,6 +218,8 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
         case EPI_SQ_W: P4V_LAUNCH2(EPI_SQ_W); break;
         case EPI_SQ: P4V_LAUNCH2(EPI_SQ); break;
         case EPI_ABS: P4V_LAUNCH2(EPI_ABS); break;
+        case EPI_FWD: P4V_LAUNCH2(EPI_FWD); break;
+        case EPI_STORE: P4V_LAUNCH2(EPI_STORE); break;
         default: P4V_LAUNCH2(EPI_W_SQ); break;
     }
 #undef P4V_LAUNCH2
@@ -536,7 +539,7 @@ int run_pass(Ctx& c, Pass& ps) {
     const int MT = Mp / 64;
     const bool cosm = ps.epi == EPI_COS;
     // fast int8 sweep (k_sweep2): needs every 32-column group inside one scale block and one score block
-    const bool fast = !stat_ok && !ps.store_out && ps.i8 && !cosm && !(g_force_v1) &&
+    const bool fast = !stat_ok && !(ps.store_out && (g_variant & 4096)) && ps.i8 && !cosm && !(g_force_v1) &&
                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
     // k_sweep4 table: [slabs of 64 stationary rows][groups of 32 streaming rows]

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const bool ncol_ok = n < p.N;
     const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
     const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
-    {
+    constexpr bool STORES = (EPI == EPI_FWD || EPI == EPI_STORE);   // no metric: the tile itself is written out
+    if constexpr (EPI != EPI_FWD) {
         // Phase 1: every load of the raw_out / weight tile issued back to back at clamped (always valid) addresses.
         // (A load inside a per-element branch costs one dependent memory round trip per element.)
         const int nc = min(n, p.N - 1);
@@ -808,9 +809,28 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
             acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c11, cur.b1, acc2[1], 0, 0, 0);
         }
         if (++kt == ktiles) {
-            // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             const float s1 = s1tab[(c - c_lo) * 8 + wid];
             const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + wid] : 1.0f;
+            if constexpr (STORES) {
+                // quant_forward (EPI_FWD: scale * acc + bias) / folded twin target (EPI_STORE: raw_out - bias - scale * acc):
+                // same arithmetic as the generic k_sweep, 128-byte coalesced rows
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        float o_sim = (float)acc[i][r] * s1;
+                        if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                        const float v = (EPI == EPI_FWD) ? o_sim + bias_n : u[i][r] - o_sim;
+                        if (ncol_ok && m < p.M) p.store[(long)z * p.M * p.N + (long)m * p.N + n] = v;
+                        acc[i][r] = 0;
+                        if (TWIN) acc2[i][r] = 0;
+                    }
+                kt = 0;
+                ++c;
+                return;
+            }
+            // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -846,6 +866,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     }
 #undef P4V_DSR
     __syncthreads();
+    if constexpr (STORES) return;
     // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
         const int cc = c_lo + i / 8, wv = i % 8;
