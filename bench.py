@@ -197,6 +197,9 @@ def main():
                     # HBM-side bytes per launch of this kernel from the PMC passes (offline: rocprofv3 --pmc cannot run
                     # inside this process; same kernel, ViT-B fc1 launches -- see pmc_offline), null for other kernels
                     "traffic": 0.82e9 if k6 else None,
+                    # the same instruction alone (MFMA-only loop, 8 waves/CU, tools/ubench_mfma.hip) sustains 4044 TOP/s on
+                    # this part at its ~2.0 GHz clock under load (profiles/r1_ubench.txt); `peak` stays the 2 x bf16 spec
+                    "peak_measured_mfma_only": 4044.0, "frac_of_measured": d_alg / (d_ms * 1e-3) / 1e12 / 4044.0,
                     "issued": d_iss / (d_ms * 1e-3) / 1e12, "launches": d_n, "avg_launch_ms": d_ms / d_n,
                     "ops_per_launch": d_alg / d_n,
                     # offline PMC pass on this kernel (ViT-B fc1 launches, profiles/r1_pmc_fc1_sweep6_v7.txt): matrix pipe
