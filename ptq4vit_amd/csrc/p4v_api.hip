@@ -600,7 +600,9 @@ int run_pass(Ctx& c, Pass& ps) {
             q.dbg = g_variant & 3;
             if (regs6) {
                 q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = (a_search ? Mp : Np) / 64;
-                const int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
+                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
+                if (const char* e = getenv("P4V_CG6")) cg6 = std::max(1, std::min(nc, atoi(e)));   // tuning only
+                if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
                 CHK(launch_sweep6(c, q, ps.epi, cg6));
                 continue;
             }
