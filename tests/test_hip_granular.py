@@ -230,3 +230,106 @@ def test_score_argmax_gather_first_maximum_and_nan_rule(eng):
     np.testing.assert_array_equal(best.cpu().numpy(), want)
     np.testing.assert_array_equal(best.cpu().numpy(), torch.argmax(torch.from_numpy(sc), dim=0).numpy())
     np.testing.assert_array_equal(iv.cpu().numpy(), cands[want, np.arange(9)])
+
+
+@pytest.mark.parametrize("name", ["linear_qkv_hessian_w8a8", "postgelu_hessian_w8a8", "linear_cosine_w8a8"])
+def test_linear_passes_honour_a_custom_candidate_table(eng, name):
+    """The granular calls take the candidate table as an INPUT (the reference passes `weight_interval_candidates` /
+    `input_interval_candidates` as arguments, linear.py:455,497): a non-uniform, per-block table must give the
+    oracle's scores and selections for exactly that table."""
+    from oracle import ptq4vit_oracle as orc
+    from tests.helpers import assert_argmax_tie_aware, assert_scores_close
+    g = load_golden(name)
+    p = g["params"]
+    nV, eq_n = p["n_V"], p["eq_n"]
+    o = orc.LinearOracle(g["weight"], g.get("bias"), w_bit=p["w_bit"], a_bit=p["a_bit"], metric=p["metric"],
+                         search_round=1, eq_alpha=p["eq_alpha"], eq_beta=p["eq_beta"], eq_n=eq_n, n_V=nV,
+                         postgelu=p["postgelu"])
+    o.initialize_intervals(g["x"])
+    rng = np.random.default_rng(5)
+    # geometric grid with a different ratio per block, shuffled: nothing like the reference's uniform grid
+    ratios = np.exp(np.linspace(np.log(0.35), np.log(1.4), eq_n + 1)).astype(np.float32)
+    w_tab = np.stack([rng.permutation(ratios) * o.w_interval.reshape(-1)[v] * (1 + 0.1 * v) for v in range(nV)], axis=1)  # (eq_n+1, nV)
+    a_tab = rng.permutation(ratios) * o.a_interval.reshape(-1)[0]                                                     # (eq_n+1,)
+    st = eng.LinearStepper(weight=_t(g["weight"]), bias=_t(g["bias"]) if "bias" in g else None, x=_t(g["x"]),
+                           out=_t(g["out"]), grad=_t(g["grad"]), w_bit=p["w_bit"], a_bit=p["a_bit"], metric=p["metric"],
+                           eq_n=eq_n, n_V=nV, n_H=1, n_a=1, postgelu=p["postgelu"])
+    w0, a0 = st.init_intervals()
+    np.testing.assert_array_equal(w0.cpu().numpy(), o.w_interval.reshape(-1))
+    np.testing.assert_array_equal(a0.cpu().numpy(), o.a_interval.reshape(-1))
+    grad = g["grad"] if p["metric"] == "hessian" else None
+    # weight pass
+    o.search_w(g["x"], g["out"], grad, w_tab.reshape(eq_n + 1, nV, 1, 1, 1))
+    w1, sw, bw = st.search_w(_t(w_tab), w0, a0, want_scores=True)
+    ref_w = o.trace[-1][1]
+    assert_scores_close(sw.cpu().numpy(), ref_w, what=name + " w table")
+    flips = assert_argmax_tie_aware(bw.cpu().numpy(), ref_w, what=name + " w argmax")
+    if flips == 0:
+        np.testing.assert_array_equal(w1.cpu().numpy(), o.w_interval.reshape(-1))
+    # activation pass against the weight interval just selected (by the oracle: keeps the two sides comparable)
+    w_sel = _t(o.w_interval.reshape(-1).copy())
+    o.search_a(g["x"], g["out"], grad, a_tab.reshape(1, 1, eq_n + 1))
+    a1, sa, ba = st.search_a(_t(a_tab), w_sel, a0, want_scores=True)
+    ref_a = o.trace[-1][1].reshape(-1, 1)
+    assert_scores_close(sa.cpu().numpy()[:, :1], ref_a, what=name + " a table")
+    flips = assert_argmax_tie_aware(ba.cpu().numpy()[:1], ref_a, what=name + " a argmax")
+    if flips == 0:
+        np.testing.assert_array_equal(a1.cpu().numpy(), o.a_interval.reshape(-1))
+
+
+def test_matmul_passes_honour_a_custom_candidate_table(eng):
+    """matmul.py:483-563 with caller-supplied (non-uniform, per-head) candidate tables, against the oracle."""
+    from oracle import ptq4vit_oracle as orc
+    from tests.helpers import assert_argmax_tie_aware, assert_scores_close
+    name = "matmul_qk_hessian_w8a8"
+    g = load_golden(name)
+    p = g["params"]
+    eq_n, H = p["eq_n"], g["A"].shape[1]
+    o = orc.MatMulOracle(A_bit=p["A_bit"], B_bit=p["B_bit"], metric=p["metric"], search_round=1, eq_alpha=p["eq_alpha"],
+                         eq_beta=p["eq_beta"], eq_n=eq_n)
+    o.initialize_intervals(g["A"], g["B"])
+    rng = np.random.default_rng(11)
+    ratios = np.exp(np.linspace(np.log(0.3), np.log(1.5), eq_n + 1)).astype(np.float32)
+    A_tab = np.stack([rng.permutation(ratios) * o.A_interval.reshape(-1)[h] for h in range(H)], axis=1)   # (eq_n+1, H)
+    B_tab = np.stack([rng.permutation(ratios) * o.B_interval.reshape(-1)[h] for h in range(H)], axis=1)
+    st = eng.MatMulStepper(A=_t(g["A"]), B=_t(g["B"]), out=_t(g["out"]), grad=_t(g["grad"]), A_bit=p["A_bit"],
+                           B_bit=p["B_bit"], metric=p["metric"], eq_n=eq_n)
+    A0, B0 = st.init_intervals()
+    np.testing.assert_array_equal(A0.cpu().numpy(), o.A_interval.reshape(-1))
+    np.testing.assert_array_equal(B0.cpu().numpy(), o.B_interval.reshape(-1))
+    o._search_blockwise("A", g["A"], g["B"], g["out"], g["grad"], A_tab.reshape(eq_n + 1, 1, H, 1, 1, 1, 1, 1))
+    A1, sA, bA = st.search_A(_t(A_tab), A0, B0, want_scores=True)
+    assert_scores_close(sA.cpu().numpy(), o.trace[-1][1], what="A table")
+    if assert_argmax_tie_aware(bA.cpu().numpy(), o.trace[-1][1], what="A argmax") == 0:
+        np.testing.assert_array_equal(A1.cpu().numpy(), o.A_interval.reshape(-1))
+    A_sel = _t(o.A_interval.reshape(-1).copy())
+    o._search_blockwise("B", g["A"], g["B"], g["out"], g["grad"], B_tab.reshape(eq_n + 1, 1, H, 1, 1, 1, 1, 1))
+    B1, sB, bB = st.search_B(_t(B_tab), A_sel, B0, want_scores=True)
+    assert_scores_close(sB.cpu().numpy(), o.trace[-1][1], what="B table")
+    if assert_argmax_tie_aware(bB.cpu().numpy(), o.trace[-1][1], what="B argmax") == 0:
+        np.testing.assert_array_equal(B1.cpu().numpy(), o.B_interval.reshape(-1))
+
+
+def test_conv_pass_honours_a_custom_candidate_table(eng):
+    """conv.py:526-557 with a caller-supplied per-channel candidate table, against the oracle."""
+    from oracle import ptq4vit_oracle as orc
+    from tests.helpers import assert_argmax_tie_aware, assert_scores_close
+    g = load_golden("conv_channelwise_hessian")
+    p = g["params"]
+    eq_n, oc = p["eq_n"], g["weight"].shape[0]
+    o = orc.ConvOracle(g["weight"], g["bias"], stride=p["stride"], w_bit=p["w_bit"], a_bit=p["a_bit"], metric=p["metric"],
+                       search_round=1, eq_alpha=p["eq_alpha"], eq_beta=p["eq_beta"], eq_n=eq_n, channelwise=True)
+    o.initialize_intervals(g["x"])
+    rng = np.random.default_rng(13)
+    ratios = np.exp(np.linspace(np.log(0.3), np.log(1.5), eq_n + 1)).astype(np.float32)
+    w_tab = np.stack([rng.permutation(ratios) * np.asarray(o.w_interval).reshape(-1)[c] for c in range(oc)], axis=1)   # (eq_n+1, oc)
+    st = eng.ConvStepper(weight=_t(g["weight"]), bias=_t(g["bias"]), x=_t(g["x"]), out=_t(g["out"]), grad=_t(g["grad"]),
+                         stride=(p["stride"],) * 2, padding=(0, 0), dilation=(1, 1), w_bit=p["w_bit"], a_bit=p["a_bit"],
+                         metric=p["metric"], eq_n=eq_n, channelwise=True)
+    w0, a0 = st.init_intervals()
+    np.testing.assert_array_equal(w0.cpu().numpy(), np.asarray(o.w_interval).reshape(-1))
+    o.search_w(g["x"], g["out"], g["grad"], w_tab.reshape(eq_n + 1, oc, 1, 1, 1))
+    w1, sw, bw = st.search_w(_t(w_tab), w0, a0, want_scores=True)
+    assert_scores_close(sw.cpu().numpy(), o.trace[-1][1], what="conv w table")
+    if assert_argmax_tie_aware(bw.cpu().numpy(), o.trace[-1][1], what="conv w argmax") == 0:
+        np.testing.assert_array_equal(w1.cpu().numpy(), np.asarray(o.w_interval).reshape(-1))
