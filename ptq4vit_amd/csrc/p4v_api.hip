@@ -89,6 +89,7 @@ p4v_kernel_stats g_stats = {};
 //   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
 //   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
 //   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
+//   8192 no candidate groups for the generic k_sweep
 //   1, 2: kernel debug flags (SweepParams::dbg)
 int g_variant = 0;
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
@@ -155,9 +156,9 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
     return 0;
 }
 
-template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams& p, int epi) {
+template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams& p, int epi, int cgroups = 1) {
     const size_t lds = 2 * (TWIN ? 3 : 2) * SW_TILE_BYTES;
-    dim3 grid(p.mtiles * p.ntiles, p.Z), block(512);
+    dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
     switch (epi) {
         case EPI_SQ_W: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ_W>), grid, block, lds, c.st, p); break;
         case EPI_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ>), grid, block, lds, c.st, p); break;
@@ -399,8 +400,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     int r;
     if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
     else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
-    else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi) : launch_sweep_epi<int8_t, false>(c, p, epi);
-    else r = twin ? launch_sweep_epi<float, true>(c, p, epi) : launch_sweep_epi<float, false>(c, p, epi);
+    else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups);
+    else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
         std::lock_guard<std::mutex> lk(g_stat_mu);
@@ -637,6 +638,12 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.dbg = g_variant & 3;
         sp.store = ps.store_out;
         int cgroups = 1;
+        if (!fast && !(g_variant & 8192)) {
+            // generic sweep: 2 workgroups per CU; per k-tile step ~2.6 us with fp32 operands (8 x mfma_f32_32x32x2 per
+            // 32x32 block), ~1.6 us on the int8 grid (measured on the patch-embedding search)
+            const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
+            cgroups = choose_cgroups(wgs, nc, sp.ktiles, 512, 20.0, ps.i8 ? 1.6 : 2.6);
+        }
         if (fast) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))

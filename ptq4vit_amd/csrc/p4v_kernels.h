@@ -397,6 +397,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const int mt = t % p.mtiles, nt = t / p.mtiles;   // m fastest: tiles sharing a B (weight) panel are adjacent
     const int z = blockIdx.y;
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
+    // candidate groups over gridDim.z (host: choose_cgroups) -- a sweep with few tiles fills the chip this way
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
 
     // ---- candidate-invariant epilogue operands, kept in registers for the whole sweep -------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -455,11 +459,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const char* gB = (const char*)p.B + (long)z * p.b_zs + (long)(n0 + ld_row) * p.ldk + ld_col;
     const int lds_st = ld_row * SW_ROW + ld_col;
 
-    const int ncand = p.c1 - p.c0;
+    const int ncand = c_hi - c_lo;
     const int total = ncand * p.ktiles;
     v4i ra, ra2, rb;
     auto gload = [&](int it) {
-        const int c = p.c0 + it / p.ktiles, kt = it % p.ktiles;
+        const int c = c_lo + it / p.ktiles, kt = it % p.ktiles;
         ra = *reinterpret_cast<const v4i*>(gA + (long)c * p.a_cs + kt * SW_BKB);
         if (TWIN) ra2 = *reinterpret_cast<const v4i*>(gA2 + (long)c * p.a2_cs + kt * SW_BKB);
         rb = *reinterpret_cast<const v4i*>(gB + (long)c * p.b_cs + kt * SW_BKB);
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
 
         if ((it + 1) % p.ktiles == 0) {
             // ---- fused similarity epilogue for candidate c ------------------------------------------
-            const int c = p.c0 + it / p.ktiles;
+            const int c = c_lo + it / p.ktiles;
             const float s1 = p.S1 ? p.S1[c * p.s_cs + sb] : 1.0f;
             const float s2 = (TWIN && p.S2) ? p.S2[c * p.s_cs + sb] : 1.0f;
             if constexpr (EPI == EPI_STORE || EPI == EPI_FWD) {
