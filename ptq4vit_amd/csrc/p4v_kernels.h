@@ -47,8 +47,7 @@ struct AbsMaxParams {
 };
 
 __global__ __launch_bounds__(256) void k_absmax(AbsMaxParams p) {
-    // grid.x = tiles-per-v * nV * nH, grid.y = D1, grid.z = D0
-    const int tiles_per_v = (p.crb_r + p.row_tile - 1) / p.row_tile;
+    // grid.x = ceil(crb_r / row_tile) * nV * nH, grid.y = D1, grid.z = D0
     int bx = blockIdx.x;
     const int h = bx % p.nH; bx /= p.nH;
     const int v = bx % p.nV; bx /= p.nV;
