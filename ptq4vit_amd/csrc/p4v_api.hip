@@ -90,6 +90,7 @@ p4v_kernel_stats g_stats = {};
 //   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
 //   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
 //   8192 no candidate groups for the generic k_sweep
+//   16384 k_sweep6 without the separate launch of the last, partial wave of workgroups
 //   1, 2: kernel debug flags (SweepParams::dbg)
 int g_variant = 0;
 bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
@@ -330,19 +331,27 @@ int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t l
 // ViT/DeiT-T/S/B and of Swin stages 2-3
 bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 4 || ktiles == 6 || ktiles == 8 || ktiles == 12; }
 
+int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups);
+
+// One workgroup per CU (512 registers per wave): `tiles` equal workgroups run in ceil(tiles / 256) waves and the last
+// one is mostly empty (ViT-B qkv: 900 tiles = 3.5 waves).  The tiles of the last, partial wave are launched separately
+// with their candidates split over q groups, so that it takes a fraction of a full wave's time; every group pays
+// the workgroup prologue (stationary operand + raw_out / raw_grad tile) again.  Cost model in microseconds.
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
-    const int per = cdiv(p.c1 - p.c0, cgroups);
-    // 32-row blocks per wave: 2 = 4 waves, one per SIMD (default: bound by its own VALU + MFMA issue, LDS-light);
-    // 1 = 8 waves, two per SIMD (A/B variant 32: hides the VALU work but doubles the fragment reads -> LDS-bound;
-    // both measure 3.33 ms per fc1 search round on MI355X)
-    const int rb = (g_variant & 32) ? 1 : 2;
-    const int nw = 8 / rb;
-    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 2 * nw * sizeof(float) + (size_t)per * nw * sizeof(float) + 64 * sizeof(float) + 256;
-    dim3 grid(p.stiles * p.ttiles, 1, cgroups);
-#ifdef P4V_TRACE
-    CHK(trace_attach(const_cast<Sweep3Params&>(p)));
-#endif
+    const int tiles = p.stiles * p.ttiles, nc = p.c1 - p.c0;
+    const int full = tiles / 256 * 256, rem = tiles - full;
+    double P = 20.0, t_c = 0.196 * p.ktiles;              // prologue, one candidate of one tile
+    if (const char* e = getenv("P4V_T6_P")) P = atof(e);  // tuning only
+    auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
+    int q_best = 0;
+    if (rem > 0 && full > 0 && !(g_variant & 16384)) {
+        double best = waves((long)tiles * cgroups) * (P + cdiv(nc, cgroups) * t_c) * 0.97;   // the uniform plan
+        for (int q = 1; q <= std::min(nc, 12); ++q) {
+            const double t = waves(full) * (P + nc * t_c) + waves((long)rem * q) * (P + cdiv(nc, q) * t_c);
+            if (t < best) { best = t; q_best = q; }
+        }
+    }
     bool timed;
     StatRec rec{};
     {
@@ -357,6 +366,36 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
+    if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
+    if (q_best > 0) {
+        Sweep3Params a = p, b = p;
+        a.tile0 = 0; a.ntile = full;
+        b.tile0 = full; b.ntile = rem;
+        CHK(launch_sweep6_part(c, a, epi, 1));
+        CHK(launch_sweep6_part(c, b, epi, q_best));
+    } else {
+        CHK(launch_sweep6_part(c, p, epi, cgroups));
+    }
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        g_stat_recs.push_back(rec);
+    }
+    return 0;
+}
+
+int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    // 32-row blocks per wave: 2 = 4 waves, one per SIMD (default: bound by its own VALU + MFMA issue, LDS-light);
+    // 1 = 8 waves, two per SIMD (A/B variant 32: hides the VALU work but doubles the fragment reads -> LDS-bound;
+    // both measure 3.33 ms per fc1 search round on MI355X)
+    const int rb = (g_variant & 32) ? 1 : 2;
+    const int nw = 8 / rb;
+    const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 2 * nw * sizeof(float) + (size_t)per * nw * sizeof(float) + 64 * sizeof(float) + 256;
+    dim3 grid(p.ntile > 0 ? p.ntile : p.stiles * p.ttiles, 1, cgroups);
+#ifdef P4V_TRACE
+    CHK(trace_attach(const_cast<Sweep3Params&>(p)));
+#endif
     int r;
 #define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds))
     switch (p.ktiles) {
@@ -372,11 +411,6 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_dump(c, grid, p.ktiles));
 #endif
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        g_stat_recs.push_back(rec);
-    }
     return 0;
 }
 

@@ -1096,6 +1096,7 @@ struct Sweep3Params {
     float* part; long p_cs; int NG;     // part[c*p_cs + (st*2+wr)*NG + tt*4+wc]
     int stiles, ttiles;
     int dbg;
+    int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them)
 #ifdef P4V_TRACE
     unsigned long long* trace;          // tuning builds only: [workgroup][8] timestamps (100 MHz) + hw id
 #endif
@@ -1531,8 +1532,8 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
 
-    const int nwg = p.stiles * p.ttiles;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    const int nwg = p.ntile > 0 ? p.ntile : p.stiles * p.ttiles;
+    const int t = p.tile0 + xcd_remap(blockIdx.x, nwg);
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
     const int s0 = st * 256 + wid * (32 * RB), t0 = tt * 64;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
