@@ -634,7 +634,8 @@ int run_pass(Ctx& c, Pass& ps) {
             q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 128;
             q.dbg = g_variant & 3;
             if (regs6) {
-                q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = (a_search ? Mp : Np) / 64;
+                // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
+                q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
                 int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
                 if (const char* e = getenv("P4V_CG6")) cg6 = std::max(1, std::min(nc, atoi(e)));   // tuning only
                 if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
@@ -689,7 +690,9 @@ int run_pass(Ctx& c, Pass& ps) {
     if (!cosm) {
         const int gdiv = stat_ok ? s3_gw : 32;
         // k_sweep4 activation search (j_mode 0) sums the whole table; its columns are sample groups
-        const int fin_cols = stat_ok ? (a_search ? s3_groups : cdiv(ps.Ncols, s3_gw)) : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
+        // (k_sweep6 skips streaming tiles that are pure padding: their table entries are never written)
+        const int fin_cols = stat_ok ? (a_search ? (regs6 ? 2 * cdiv(ps.Mrows, 64) : s3_groups) : cdiv(ps.Ncols, s3_gw))
+                                     : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
         FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
                         std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));
