@@ -684,6 +684,10 @@ int run_pass(Ctx& c, Pass& ps) {
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
                                         : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
+        if (fast && !ps.store_out) {
+            if (const char* e = getenv(sweep2g_ok(sp) ? "P4V_CG2G" : "P4V_CG2")) cgroups = std::max(1, std::min(nc, atoi(e)));   // tuning only
+            if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep2%s tiles %d x %d z %d ktiles %d cand %d twin %d -> cgroups %d\n", sweep2g_ok(sp) ? "g" : "", sp.mtiles, sp.ntiles, ps.Z, sp.ktiles, nc, (int)ps.twin, cgroups);
+        }
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
     if (ps.store_out) { c.ws.off = mark; return 0; }
