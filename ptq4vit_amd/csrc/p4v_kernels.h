@@ -1731,15 +1731,20 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+            for (int i = 0; i < RB; ++i) {
                 acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
-        // the streamed tile of candidate ci+2 trickles in one 1 KB piece per wave and step (a burst right after the
-        // barrier stalls the fragment reads)
-        {
-            constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
-            constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index of this wave
-            if constexpr (j < PPW) piece(fillT, fill_stage, std::integral_constant<int, j>{});
-        }
+                if (h == 1 && i == 0) {
+                    // the streamed tile of candidate ci+2 trickles in one 1 KB piece per wave and step (a burst right after
+                    // the barrier stalls the fragment reads).  Issue point: after the third MFMA of the step, fenced so that
+                    // only VALU / SALU work may cross -- left to the scheduler the LDS-DMA lands in the gap right behind the
+                    // fragment reads, its most expensive place (measured: -2 % per launch; after the second MFMA: no change)
+                    constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
+                    constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index of this wave
+                    __builtin_amdgcn_sched_barrier(0x6);
+                    if constexpr (j < PPW) piece(fillT, fill_stage, std::integral_constant<int, j>{});
+                    __builtin_amdgcn_sched_barrier(0x6);
+                }
+            }
         // phase 0 carries the epilogue of block 1 of the previous candidate (slot ci), phase 1 that of block 0 of this one
         if constexpr (cb == 0) epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 1>{}, ci);
         else epi_slice(std::integral_constant<int, kt>{}, std::integral_constant<int, 0>{}, ci + 1);
