@@ -352,20 +352,6 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
             if (t < best) { best = t; q_best = q; }
         }
     }
-    bool timed;
-    StatRec rec{};
-    {
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        timed = g_stat_on;
-    }
-    if (timed) {
-        HIPCHK(hipEventCreate(&rec.a));
-        HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 2;
-        rec.macs = (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
-        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
-        HIPCHK(hipEventRecord(rec.a, c.st));
-    }
     if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
     if (q_best > 0) {
         Sweep3Params a = p, b = p;
@@ -375,11 +361,6 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         CHK(launch_sweep6_part(c, b, epi, q_best));
     } else {
         CHK(launch_sweep6_part(c, p, epi, cgroups));
-    }
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -396,6 +377,21 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
+    bool timed;
+    StatRec rec{};
+    {
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        timed = g_stat_on;
+    }
+    if (timed) {   // one record per kernel launch; a split sweep books its work in proportion to the tiles of each part
+        const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        rec.kind = 2;
+        rec.macs = share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
+        rec.alg = share * g_alg_macs_cand * (p.c1 - p.c0);
+        HIPCHK(hipEventRecord(rec.a, c.st));
+    }
     int r;
 #define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds))
     switch (p.ktiles) {
@@ -411,6 +407,11 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_dump(c, grid, p.ktiles));
 #endif
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        std::lock_guard<std::mutex> lk(g_stat_mu);
+        g_stat_recs.push_back(rec);
+    }
     return 0;
 }
 
