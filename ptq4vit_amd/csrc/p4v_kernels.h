@@ -922,8 +922,15 @@ __global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
     // plain [M][N] output layout only (host: o_bs == o_nbs == 0): element (m, n) at z*o_zs + m*o_ms + n*o_ns
     const int nc = min(n, p.N - 1);
     const int mlane = m0 + wr * 64 + 4 * g;               // row of element (i = 0, r = 0) of this lane
-    const float* Obase = p.O + (long)z * p.o_zs + (long)nc * p.o_ns;
-    const float* Wbase = p.Wt + (long)z * p.o_zs + (long)nc * p.o_ns;
+    // Epilogue addressing: wave-uniform row base (SGPRs) + a per-lane offset (column, row group); every lane reads a
+    // valid element, elements outside the matrix are masked by `ok` below.
+    // (Per-element 64-bit addresses in VGPRs spill and make hipcc serialise the 64 loads of a candidate pair.)
+    const int m0w = m0 + wr * 64;
+    const int gl_max = min(4, p.M - 1), gl = min(4 * g, p.M - 1);
+    const unsigned lane_off0 = (unsigned)(nc * (int)p.o_ns);                 // this lane's column
+    const unsigned lane_off = lane_off0 + (unsigned)(gl * (int)p.o_ms);     // ... and its row group (+0 / +4 rows)
+    const float* Ou = p.O + (long)z * p.o_zs;
+    const float* Wu = p.Wt + (long)z * p.o_zs;
     const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
     const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
     const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
@@ -1028,10 +1035,18 @@ __global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = q * 8 + e;
-                        const int mc = min(mlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1);
-                        const long idx = (long)mc * p.o_ms;
-                        uo[e] = Obase[idx];
-                        gw[e] = Wbase[idx];
+                        // uniform row of the g = 0 lanes; the g = 1 lanes sit 4 rows below.  Where those 4 rows would leave
+                        // the matrix (last rows of a ragged tile) every lane reads the g = 0 row: the g = 1 elements are
+                        // masked by `ok`, the g = 0 ones still get their own row
+                        const int br = m0w + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const bool whole = br + gl_max <= p.M - 1;
+                        const long rowb = (long)min(br, p.M - 1) * p.o_ms;
+                        const unsigned lo = whole ? lane_off : lane_off0;
+                        unsigned long long ob = (unsigned long long)(Ou + rowb), wb = (unsigned long long)(Wu + rowb);
+                        asm volatile("" : "+s"(ob), "+s"(wb));   // SGPR pairs, computed here (not hoisted into 64 VGPR pairs)
+                        typedef const __attribute__((address_space(1))) float* gptr_t;   // (an integer -> pointer cast is a FLAT pointer otherwise)
+                        uo[e] = reinterpret_cast<gptr_t>(ob)[lo];
+                        gw[e] = reinterpret_cast<gptr_t>(wb)[lo];
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
