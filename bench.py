@@ -184,7 +184,7 @@ def main():
             issued_ops = 2.0 * st["sweep_i8_macs"]  # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-            # The dominant kernel (largest share of GPU time, profiles/r1_v9_bench_1stream_kernel_stats.csv) is the
+            # The dominant kernel (largest share of GPU time, profiles/r1_v10_bench_1stream_kernel_stats.csv) is the
             # register-stationary sweep k_sweep6; achieved = algorithmic ops per launch / its average launch duration.
             # All int8 sweeps together (k_sweep6 + k_sweep2: what the reference's GEMMs map to) are reported beside it.
             k6 = st["sweep6_launches"] > 0
