@@ -69,6 +69,26 @@ def test_calibration_without_gpu_fails_loudly():
         m.calibration_step2()
 
 
+def test_per_pass_methods_without_gpu_fail_loudly():
+    """The reference's per-pass methods (_initialize_intervals, _search_best_*_interval) are GPU passes too: no GPU,
+    no result -- never a silent CPU computation."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lin = PTQSLBatchingQuantLinear(8, 8, metric="L2_norm")
+    lin.raw_input, lin.raw_out, lin.raw_grad = torch.randn(2, 3, 8), torch.randn(2, 3, 8), None
+    mm = PTQSLBatchingQuantMatMul(metric="L2_norm")
+    mm.raw_input, mm.raw_out, mm.raw_grad = [torch.randn(2, 2, 3, 4), torch.randn(2, 2, 4, 3)], torch.randn(2, 2, 3, 3), None
+    conv = ChannelwiseBatchingQuantConv2d(3, 4, 2, stride=2, metric="L2_norm")
+    conv.raw_input, conv.raw_out, conv.raw_grad = torch.randn(2, 3, 4, 4), torch.randn(2, 4, 2, 2), None
+    for m in (lin, mm, conv):
+        with pytest.raises(RuntimeError, match="no CPU fallback|needs an MI355X"):
+            m._initialize_intervals()
+    cands = torch.ones(101, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback|needs an MI355X"):
+        lin.w_interval, lin.a_interval = torch.ones(1, 1, 1, 1), torch.ones(1, 1)
+        lin._search_best_w_interval(cands)
+
+
 @pytest.mark.parametrize("name", ["linear_qkv_hessian_w8a8", "postgelu_hessian_w6a6", "linear_blocks_nH2_na2"])
 def test_linear_quant_forward_matches_reference(name):
     """quant_forward (reference linear.py:62-67,601-607) with the reference's calibrated intervals."""
