@@ -1688,6 +1688,12 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     TF2 tf[NB];
     static_assert((2 * KT) % NB == 0 && KT >= 3, "fragment ring needs 2 * KT divisible by the buffer count");
     constexpr int NSTEP = 2 * KT;
+    // Step before which the ring barrier of a candidate sits: in the middle of phase 1, but never later than the first
+    // read of the NEXT candidate's stage (step NSTEP - PD) -- those fragments are only guaranteed to have landed, and
+    // to be visible to every wave, behind this candidate's wait + barrier.  (KT = 4: PD = 3 -> step 5, not 6: with the
+    // barrier at 6 the read at step 5 raced with the other waves' pieces -- practically always landed, never ordered.)
+    constexpr int SBAR = (KT + KT / 2 < NSTEP - PD) ? KT + KT / 2 : NSTEP - PD;
+    static_assert(SBAR >= KT && SBAR <= NSTEP - PD, "ring barrier must sit in phase 1, before the next candidate's first read");
     constexpr int NEL = RB * 16;                             // accumulator elements per lane and column block
     constexpr int NSL = KT - 1;                              // slices that carry element math (the last one reduces)
     constexpr int EPS = (NEL + NSL - 1) / NSL;               // elements per slice
@@ -1753,8 +1759,8 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
                     // the barrier stalls the fragment reads).  Issue point: after the third MFMA of the step, fenced so that
                     // only VALU / SALU work may cross -- left to the scheduler the LDS-DMA lands in the gap right behind the
                     // fragment reads, its most expensive place (measured: -2 % per launch; after the second MFMA: no change)
-                    constexpr int P1 = NSTEP - (KT + KT / 2);                       // steps left in this candidate after the barrier
-                    constexpr int j = (s >= KT + KT / 2) ? s - (KT + KT / 2) : s + P1;   // piece index of this wave
+                    constexpr int P1 = NSTEP - SBAR;                                // steps left in this candidate after the barrier
+                    constexpr int j = (s >= SBAR) ? s - SBAR : s + P1;              // piece index of this wave
                     __builtin_amdgcn_sched_barrier(0x6);
                     if constexpr (j < PPW) piece(fillT, fill_stage, std::integral_constant<int, j>{});
                     __builtin_amdgcn_sched_barrier(0x6);
@@ -1792,7 +1798,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
                 (step(std::integral_constant<int, decltype(lo_c)::value + S>{}, ad0, ad1, adn0, adn1, ci), ...);
             }(std::make_integer_sequence<int, decltype(hi_c)::value - decltype(lo_c)::value>{});
         };
-        constexpr int SB = KT + KT / 2;                   // the ring barrier sits in the middle of phase 1
+        constexpr int SB = SBAR;                          // the ring barrier sits in the middle of phase 1
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, SB>{});
         wait_vmcnt<0>();                                  // own pieces of candidate ci+1 (issued one candidate ago)
         __builtin_amdgcn_s_barrier();                     // ci+1 visible to all; nobody reads the stage of ci-1 any more
