@@ -1,0 +1,48 @@
+"""Register / scratch budget of the HIP kernels, read from the cross-compiled gfx950 ISA (no GPU needed).
+
+A kernel that spills pays for it twice on this path: scratch traffic is vector-memory traffic, and while an LDS-DMA is
+in flight hipcc follows every scratch access with its own `s_waitcnt vmcnt` (k_sweep2g lost 7 % per launch that way
+before its epilogue addressing was rewritten).  This test keeps that from coming back unnoticed."""
+import importlib.util
+import os
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def resources():
+    spec = importlib.util.spec_from_file_location("isa_report", os.path.join(ROOT, "tools", "isa_report.py"))
+    rep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rep)
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as d:
+        lines = open(rep.compile_asm(d)).read().split("\n")
+    res = rep.resources(lines)
+    names = rep.demangle(list(res))
+    return {names[k]: v for k, v in res.items()}
+
+
+def test_no_kernel_uses_scratch(resources):
+    assert len(resources) > 60
+    spilled = {k: v["ScratchSize"] for k, v in resources.items() if v.get("ScratchSize", 0)}
+    assert not spilled, f"kernels with scratch (register spills): {spilled}"
+
+
+def test_register_stationary_sweep_fits_one_wave_per_simd(resources):
+    k6 = {k: v for k, v in resources.items() if "k_sweep6<" in k and k.rstrip(")").split("<")[1].split(">")[0].endswith(", 2")}
+    assert len(k6) == 20                                     # 4 epilogues x KT in {3, 4, 6, 8, 12}
+    for k, v in k6.items():
+        assert v["NumVgprs"] + v["NumAgprs"] <= 512, (k, v)
+    # K = 768: the 192 stationary registers are the AGPR file, accumulators and the raw_out / raw_grad tile are VGPRs
+    big = [v for k, v in k6.items() if ", 12, 2>" in k and ("<0," in k or "<3," in k)]
+    assert big and all(v["NumAgprs"] >= 180 for v in big), big   # (hipcc keeps a few of the 192 in VGPRs)
+
+
+def test_streaming_sweeps_keep_two_waves_per_simd(resources):
+    for k, v in resources.items():
+        if "k_sweep2<" in k or "k_sweep2g<" in k or "k_sweep<" in k:
+            assert v["NumVgprs"] + v["NumAgprs"] <= 256 and v["Occupancy"] >= 2, (k, v)
