@@ -16,7 +16,9 @@
  *     desc.reserved bit 1 (or requesting score tables) disables that and makes the call fully asynchronous.
  *     *_quant_forward, p4v_quantize_i8 and p4v_fake_quant never synchronise;
  *   - return value 0 = ok, <0 = error; p4v_last_error() returns a per-thread message;
- *   - safe to call concurrently on different devices / streams (no global mutable state).
+ *   - safe to call concurrently on different devices / streams: the only state outside the call is per calling
+ *     thread (error string, the optional launch timing of p4v_stats_*) and the two p4v_debug_* words, which exist
+ *     for A/B measurements and are never written in production.
  *
  * Data layout (all fp32, row-major, K contiguous unless strides are given):
  *   Linear  x[M][K], weight[N][K], bias[N], out/grad[M][N]        (M = batch*tokens)
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define P4V_VERSION 120 /* 0.1.2: + granular entry points (amax_init / search_* / score_argmax_gather) */
+#define P4V_VERSION 130 /* 0.1.3: + p4v_pack_plane_i8, p4v_export_quantize, p4v_debug_*; stats are per calling thread */
 
 /* similarity metrics: reference quant_layers/linear.py:399-424 */
 enum p4v_metric {
@@ -243,9 +245,54 @@ int p4v_score_argmax_gather(const float* d_scores, int32_t eq_n, int32_t n_block
 int p4v_quantize_i8(const float* d_x, int64_t rows, int64_t cols, int64_t cols_padded, const float* d_scales,
                     int64_t rows_per_scale, int32_t lo, int32_t hi, int8_t* d_q, void* stream);
 
+/* ONE int8 operand plane exactly as the candidate sweeps consume it (the pack kernel of the search, one candidate):
+ *   P4V_PLANE_SYM     clamp(rint(x / s), lo, hi)                      linear.py:167; post-GELU twin linear.py:605-606 with
+ *                     (lo, hi) = (0, q-1) for the positive and (-q, 0) for the negative range (s = const_scale when
+ *                     d_scales is NULL: the fixed 0.16997.../q of linear.py:574)
+ *   P4V_PLANE_SOS_HI  clamp(rint(clamp(x, split, 1) * (q-1)), 0, q-1)               matmul.py:596, split = d_scales[0]
+ *   P4V_PLANE_SOS_LO  clamp(rint(clamp(x, 0, split) / (split / (q-1))), 0, q-1)     matmul.py:597
+ * q = qmax = 2^(bit-1).  Output layout as p4v_quantize_i8. */
+enum p4v_plane_mode { P4V_PLANE_SYM = 1, P4V_PLANE_SOS_HI = 2, P4V_PLANE_SOS_LO = 3 };
+typedef struct p4v_plane_desc {
+    int64_t rows, cols, cols_padded;
+    int64_t rows_per_scale;   /* P4V_PLANE_SYM with d_scales: scale index = row / rows_per_scale */
+    int32_t mode, lo, hi, qmax;
+    float const_scale;
+    int32_t reserved;
+} p4v_plane_desc;
+int p4v_pack_plane_i8(const p4v_plane_desc* desc, const float* d_x, const float* d_scales, int8_t* d_q, void* stream);
+
 /* y = clamp(rint(x / s), lo, hi) * s  (fake quantisation, fp32 in / fp32 out), same scale indexing. */
 int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_scales, int64_t rows_per_scale,
                    int32_t lo, int32_t hi, float* d_y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Integer export of a calibrated operand -- the data formats of the reference's utils/integer.py:8-110
+ * (SURVEY.md s8 row f-3).  The source is a logical 4-D fp32 tensor dims[0..3] read through element strides
+ * (non-contiguous views are read in place; a stride of 0 repeats the source along that dimension, which is how a
+ * weight is exported once per V-block interval, integer.py:16); the destination is contiguous, 1 byte per element
+ * (4 for P4V_EXPORT_SYM_F32).  Scale of region r for element (i0..i3): d_scale_r[sum_k (i_k / scale_r_div[k]) *
+ * scale_r_stride[k]] -- the block geometry of the (n_G, n_V, n_H) padding view (integer.py:28-43).
+ *   P4V_EXPORT_SYM_I8   int8   clamp(rint(x / s1), lo1, hi1)                               integer.py:16,75,36
+ *   P4V_EXPORT_SYM_F32  fp32   the same value as a float grid index                         integer.py:36
+ *   P4V_EXPORT_GELU_U8  uint8  (clamp(rint(x / s1), 0, hi1) + 128) + |clamp(rint(x / s2), lo2, 0)|   integer.py:63-70
+ *                              (s2 = scale2_const when d_scale2 is NULL)
+ *   P4V_EXPORT_SOS_U8   uint8  (clamp(rint(clamp(x, s1, 1) * (q-1)), 0, q-1) + 128)
+ *                              + clamp(rint(clamp(x, 0, s1) / s2), 0, q-1),  s1 = split, s2 = A_interval; the uint8 sum
+ *                              wraps modulo 256 exactly like the reference's                 integer.py:88-94
+ * Never synchronises. */
+enum p4v_export_mode { P4V_EXPORT_SYM_I8 = 0, P4V_EXPORT_SYM_F32 = 1, P4V_EXPORT_GELU_U8 = 2, P4V_EXPORT_SOS_U8 = 3 };
+typedef struct p4v_export_desc {
+    int32_t dims[4];
+    int64_t src_stride[4];
+    int64_t scale1_stride[4]; int32_t scale1_div[4];
+    int64_t scale2_stride[4]; int32_t scale2_div[4];
+    float scale2_const;
+    int32_t mode, lo1, hi1, lo2, hi2, qmax;
+    int32_t reserved;
+} p4v_export_desc;
+int p4v_export_quantize(const p4v_export_desc* desc, const float* d_src, const float* d_scale1, const float* d_scale2,
+                        void* d_dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * quant_forward of a calibrated module as ONE integer GEMM:
@@ -266,12 +313,13 @@ int p4v_matmul_quant_forward(const p4v_matmul_desc* desc, const float* d_A, cons
                              const float* d_B_interval, const float* d_split, float* d_out, void* d_workspace,
                              size_t workspace_bytes, void* stream);
 
-/* Timing hook used by bench.py: when non-NULL, the named events bracket every launch of the dominant
- * sweep kernel on `stream` so its duration can be measured live with HIP events. */
+/* Launch timing used by bench.py's roofline: while enabled on the CALLING THREAD, every sweep launch that thread
+ * enqueues is bracketed by a HIP event pair on its stream; p4v_stats_get waits for those events and returns the
+ * thread's totals.  Other threads / streams are not affected. */
 typedef struct p4v_kernel_stats {
-    double sweep_i8_ms;     /* accumulated duration of k_sweep<int8> launches  */
+    double sweep_i8_ms;     /* accumulated duration of every int8 sweep launch (k_sweep2/2g/4/5/6/7, generic int8) */
     int64_t sweep_i8_launches;
-    double sweep_i8_macs;   /* integer MACs issued by those launches (padded tiles included) */
+    double sweep_i8_macs;   /* integer MACs issued by those launches (padded tiles, second twin plane included) */
     double sweep_f32_ms;
     int64_t sweep_f32_launches;
     double sweep_f32_macs;
@@ -283,12 +331,23 @@ typedef struct p4v_kernel_stats {
     double sweep6_alg_macs;
     int64_t memo_hits;      /* search passes skipped because their input interval had already been evaluated */
     int64_t memo_misses;    /* search passes executed (with memoisation enabled)                            */
+    double sweep7_ms;          /* the large-K sweep k_sweep7 alone (also included in sweep_i8_*) */
+    int64_t sweep7_launches;
+    double sweep7_macs;
+    double sweep7_alg_macs;
 } p4v_kernel_stats;
 
-/* Enable (1) / disable (0) per-launch HIP-event timing of the sweep kernels (adds a sync per launch). */
-int p4v_stats_enable(int enable);
+int p4v_stats_enable(int enable);   /* 1 / 0: launch timing on the calling thread */
 int p4v_stats_reset(void);
 int p4v_stats_get(p4v_kernel_stats* out);
+
+/* A/B switches for measurements and kernel-vs-kernel agreement tests; never needed in production (default 0).
+ * `variant` disables individual kernel paths (bit list in csrc/p4v_api.hip), `force_generic` routes every int8 sweep
+ * through the generic kernel.  Process-wide, relaxed atomics: set them while no call is in flight. */
+int p4v_debug_set_variant(int variant, int force_generic);
+/* Overrides of launch heuristics: key 0 / 1 / 2 / 3 = candidate groups of k_sweep6 / k_sweep2 / k_sweep2g / k_sweep7
+ * (0 = cost model), key 4 = print the launch plans to stderr. */
+int p4v_debug_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

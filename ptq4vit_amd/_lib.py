@@ -43,7 +43,27 @@ class KernelStats(C.Structure):
                 ("sweep_f32_ms", C.c_double), ("sweep_f32_launches", C.c_int64), ("sweep_f32_macs", C.c_double),
                 ("sweep_i8_alg_macs", C.c_double), ("sweep_f32_alg_macs", C.c_double),
                 ("sweep6_ms", C.c_double), ("sweep6_launches", C.c_int64), ("sweep6_macs", C.c_double), ("sweep6_alg_macs", C.c_double),
-                ("memo_hits", C.c_int64), ("memo_misses", C.c_int64)]
+                ("memo_hits", C.c_int64), ("memo_misses", C.c_int64),
+                ("sweep7_ms", C.c_double), ("sweep7_launches", C.c_int64), ("sweep7_macs", C.c_double), ("sweep7_alg_macs", C.c_double)]
+
+
+class PlaneDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("cols_padded", C.c_int64), ("rows_per_scale", C.c_int64),
+                ("mode", C.c_int32), ("lo", C.c_int32), ("hi", C.c_int32), ("qmax", C.c_int32),
+                ("const_scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class ExportDesc(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 4), ("src_stride", C.c_int64 * 4),
+                ("scale1_stride", C.c_int64 * 4), ("scale1_div", C.c_int32 * 4),
+                ("scale2_stride", C.c_int64 * 4), ("scale2_div", C.c_int32 * 4),
+                ("scale2_const", C.c_float),
+                ("mode", C.c_int32), ("lo1", C.c_int32), ("hi1", C.c_int32), ("lo2", C.c_int32), ("hi2", C.c_int32),
+                ("qmax", C.c_int32), ("reserved", C.c_int32)]
+
+
+PLANE_SYM, PLANE_SOS_HI, PLANE_SOS_LO = 1, 2, 3
+EXPORT_SYM_I8, EXPORT_SYM_F32, EXPORT_GELU_U8, EXPORT_SOS_U8 = 0, 1, 2, 3
 
 
 EXPORTS = [
@@ -56,8 +76,9 @@ EXPORTS = [
     "p4v_amax_init_matmul", "p4v_matmul_search_A", "p4v_sos_search_split", "p4v_matmul_search_B",
     "p4v_amax_init_conv", "p4v_conv_search_w_channelwise", "p4v_conv_search_w_layerwise", "p4v_conv_search_a",
     "p4v_score_argmax_gather",
-    "p4v_quantize_i8", "p4v_fake_quant",
+    "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize",
     "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
+    "p4v_debug_set_variant", "p4v_debug_set_tuning",
 ]
 
 _lib = None
@@ -120,6 +141,14 @@ def load():
     lib.p4v_quantize_i8.argtypes = [fp, C.c_int64, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
     lib.p4v_fake_quant.restype = C.c_int
     lib.p4v_fake_quant.argtypes = [fp, C.c_int64, C.c_int64, fp, C.c_int64, C.c_int32, C.c_int32, fp, vp]
+    lib.p4v_pack_plane_i8.restype = C.c_int
+    lib.p4v_pack_plane_i8.argtypes = [C.POINTER(PlaneDesc), fp, fp, vp, vp]
+    lib.p4v_export_quantize.restype = C.c_int
+    lib.p4v_export_quantize.argtypes = [C.POINTER(ExportDesc), fp, fp, fp, vp, vp]
+    lib.p4v_debug_set_variant.restype = C.c_int
+    lib.p4v_debug_set_variant.argtypes = [C.c_int, C.c_int]
+    lib.p4v_debug_set_tuning.restype = C.c_int
+    lib.p4v_debug_set_tuning.argtypes = [C.c_int, C.c_int]
     lib.p4v_stats_enable.restype = C.c_int
     lib.p4v_stats_enable.argtypes = [C.c_int]
     lib.p4v_stats_reset.restype = C.c_int

@@ -13,7 +13,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -76,13 +75,17 @@ struct Arena {
 };
 
 // ---- optional per-launch timing of the sweep kernels (bench.py roofline) -----------------------
+// Per CALLING THREAD: a thread that enabled timing (p4v_stats_enable) gets an event pair around every sweep launch
+// it enqueues and reads its own totals back with p4v_stats_get.  Nothing here is shared between threads, so calls
+// on other threads / streams / devices are unaffected.
 struct StatRec { hipEvent_t a, b; int kind; double macs, alg; };
 thread_local double g_alg_macs_cand = 0;   // unpadded single-plane MACs of one candidate of the pass being launched
-std::mutex g_stat_mu;
-bool g_stat_on = false;
-std::vector<StatRec> g_stat_recs;
-p4v_kernel_stats g_stats = {};
-// Tuning A/B switches, set through p4v_stats_enable(enable) bits 2.. (tools/bench_layer.py --variant V):
+thread_local bool g_stat_on = false;
+thread_local std::vector<StatRec> g_stat_recs;
+thread_local p4v_kernel_stats g_stats = {};
+thread_local long g_memo_hits = 0, g_memo_misses = 0;
+// Kernel-variant switches for A/B measurements and kernel-vs-kernel agreement tests (p4v_debug_set_variant; 0 in
+// production).  One relaxed atomic word, read once per pass:
 //   4   no stationary-operand sweeps (everything on k_sweep2)      8   k_sweep4 instead of k_sweep5 (one candidate per pass)
 //   16  no k_sweep6 (stationary operand in LDS instead of registers)  32  k_sweep6 with 8 waves (two per SIMD)
 //   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
@@ -91,9 +94,16 @@ p4v_kernel_stats g_stats = {};
 //   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
 //   8192 no candidate groups for the generic k_sweep
 //   16384 k_sweep6 without the separate launch of the last, partial wave of workgroups
+//   32768 no k_sweep7 (K >= 1024 sweeps on k_sweep2 / k_sweep2g)
 //   1, 2: kernel debug flags (SweepParams::dbg)
-int g_variant = 0;
-bool g_force_v1 = false;   // debug / A-B switch: route every int8 sweep through the generic k_sweep
+//   bit 30: route every int8 sweep through the generic k_sweep
+std::atomic<int> g_variant_word{0};
+#define g_variant (g_variant_word.load(std::memory_order_relaxed) & 0x3fffffff)
+#define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
+// tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
+std::atomic<int> g_tune[8];
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4 };
+inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
     hipStream_t st;
@@ -258,12 +268,8 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    bool timed;
+    const bool timed = g_stat_on;
     StatRec rec{};
-    {
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        timed = g_stat_on;
-    }
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
@@ -300,7 +306,6 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        std::lock_guard<std::mutex> lk(g_stat_mu);
         g_stat_recs.push_back(rec);
     }
     return 0;
@@ -341,8 +346,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int tiles = p.stiles * p.ttiles, nc = p.c1 - p.c0;
     const int full = tiles / 256 * 256, rem = tiles - full;
-    double P = 20.0, t_c = 0.196 * p.ktiles;              // prologue, one candidate of one tile
-    if (const char* e = getenv("P4V_T6_P")) P = atof(e);  // tuning only
+    const double P = 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
     auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
     int q_best = 0;
     if (rem > 0 && full > 0 && !(g_variant & 16384)) {
@@ -352,7 +356,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
             if (t < best) { best = t; q_best = q; }
         }
     }
-    if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
+    if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
     if (q_best > 0) {
         Sweep3Params a = p, b = p;
         a.tile0 = 0; a.ntile = full;
@@ -377,12 +381,8 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    bool timed;
+    const bool timed = g_stat_on;
     StatRec rec{};
-    {
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        timed = g_stat_on;
-    }
     if (timed) {   // one record per kernel launch; a split sweep books its work in proportion to the tiles of each part
         const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
         HIPCHK(hipEventCreate(&rec.a));
@@ -409,7 +409,6 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        std::lock_guard<std::mutex> lk(g_stat_mu);
         g_stat_recs.push_back(rec);
     }
     return 0;
@@ -417,12 +416,8 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 
 int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
-    bool timed;
+    const bool timed = g_stat_on;
     StatRec rec{};
-    {
-        std::lock_guard<std::mutex> lk(g_stat_mu);
-        timed = g_stat_on;
-    }
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
@@ -439,7 +434,6 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        std::lock_guard<std::mutex> lk(g_stat_mu);
         g_stat_recs.push_back(rec);
     }
     return r;
@@ -638,8 +632,8 @@ int run_pass(Ctx& c, Pass& ps) {
                 // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
                 q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
                 int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
-                if (const char* e = getenv("P4V_CG6")) cg6 = std::max(1, std::min(nc, atoi(e)));   // tuning only
-                if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
+                if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
+                if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
                 CHK(launch_sweep6(c, q, ps.epi, cg6));
                 continue;
             }
@@ -686,8 +680,8 @@ int run_pass(Ctx& c, Pass& ps) {
                                         : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
         if (fast && !ps.store_out) {
-            if (const char* e = getenv(sweep2g_ok(sp) ? "P4V_CG2G" : "P4V_CG2")) cgroups = std::max(1, std::min(nc, atoi(e)));   // tuning only
-            if (getenv("P4V_CG6_PRINT")) fprintf(stderr, "[p4v] sweep2%s tiles %d x %d z %d ktiles %d cand %d twin %d -> cgroups %d\n", sweep2g_ok(sp) ? "g" : "", sp.mtiles, sp.ntiles, ps.Z, sp.ktiles, nc, (int)ps.twin, cgroups);
+            if (const int t_ = tune(sweep2g_ok(sp) ? TUNE_CG2G : TUNE_CG2); t_ > 0) cgroups = std::max(1, std::min(nc, t_));
+            if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep2%s tiles %d x %d z %d ktiles %d cand %d twin %d -> cgroups %d\n", sweep2g_ok(sp) ? "g" : "", sp.mtiles, sp.ntiles, ps.Z, sp.ktiles, nc, (int)ps.twin, cgroups);
         }
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
@@ -743,7 +737,6 @@ int write_dev(Ctx& c, float* d, const std::vector<float>& h) {
     return 0;
 }
 
-std::atomic<long> g_memo_hits{0}, g_memo_misses{0};
 
 // Which parts of calibration_step2 one call runs.  The fused entry points run everything (ST_ALL: initialisation, then
 // search_round x {first operand, second operand} with memoisation); the granular entry points of the C ABI
@@ -879,8 +872,13 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
     for (int round = 0; round < n_rounds; ++round) {
         // ================= weight search (linear.py:455-495) =================
+        // With n_H > 1 the weight search is a coordinate descent over the column blocks: block h is swept with the other
+        // blocks at the interval ENTERING the pass (linear.py:468), so its result also depends on w_iv, not only on a_iv
+        // (same for n_a > 1 and the activation search).  The memo keys on the counterpart interval alone and is therefore
+        // only used where that is the whole input of the pass.
+        const bool memo_w_on = memo_on && nH == 1, memo_a_on = memo_on && nA == 1;
         bool skip_w = false;
-        if (memo_on) {
+        if (memo_w_on) {
             CHK(read_dev(c, a_iv, nA, key));
             if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
         }
@@ -935,10 +933,10 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass(c, ps));
         }
-        if (memo_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
+        if (memo_w_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
         // ================= activation search (linear.py:497-533 / 609-642) =================
         bool skip_a = false;
-        if (memo_on) {
+        if (memo_a_on) {
             CHK(read_dev(c, w_iv, nV * nH, key));
             if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
         }
@@ -1002,7 +1000,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass(c, ps));
         }
-        if (memo_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
+        if (memo_a_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
     }
     return 0;
 }
@@ -1593,20 +1591,18 @@ int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_
 }
 
 int p4v_stats_enable(int enable) {
-    std::lock_guard<std::mutex> lk(g_stat_mu);
-    g_stat_on = (enable & 1) != 0;
-    g_force_v1 = (enable & 2) != 0;   // bit 1: A/B switch, generic sweep kernel only
-    g_variant = (enable >> 2);        // bits 2..: kernel tuning variants
+    g_stat_on = enable != 0;
     return 0;
 }
 
-static int stats_drain_locked() {
+static int stats_drain() {
     for (auto& r : g_stat_recs) {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        if (r.kind == 0 || r.kind == 2) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || r.kind == 2 || r.kind == 3) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
+        if (r.kind == 3) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
         if (r.kind == 1) { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
@@ -1616,8 +1612,7 @@ static int stats_drain_locked() {
 }
 
 int p4v_stats_reset(void) {
-    std::lock_guard<std::mutex> lk(g_stat_mu);
-    int r = stats_drain_locked();
+    int r = stats_drain();
     g_stats = p4v_kernel_stats{};
     g_memo_hits = 0; g_memo_misses = 0;
     return r;
@@ -1625,11 +1620,70 @@ int p4v_stats_reset(void) {
 
 int p4v_stats_get(p4v_kernel_stats* out) {
     if (!out) return fail(P4V_ERR_INVALID, "stats_get: null");
-    std::lock_guard<std::mutex> lk(g_stat_mu);
-    int r = stats_drain_locked();
-    g_stats.memo_hits = g_memo_hits.load(); g_stats.memo_misses = g_memo_misses.load();
+    int r = stats_drain();
+    g_stats.memo_hits = g_memo_hits; g_stats.memo_misses = g_memo_misses;
     *out = g_stats;
     return r;
+}
+
+int p4v_debug_set_variant(int variant, int force_generic) {
+    if (variant < 0 || variant >= (1 << 30)) return fail(P4V_ERR_INVALID, "p4v_debug_set_variant: bad variant word");
+    g_variant_word.store(variant | (force_generic ? (1 << 30) : 0), std::memory_order_relaxed);
+    return 0;
+}
+
+int p4v_debug_set_tuning(int key, int value) {
+    if (key < 0 || key >= 8) return fail(P4V_ERR_INVALID, "p4v_debug_set_tuning: unknown key %d", key);
+    g_tune[key].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_scales, int8_t* d_q, void* stream) {
+    if (!d || !d_x || !d_q || d->rows <= 0 || d->cols <= 0 || d->cols_padded % 64 || d->cols_padded < d->cols)
+        return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: bad argument");
+    if (d->mode != P4V_PLANE_SYM && d->mode != P4V_PLANE_SOS_HI && d->mode != P4V_PLANE_SOS_LO)
+        return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: unknown mode %d", d->mode);
+    if (d->mode != P4V_PLANE_SYM && !d_scales) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: split-of-softmax planes need d_scales = &split");
+    if (d->mode == P4V_PLANE_SYM && d_scales && d->rows_per_scale <= 0) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: rows_per_scale");
+    if (d->lo < -128 || d->hi > 127 || d->qmax < 2 || d->qmax > 128) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: grid wider than int8");
+    Ctx c{(hipStream_t)stream, Arena(nullptr, 0), false};
+    PackParams p = pack2d(d_x, d->rows, d->cols, d->cols);
+    p.Rp = (int)d->rows; p.Kp = (int)d->cols_padded; p.dst = d_q; p.C = 1;
+    p.scales = d_scales; p.sc_cs = 0; p.neg_scale = d->const_scale;
+    p.lo = d->lo; p.hi = d->hi; p.qm1 = (float)(d->qmax - 1);
+    if (d->mode == P4V_PLANE_SYM) {
+        p.mode = PACK_SYM;
+        if (d_scales) { p.blk_mode = 1; p.blk_div = (int)d->rows_per_scale; p.nblk_r = cdiv(d->rows, d->rows_per_scale); p.nblk_k = 1; }
+    } else {
+        p.mode = d->mode == P4V_PLANE_SOS_HI ? PACK_SOS_HI : PACK_SOS_LO;
+    }
+    return launch_pack<int8_t>(c, p);
+}
+
+int p4v_export_quantize(const p4v_export_desc* d, const float* d_src, const float* d_scale1, const float* d_scale2,
+                        void* d_dst, void* stream) {
+    if (!d || !d_src || !d_scale1 || !d_dst) return fail(P4V_ERR_INVALID, "p4v_export_quantize: null pointer");
+    if (d->mode < P4V_EXPORT_SYM_I8 || d->mode > P4V_EXPORT_SOS_U8) return fail(P4V_ERR_INVALID, "p4v_export_quantize: unknown mode %d", d->mode);
+    if (d->mode == P4V_EXPORT_SOS_U8 && !d_scale2) return fail(P4V_ERR_INVALID, "p4v_export_quantize: the split-of-softmax format needs d_scale2 = A_interval");
+    ExportParams p{};
+    long total = 1;
+    for (int i = 0; i < 4; ++i) {
+        if (d->dims[i] <= 0 || d->scale1_div[i] <= 0 || (d_scale2 && d->scale2_div[i] <= 0))
+            return fail(P4V_ERR_INVALID, "p4v_export_quantize: non-positive dimension / block size");
+        p.d[i] = d->dims[i]; p.ss[i] = d->src_stride[i];
+        p.s1s[i] = d->scale1_stride[i]; p.s1d[i] = d->scale1_div[i];
+        p.s2s[i] = d->scale2_stride[i]; p.s2d[i] = d_scale2 ? d->scale2_div[i] : 1;
+        total *= d->dims[i];
+    }
+    p.src = d_src; p.s1 = d_scale1; p.s2 = d_scale2; p.s2_const = d->scale2_const;
+    p.mode = d->mode == P4V_EXPORT_SYM_I8 ? EXP_SYM_I8 : d->mode == P4V_EXPORT_SYM_F32 ? EXP_SYM_F32
+           : d->mode == P4V_EXPORT_GELU_U8 ? EXP_GELU_U8 : EXP_SOS_U8;
+    p.lo1 = d->lo1; p.hi1 = d->hi1; p.lo2 = d->lo2; p.hi2 = d->hi2; p.qm1 = (float)(d->qmax - 1);
+    p.dst = d_dst;
+    const unsigned blocks = (unsigned)std::min<long>(cdiv(total, 256), 256L * 32);
+    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

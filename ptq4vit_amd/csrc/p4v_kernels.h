@@ -326,6 +326,55 @@ __global__ void k_fake_quant_rows(const float* x, long rows, long cols, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// k_export: integer image of a calibrated operand (the reference's utils/integer.py formats)
+// ------------------------------------------------------------------------------------------
+// One kernel for every export format: the source is a logical 4-D tensor [d0][d1][d2][d3] read through element
+// strides (a weight exported once per V-block interval has stride 0 on d0; matmul operands keep torch's strides), the
+// destination is contiguous.  Scale index of region r: sum_i (d_i / div_r[i]) * ss_r[i] -- the block geometry of the
+// (n_G, n_V, n_H) padding view (integer.py:28-43: padding is cropped again, so only the block of each REAL element
+// matters).  Arithmetic as the reference writes it: IEEE division, round-half-even, clamp; the split-of-softmax high
+// range multiplies by (q-1) (integer.py:88) where every other range divides.  HBM-bound: 4 B read, 1 B written.
+enum ExportMode {
+    EXP_SYM_I8 = 0,     // int8  clamp(rint(x / s1), lo1, hi1)                                       integer.py:16,75,36
+    EXP_SYM_F32 = 1,    // fp32  same value (quantize_matmul_input returns the float grid index)      integer.py:36
+    EXP_GELU_U8 = 2,    // uint8 (clamp(rint(x / s1), 0, hi1) + 128) + |clamp(rint(x / s2), lo2, 0)|  integer.py:63-70
+    EXP_SOS_U8 = 3      // uint8 (clamp(rint(clamp(x, s1, 1) * qm1), 0, qm1) + 128) + clamp(rint(clamp(x, 0, s1) / s2), 0, qm1)
+                        //       with s1 = split, s2 = A_interval; uint8 wrap-around like the reference  integer.py:88-94
+};
+
+struct ExportParams {
+    const float* src; long ss[4]; int d[4];
+    const float* s1; long s1s[4]; int s1d[4];
+    const float* s2; long s2s[4]; int s2d[4]; float s2_const;
+    int mode, lo1, hi1, lo2, hi2; float qm1;
+    void* dst;
+};
+
+__global__ __launch_bounds__(256) void k_export(ExportParams p) {
+    const long n3 = p.d[3], n23 = (long)p.d[2] * n3, n123 = (long)p.d[1] * n23, total = (long)p.d[0] * n123;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int i0 = (int)(i / n123), i1 = (int)((i % n123) / n23), i2 = (int)((i % n23) / n3), i3 = (int)(i % n3);
+        const float x = p.src[i0 * p.ss[0] + i1 * p.ss[1] + i2 * p.ss[2] + i3 * p.ss[3]];
+        const float s1 = p.s1[(i0 / p.s1d[0]) * p.s1s[0] + (i1 / p.s1d[1]) * p.s1s[1] + (i2 / p.s1d[2]) * p.s1s[2] + (i3 / p.s1d[3]) * p.s1s[3]];
+        const float s2 = p.s2 ? p.s2[(i0 / p.s2d[0]) * p.s2s[0] + (i1 / p.s2d[1]) * p.s2s[1] + (i2 / p.s2d[2]) * p.s2s[2] + (i3 / p.s2d[3]) * p.s2s[3]]
+                              : p.s2_const;
+        if (p.mode == EXP_SYM_I8 || p.mode == EXP_SYM_F32) {
+            const float q = fminf(fmaxf(rintf(x / s1), (float)p.lo1), (float)p.hi1);
+            if (p.mode == EXP_SYM_I8) reinterpret_cast<int8_t*>(p.dst)[i] = (int8_t)(int)q;
+            else reinterpret_cast<float*>(p.dst)[i] = q;
+        } else if (p.mode == EXP_GELU_U8) {
+            const float pos = fminf(fmaxf(rintf(x / s1), 0.0f), (float)p.hi1);
+            const float neg = fabsf(fminf(fmaxf(rintf(x / s2), (float)p.lo2), 0.0f));
+            reinterpret_cast<uint8_t*>(p.dst)[i] = (uint8_t)(((int)pos + 128 + (int)neg) & 0xff);
+        } else {
+            const float hi = fminf(fmaxf(rintf(fminf(fmaxf(x, s1), 1.0f) * p.qm1), 0.0f), p.qm1);
+            const float lo = fminf(fmaxf(rintf(fminf(fmaxf(x, 0.0f), s1) / s2), 0.0f), p.qm1);
+            reinterpret_cast<uint8_t*>(p.dst)[i] = (uint8_t)(((int)hi + 128 + (int)lo) & 0xff);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_sweep: the candidate-sweep GEMM with the similarity metric fused into the epilogue
 // ------------------------------------------------------------------------------------------
 enum EpiMode {

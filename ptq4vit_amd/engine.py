@@ -427,8 +427,89 @@ def quantize_i8(x2d, scales, rows_per_scale, lo, hi):
     return q[:, :cols]
 
 
+def pack_plane_i8(x2d, *, mode="sym", scales=None, rows_per_scale=1, lo=-128, hi=127, qmax=128, const_scale=0.0):
+    """ONE int8 operand plane exactly as the candidate sweeps consume it (p4v_pack_plane_i8): mode "sym"
+    (clamp(rint(x/s), lo, hi); `scales=None` uses `const_scale`, the post-GELU negative range), "sos_hi" / "sos_lo"
+    (split-of-softmax ranges, `scales` = the split).  Returns the [rows][cols] int8 plane (padding stripped)."""
+    lib = _lib.load()
+    _require_cuda(x2d, "x")
+    x2d = x2d.contiguous().float()
+    rows, cols = x2d.shape
+    colsp = (cols + 63) // 64 * 64
+    q = torch.empty(rows, colsp, dtype=torch.int8, device=x2d.device)
+    d = _lib.PlaneDesc(rows, cols, colsp, int(rows_per_scale),
+                       {"sym": _lib.PLANE_SYM, "sos_hi": _lib.PLANE_SOS_HI, "sos_lo": _lib.PLANE_SOS_LO}[mode],
+                       int(lo), int(hi), int(qmax), float(const_scale), 0)
+    sc = scales.to(x2d.device, torch.float32).reshape(-1).contiguous() if scales is not None else None
+    with torch.cuda.device(x2d.device):
+        rc = lib.p4v_pack_plane_i8(C.byref(d), ptr(x2d), ptr(sc), ptr(q), stream_ptr(x2d.device))
+    _lib.check(rc, "p4v_pack_plane_i8")
+    return q[:, :cols], q
+
+
+def fake_quant(x2d, scales, rows_per_scale, lo, hi):
+    """clamp(rint(x / s), lo, hi) * s of a 2-D fp32 tensor, s = scales[row // rows_per_scale] (p4v_fake_quant)."""
+    lib = _lib.load()
+    _require_cuda(x2d, "x")
+    x2d = x2d.contiguous().float()
+    rows, cols = x2d.shape
+    y = torch.empty_like(x2d)
+    scales = scales.to(x2d.device, torch.float32).reshape(-1).contiguous()
+    with torch.cuda.device(x2d.device):
+        rc = lib.p4v_fake_quant(ptr(x2d), rows, cols, ptr(scales), int(rows_per_scale), int(lo), int(hi), ptr(y),
+                                stream_ptr(x2d.device))
+    _lib.check(rc, "p4v_fake_quant")
+    return y
+
+
+def _pad4(seq, fill):
+    seq = list(seq)
+    return [fill] * (4 - len(seq)) + seq
+
+
+def export_quantize(src, *, mode, scale1, scale1_stride, scale1_div, lo1=0, hi1=0, scale2=None, scale2_stride=(0, 0, 0, 0),
+                    scale2_div=(1, 1, 1, 1), scale2_const=0.0, lo2=0, hi2=0, qmax=128, dims=None, src_stride=None):
+    """Integer image of `src` on the GPU (p4v_export_quantize).  `src` is viewed as the 4-D tensor `dims` through the
+    element strides `src_stride` (default: src's own shape / strides, left-padded to 4-D).  Returns a contiguous device
+    tensor of `dims`: int8 (sym_i8), float32 (sym_f32) or uint8 (gelu_u8 / sos_u8)."""
+    lib = _lib.load()
+    _require_cuda(src, "export source")
+    dev = src.device
+    src = src.detach()
+    if src.dtype != torch.float32:
+        src = src.float()
+    if dims is None:
+        dims, src_stride = _pad4(src.shape, 1), _pad4(src.stride(), 0)
+    code = {"sym_i8": _lib.EXPORT_SYM_I8, "sym_f32": _lib.EXPORT_SYM_F32, "gelu_u8": _lib.EXPORT_GELU_U8,
+            "sos_u8": _lib.EXPORT_SOS_U8}[mode]
+    out = torch.empty(tuple(dims), dtype={"sym_i8": torch.int8, "sym_f32": torch.float32}.get(mode, torch.uint8), device=dev)
+    d = _lib.ExportDesc()
+    for i in range(4):
+        d.dims[i], d.src_stride[i] = int(dims[i]), int(src_stride[i])
+        d.scale1_stride[i], d.scale1_div[i] = int(scale1_stride[i]), int(scale1_div[i])
+        d.scale2_stride[i], d.scale2_div[i] = int(scale2_stride[i]), int(scale2_div[i])
+    d.scale2_const = float(scale2_const)
+    d.mode, d.lo1, d.hi1, d.lo2, d.hi2, d.qmax, d.reserved = code, int(lo1), int(hi1), int(lo2), int(hi2), int(qmax), 0
+    s1 = to_dev(torch.as_tensor(scale1), dev).reshape(-1).contiguous()
+    s2 = to_dev(torch.as_tensor(scale2), dev).reshape(-1).contiguous() if scale2 is not None else None
+    with torch.cuda.device(dev):
+        rc = lib.p4v_export_quantize(C.byref(d), ptr(src), ptr(s1), ptr(s2), ptr(out), stream_ptr(dev))
+    _lib.check(rc, "p4v_export_quantize")
+    return out
+
+
 def stats_enable(flag):
-    _lib.load().p4v_stats_enable(int(flag))
+    """Launch timing of the sweep kernels on the CALLING thread (bench.py roofline)."""
+    _lib.load().p4v_stats_enable(int(bool(flag)))
+
+
+def debug_variant(variant=0, force_generic=False):
+    """Kernel A/B switches (tests, tools/bench_layer.py); 0 in production."""
+    _lib.check(_lib.load().p4v_debug_set_variant(int(variant), int(bool(force_generic))), "p4v_debug_set_variant")
+
+
+def debug_tuning(key, value):
+    _lib.check(_lib.load().p4v_debug_set_tuning(int(key), int(value)), "p4v_debug_set_tuning")
 
 
 def stats_reset():

@@ -111,15 +111,16 @@ class PTQSLQuantLinear(MinMaxQuantLinear):
         grid indices (exact int32 accumulation) and rescaled by s_a * s_w[block] -- the arithmetic of the candidate
         sweeps; the fake-quant fp32 formulation below is kept for CPU tensors and whenever autograd is recording."""
         assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
-        if (self.int8_forward and x.is_cuda and self.w_bit <= 8 and self.a_bit <= 8
+        # what p4v_linear_quant_forward implements (include/ptq4vit_hip.h): 2..8 bit grids, blocks that tile the layer.
+        # Inside that envelope the engine's errors propagate -- no silent switch to another arithmetic.
+        native = (2 <= self.w_bit <= 8 and 2 <= self.a_bit <= 8 and self.out_features % self.n_V == 0
+                  and self.in_features % self.n_H == 0 and self.in_features % self.n_a == 0)
+        if (self.int8_forward and native and x.is_cuda
                 and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
-            try:
-                return engine.linear_quant_forward(
-                    weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=x,
-                    w_interval=self.w_interval, a_interval=self._positive_a_interval(), w_bit=self.w_bit,
-                    a_bit=self.a_bit, n_V=self.n_V, n_H=self.n_H, n_a=self.n_a, postgelu=self._postgelu)
-            except NotImplementedError:
-                pass
+            return engine.linear_quant_forward(
+                weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=x,
+                w_interval=self.w_interval, a_interval=self._positive_a_interval(), w_bit=self.w_bit,
+                a_bit=self.a_bit, n_V=self.n_V, n_H=self.n_H, n_a=self.n_a, postgelu=self._postgelu)
         w_sim, bias_sim = self.quant_weight_bias()
         return F.linear(self.quant_input(x), w_sim, bias_sim)
 
@@ -206,8 +207,19 @@ class PTQSLBatchingQuantLinear(PTQSLQuantLinear):
         self.w_interval = w_iv.view(self.n_V, 1, self.n_H, 1)
 
     def _search_best_a_interval(self, input_interval_candidates):
-        """Reference linear.py:497-533 (twin: 609-642); candidates (eq_n+1, n_a, 1)."""
-        a_iv, _, _ = self._stepper().search_a(input_interval_candidates, self.w_interval, self._positive_a_interval())
+        """Reference linear.py:497-533 (twin: 609-642).  The reference builds and indexes this table as
+        (n_a, 1, eq_n+1) (linear.py:544, 512); the engine wants candidate-major (eq_n+1, n_a).  Both layouts are
+        accepted -- they only coincide for n_a == 1 -- anything else is refused."""
+        c = input_interval_candidates
+        n_c = self.eq_n + 1
+        if c.dim() == 3 and tuple(c.shape) == (self.n_a, 1, n_c):
+            c = c.reshape(self.n_a, n_c).t()                  # the reference's layout
+        elif c.numel() == n_c * self.n_a and c.shape[0] == n_c:
+            c = c.reshape(n_c, self.n_a)                      # candidate-major
+        else:
+            raise ValueError(f"input_interval_candidates: expected shape ({self.n_a}, 1, {n_c}) (reference layout) or "
+                             f"({n_c}, {self.n_a}[, 1]), got {tuple(c.shape)}")
+        a_iv, _, _ = self._stepper().search_a(c.contiguous(), self.w_interval, self._positive_a_interval())
         self._set_a_interval(a_iv.view(self.n_a, 1))
 
     def _get_similarity(self, tensor_raw, tensor_sim, metric=None, raw_grad=None):

@@ -106,16 +106,18 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
         epilogue; the fake-quant fp32 formulation is kept for CPU tensors, autograd and block layouts other than
         head-wise."""
         assert self.calibrated is not None, f"You should run calibrate_forward before run quant_forward for {self}"
+        if self.crb_rows_A is None or self.crb_rows_B is None:
+            # intervals loaded from elsewhere (shard.exchange_intervals on a rank that did not search this module, or a
+            # checkpoint): the block geometry is a function of the operand shapes only (matmul.py:109-122)
+            self._get_padding_parameters(A, B)
         headwise = (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) == (1, 1, 1, 1) and A.dim() == 4 and \
             self.n_G_B == A.shape[1] and (self._sos or self.n_G_A == A.shape[1])
-        if (self.int8_forward and A.is_cuda and headwise and self.A_bit <= 8 and self.B_bit <= 8
+        if (self.int8_forward and A.is_cuda and headwise and 2 <= self.A_bit <= 8 and 2 <= self.B_bit <= 8
                 and not (torch.is_grad_enabled() and (A.requires_grad or B.requires_grad))):
-            try:
-                return engine.matmul_quant_forward(A=A, B=B, A_interval=self.A_interval, B_interval=self.B_interval,
-                                                   split=self.split if self._sos else None, A_bit=self.A_bit,
-                                                   B_bit=self.B_bit, sos=self._sos)
-            except NotImplementedError:
-                pass
+            # inside the envelope of p4v_matmul_quant_forward the engine's errors propagate (no silent fallback)
+            return engine.matmul_quant_forward(A=A, B=B, A_interval=self.A_interval, B_interval=self.B_interval,
+                                               split=self.split if self._sos else None, A_bit=self.A_bit,
+                                               B_bit=self.B_bit, sos=self._sos)
         return self.quant_input_A(A) @ self.quant_input_B(B)
 
     # ---- the GPU search --------------------------------------------------------------------------
@@ -255,7 +257,8 @@ class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         self.A_interval = A_iv.reshape(())
 
     def calibration_step2(self):
-        # the reference keeps raw_input / raw_out / raw_grad alive on this class (matmul.py:633-644 has no `del`)
+        """Reference matmul.py:633-644 (caches are deleted at the end, :644)."""
         self._initialize_calib_parameters()
         self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
         self.calibrated = True
+        del self.raw_input, self.raw_out, self.raw_grad

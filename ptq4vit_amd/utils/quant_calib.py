@@ -418,8 +418,28 @@ class HessianQuantCalibrator(QuantCalibrator):
         self.owner = owner
         raw_pred_softmax = self._raw_pred_softmax() if with_grad else None
 
+        # Capture plan.  Default (the design BASELINE.json's north_star names): every rank runs the same deterministic
+        # capture passes with hooks on its OWN modules only -- no data-path collective -- and the only exchange is the
+        # interval all-gather at the end.  Opt-in (`shard_capture = True` / P4V_SHARD_CAPTURE=1): sub-batch sharded
+        # capture, every rank runs 1/world of the passes hooking ALL modules and the pieces are gathered onto the owners
+        # (shard.exchange_captures).  Whether that collective is entered must be the SAME decision on every rank, so it
+        # is derived from rank-invariant quantities only (all_sizes covers every module on every rank; a rank that owns
+        # nothing, or whose own cache would need several groups, decides exactly like the others).
+        bs_ = getattr(self, "batch_size", None) or self.calib_loader.batch_size
+        n_sub = sum(-(-inp.shape[0] // bs_) for inp, _ in self.calib_loader)
+        want_shard = getattr(self, "shard_capture", None)
+        if want_shard is None:
+            want_shard = os.environ.get("P4V_SHARD_CAPTURE", "0") == "1"
+        shard_cap = False
+        if world > 1 and not self.sequential and want_shard:
+            per_rank = [sum(all_sizes.get(n, 0) for n in names if owner[n] == r) for r in range(world)]
+            during = sum(all_sizes.values()) / world          # every rank holds all modules x its share of sub-batches
+            shard_cap = (n_sub >= world and max(per_rank) + during <= self.cache_budget_bytes
+                         and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
         if self.sequential:
             groups = [[n] for n in mine]  # predecessors must already run quantised: one capture per module
+        elif shard_cap:
+            groups = [mine]               # one exchange, then everything this rank owns (possibly nothing)
         else:
             sizes = all_sizes if all_sizes is not None else self._estimate_cache_bytes(mine)
             groups, cur, acc = [], [], 0
@@ -432,13 +452,6 @@ class HessianQuantCalibrator(QuantCalibrator):
             if cur:
                 groups.append(cur)
         t_cap = t_cal = 0.0
-        # Sub-batch sharded capture (world > 1): every rank runs 1/world of the sub-batch passes hooking ALL modules
-        # and the pieces are gathered onto the owners -- instead of every rank repeating all passes for its own
-        # modules.  Needs every rank to see at least one sub-batch and the whole cache to fit the budget.
-        bs_ = getattr(self, "batch_size", None) or self.calib_loader.batch_size
-        n_sub = sum(-(-inp.shape[0] // bs_) for inp, _ in self.calib_loader)
-        shard_cap = (world > 1 and not self.sequential and getattr(self, "shard_capture", True) and n_sub >= world
-                     and len(groups) == 1 and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
         for grp in groups:
             t1 = time.time()
             if shard_cap:

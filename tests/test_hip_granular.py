@@ -146,7 +146,7 @@ def test_linear_module_per_pass_methods_reproduce_calibration_step2(name):
     m._initialize_intervals()
     mult = _mult5(m, m.weight.device)
     wc = mult.view(-1, 1, 1, 1, 1) * m.w_interval.unsqueeze(0)                    # reference linear.py:544
-    ac = mult.view(-1, 1, 1) * m._positive_a_interval().unsqueeze(0)              # reference linear.py:545
+    ac = mult.view(1, 1, -1) * m._positive_a_interval().unsqueeze(-1)             # reference linear.py:545: (n_a, 1, eq_n+1)
     _drive(m, "_search_best_w_interval", "_search_best_a_interval", wc, ac, m.search_round)
     _same(m.w_interval, fused.w_interval, name + " w_interval")
     _same(m._positive_a_interval(), fused._positive_a_interval(), name + " a_interval")

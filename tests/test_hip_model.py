@@ -199,11 +199,11 @@ def test_full_size_determinism_and_kernel_agreement(vitb_qkv):
     r2 = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
     for a, b in zip(r1, r2):
         assert torch.equal(a, b), "run-to-run results differ"
-    engine.stats_enable(4 << 2)          # variant bit 2: stationary-operand sweep off -> streaming k_sweep2
+    engine.debug_variant(4)              # variant 4: stationary-operand sweep off -> streaming k_sweep2
     try:
         r3 = engine.linear_calibrate(**vitb_qkv, want_scores=True, **HP)
     finally:
-        engine.stats_enable(0)
+        engine.debug_variant(0)
     assert_scores_close(r1[2].cpu().numpy(), r3[2].cpu().numpy(), rtol=2e-5, what="k_sweep3 vs k_sweep2")
     assert torch.equal(r1[3], r3[3]) and torch.equal(r1[0], r3[0]) and torch.equal(r1[1], r3[1])
     assert torch.isfinite(r1[2]).all() and (r1[2][:, 0] < 0).all() and (r1[2][:, 1, :, 0] < 0).all()

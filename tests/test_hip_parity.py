@@ -232,11 +232,11 @@ def test_fast_sweep_matches_generic_sweep(eng):
     hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, n_V=3, n_H=1, n_a=1)
     args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), want_scores=True)
     fast = eng.linear_calibrate(**args, **hp)
-    eng.stats_enable(2)
+    eng.debug_variant(0, force_generic=True)
     try:
         slow = eng.linear_calibrate(**args, **hp)
     finally:
-        eng.stats_enable(0)
+        eng.debug_variant(0)
     torch.cuda.synchronize()
     assert_scores_close(fast[2].cpu().numpy(), slow[2].cpu().numpy(), rtol=1e-5, what="fast vs generic")
     assert torch.equal(fast[3], slow[3])

@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=197)
     ap.add_argument("--bits", type=int, default=8)
-    ap.add_argument("--variant", type=int, default=0, help="bits 1.. of p4v_stats_enable (kernel A/B switches)")
+    ap.add_argument("--variant", type=int, default=0, help="p4v_debug_set_variant word (kernel A/B switches)")
+    ap.add_argument("--tune", default="", help="key=value,... launch-heuristic overrides (p4v_debug_set_tuning)")
     ap.add_argument("--kernel-stats", action="store_true", help="per-launch time of the sweep kernels (HIP events)")
     a = ap.parse_args()
     if "," in a.layer:
@@ -42,8 +43,11 @@ def one(a):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
-    if a.variant or a.kernel_stats:
-        engine.stats_enable((a.variant << 2) | int(a.kernel_stats))
+    engine.debug_variant(a.variant)
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        engine.debug_tuning(int(k), int(v))
+    engine.stats_enable(a.kernel_stats)
     if a.layer in SHAPES:
         K, N, nV, gelu = SHAPES[a.layer]
         x = torch.randn(a.batch, a.tokens, K, generator=g)
