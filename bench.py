@@ -67,23 +67,143 @@ def probe_shapes(net, wrapped, image):
     return shapes
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The numpy oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample:
-    one search round of the ViT-B `proj` layer (32x197x768 -> 768, hessian, eq_n=100), then scaled by
-    algorithmic MACs to the 74-module / 3-round workload."""
-    from oracle.ptq4vit_oracle import LinearOracle
+def _cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([t.get("num_threads", 1) for t in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return model, threads, os.cpu_count() or 1
+
+
+# ViT-B/224 layer types: (count per network, builder of one seeded module at `imgs` images) -- SURVEY.md s8-d4 asks for
+# per-layer-type timings x counts for the headline config (a full ViT-B run of the CPU path takes of the order of an hour)
+def _cpu_layer_types(imgs, dim=768, heads=12, tokens=197, mlp=4, patch=16, img=224):
+    from oracle.ptq4vit_oracle import ConvOracle, LinearOracle, MatMulOracle
     rng = np.random.default_rng(0)
-    M, K, N = 32 * 197, 768, 768
-    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
-    b = np.zeros(N, np.float32)
-    x = rng.standard_normal((32, 197, K)).astype(np.float32)
-    out = (x.reshape(-1, K) @ w.T + b).reshape(32, 197, N)
-    grad = (rng.standard_normal(out.shape) * 1e-3).astype(np.float32)
-    o = LinearOracle(w, b, w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=1, n_V=1, chunk=20)
+    hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=1)
+    f32 = np.float32
+
+    def linear(K, N, n_V, gelu=False, rows=None):
+        w = (rng.standard_normal((N, K)) * 0.02).astype(f32)
+        b = np.zeros(N, f32)
+        x = rng.standard_normal((imgs, tokens, K) if rows is None else (imgs, K)).astype(f32)
+        if gelu:
+            x = (0.5 * x * (1.0 + np.tanh(0.7978845608 * (x + 0.044715 * x ** 3)))).astype(f32)
+        out = (x @ w.T + b).astype(f32)
+        grad = (rng.standard_normal(out.shape) * 1e-3).astype(f32)
+        o = LinearOracle(w, b, w_bit=8, a_bit=8, n_V=n_V, postgelu=gelu, chunk=16, **hp)
+        return (lambda: o.calibration_step2(x, out, grad)), 2.0 * 100 * x.size / K * K * N
+
+    def matmul(sos):
+        D = dim // heads
+        if sos:
+            A = rng.standard_normal((imgs, heads, tokens, tokens)).astype(f32) * 3
+            A = np.exp(A - A.max(-1, keepdims=True))
+            A = (A / A.sum(-1, keepdims=True)).astype(f32)
+            B = rng.standard_normal((imgs, heads, tokens, D)).astype(f32)
+        else:
+            A = (rng.standard_normal((imgs, heads, tokens, D)) * D ** -0.5).astype(f32)
+            B = rng.standard_normal((imgs, heads, D, tokens)).astype(f32)
+        out = (A @ B).astype(f32)
+        grad = (rng.standard_normal(out.shape) * 1e-3).astype(f32)
+        o = MatMulOracle(A_bit=8, B_bit=8, sos=sos, chunk=4, **hp)
+        per = imgs * heads * A.shape[2] * A.shape[3] * B.shape[3]
+        return (lambda: o.calibration_step2(A, B, out, grad)), ((20 + 100) if sos else 200) * per
+
+    def conv():
+        w = (rng.standard_normal((dim, 3, patch, patch)) * 0.02).astype(f32)
+        b = np.zeros(dim, f32)
+        x = rng.standard_normal((imgs, 3, img, img)).astype(f32)
+        o = ConvOracle(w, b, stride=patch, w_bit=8, a_bit=32, channelwise=True, **hp)
+        from oracle.ptq4vit_oracle import im2col
+        cols, fh, fw = im2col(x, (patch, patch), (patch, patch), (0, 0), (1, 1))
+        out = (cols @ w.reshape(dim, -1).T).transpose(0, 2, 1).reshape(imgs, dim, fh, fw).astype(f32)
+        grad = (rng.standard_normal(out.shape) * 1e-3).astype(f32)
+        return (lambda: o.calibration_step2(x, out, grad)), 100.0 * imgs * fh * fw * 3 * patch * patch * dim
+
+    depth = 12
+    return [("qkv", depth, lambda: linear(dim, 3 * dim, 3)), ("proj", depth, lambda: linear(dim, dim, 1)),
+            ("fc1", depth, lambda: linear(dim, mlp * dim, 1)), ("fc2 (post-GELU twin)", depth, lambda: linear(mlp * dim, dim, 1, gelu=True)),
+            ("matmul1 q.k", depth, lambda: matmul(False)), ("matmul2 attn.v (split-of-softmax)", depth, lambda: matmul(True)),
+            ("patch-embed conv (channel-wise)", 1, conv), ("head", 1, lambda: linear(dim, 1000, 1, rows=1))]
+
+
+def cpu_baseline(calib=32, rounds=3, sample_images=2):
+    """CPU path beside the GPU number: the numpy oracle (a port of the reference algorithm, pinned to the
+    reference by tests/golden) timed on this box's host cores, one search round of EVERY ViT-B/224 layer type at
+    `sample_images` images, scaled to the headline workload: x (calib / sample_images) images (the work is linear in
+    the rows), x `rounds`, x layer counts.  Search only -- the reference's CPU path would add 74 x 8 capture passes.
+    Returns (estimated seconds for one ViT-B/224 calibration, per-type table, seconds spent sampling)."""
+    table = []
+    total = spent = 0.0
+    for name, count, build in _cpu_layer_types(sample_images):
+        run, macs = build()
+        t = time.time()
+        run()
+        dt = time.time() - t
+        spent += dt
+        est = dt * (calib / sample_images) * rounds * count
+        total += est
+        table.append({"layer": name, "count": count, "sample_s": round(dt, 3), "sample_tmacs": round(macs / 1e12, 4),
+                      "cpu_tflops": round(2.0 * macs / dt / 1e12, 3), "est_full_s": round(est, 1)})
+    return total, table, spent
+
+
+def cpu_full_deit_tiny(calib=4):
+    """BASELINE.json config 0 on the CPU path, in full: DeiT-tiny/224, BasePTQ (cosine, 1 round), 4 calibration images --
+    every wrapped module's step 2 through the numpy oracle on tensors captured by a CPU forward/backward of the same
+    network (capture time reported separately).  ~1 min of host time: run with `bench.py --cpu-full`, not by default."""
+    import contextlib
+    import io
+    from oracle.ptq4vit_oracle import ConvOracle, LinearOracle, MatMulOracle
+    from ptq4vit_amd.configs import BasePTQ
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    net = models.get_net("deit_tiny_patch16_224", seed=0, device="cpu")
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, BasePTQ)
+    images = torch.randn(calib, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    t_search = [0.0]
+    npy = lambda t: None if t is None else t.detach().numpy()
+    for m in wrapped.values():
+        def step2(_m=m):
+            hp = dict(metric=_m.metric, eq_alpha=_m.eq_alpha, eq_beta=_m.eq_beta, eq_n=_m.eq_n, search_round=_m.search_round)
+            t = time.time()
+            if isinstance(_m, MinMaxQuantLinear):
+                LinearOracle(npy(_m.weight), npy(_m.bias), w_bit=_m.w_bit, a_bit=_m.a_bit, n_V=_m.n_V,
+                             postgelu=type(_m).__name__.startswith("PostGelu"), **hp).calibration_step2(
+                    npy(_m.raw_input), npy(_m.raw_out), npy(_m.raw_grad))
+            elif isinstance(_m, MinMaxQuantConv2d):
+                ConvOracle(npy(_m.weight), npy(_m.bias), stride=_m.stride, w_bit=_m.w_bit, a_bit=32,
+                           channelwise=type(_m).__name__.startswith("Channelwise"), **hp).calibration_step2(
+                    npy(_m.raw_input), npy(_m.raw_out), npy(_m.raw_grad))
+            else:
+                MatMulOracle(A_bit=_m.A_bit, B_bit=_m.B_bit, sos=type(_m).__name__.startswith("SoS"), **hp).calibration_step2(
+                    npy(_m.raw_input[0]), npy(_m.raw_input[1]), npy(_m.raw_out), npy(_m.raw_grad))
+            t_search[0] += time.time() - t
+            _m.calibrated = True
+            del _m.raw_input, _m.raw_out, _m.raw_grad
+        m.calibration_step2 = step2
+    cal = HessianQuantCalibrator(net, wrapped, SyntheticLoader(images), sequential=False, batch_size=4)
     t = time.time()
-    o.calibration_step2(x, out, grad)
-    dt = time.time() - t
-    return dt, 2.0 * 100 * M * K * N  # seconds, MACs of the sample (w + a search)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        cal.batching_quant_calib()
+    wall = time.time() - t
+    return {"config": "DeiT-tiny/224 BasePTQ W8A8, 4 calibration images, 74 modules (BASELINE.json config 0)",
+            "wall_s": round(wall, 2), "search_s": round(t_search[0], 2), "capture_s": round(wall - t_search[0], 2),
+            "layers_per_s": round(len(wrapped) / wall, 3)}
 
 
 def main():
@@ -95,6 +215,7 @@ def main():
     ap.add_argument("--calib", type=int, default=32)
     ap.add_argument("--bits", type=int, default=8, help="W/A bit width of every wrapped module (8 = headline W8A8; 6 = the W6A6 config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="also run BASELINE config 0 (DeiT-tiny/224 BasePTQ x 4 images) through the CPU oracle, in full")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -217,16 +338,16 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        dt, sample_macs = cpu_baseline()
-        lin, mm, conv = search_macs(wrapped, shapes, args.calib)
-        est_total = dt * (lin + mm + conv) / sample_macs
-        try:
-            from threadpoolctl import threadpool_info
-            threads = max([t.get("num_threads", 1) for t in threadpool_info()] + [1])
-        except Exception:
-            threads = os.cpu_count()
-        cpu = {"value": n_mod / est_total, "unit": "layers/s", "cores": threads, "kind": "port",
-               "sample": f"numpy oracle, ViT-B proj layer 32x197x768->768, 1 search round: {dt:.1f} s; scaled by algorithmic MACs to 74 modules x 3 rounds (search only, no capture)"}
+        cpu_model, threads, logical = _cpu_info()
+        est_s, per_type, spent = cpu_baseline(calib=args.calib)
+        cpu = {"value": n_mod / est_s, "unit": "layers/s", "cores": threads, "kind": "port",
+               "cpu_model": cpu_model, "logical_cpus": logical, "est_calibration_s": round(est_s, 1),
+               "sample": f"numpy oracle (port of the reference's calibration_step2, pinned by tests/golden), ONE search round of each "
+                         f"ViT-B/224 layer type at 2 images ({spent:.1f} s of CPU work), scaled x16 images x 3 rounds x layer "
+                         f"counts to the 74-module workload; search only (the reference's CPU path adds 74 x 8 capture passes)",
+               "per_layer_type": per_type}
+        if args.cpu_full:
+            cpu["config0_full_run"] = cpu_full_deit_tiny()
 
     if rank == 0:
         t = cals[-1].timings

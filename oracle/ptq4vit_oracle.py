@@ -71,6 +71,26 @@ def quant_int(x: np.ndarray, s, lo: int, hi: int) -> np.ndarray:
     return q.astype(np.int32)
 
 
+def twin_planes(x: np.ndarray, s_pos, s_neg, qmax: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Integer planes of the post-GELU twin quantiser, quant_layers/linear.py:605-606:
+    k_pos = clamp(round(x / s_pos), 0, q-1), k_neg = clamp(round(x / s_neg), -q, 0)."""
+    return quant_int(x, s_pos, 0, qmax - 1), quant_int(x, s_neg, -qmax, 0)
+
+
+def sos_planes(A: np.ndarray, split, qmax: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Integer planes of the split-of-softmax quantiser, quant_layers/matmul.py:596-597:
+    k_hi = clamp(round(clamp(A, split, 1) * (q-1)), 0, q-1), k_lo = clamp(round(clamp(A, 0, split) / (split/(q-1))), 0, q-1).
+    The ranges are NOT disjoint: A >= split gives k_lo = round(split / a_int) (= q-1 up to rounding), A < split gives
+    k_hi = round(split (q-1)) (0 when split (q-1) < 0.5) -- SURVEY.md App. A-9."""
+    A = np.asarray(A, dtype=F32)
+    q1 = F32(qmax - 1)
+    split = F32(split)
+    a_int = split / q1
+    hi = np.clip(np.rint(np.clip(A, split, F32(1)) * q1), 0, qmax - 1).astype(np.int32)
+    lo = np.clip(np.rint(np.clip(A, F32(0), split) / a_int), 0, qmax - 1).astype(np.int32)
+    return hi, lo
+
+
 def _cosine(a: np.ndarray, b: np.ndarray, axis: int) -> np.ndarray:
     """torch.nn.functional.cosine_similarity(a, b, dim=axis, eps=1e-8).
 

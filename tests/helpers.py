@@ -61,3 +61,27 @@ def assert_interval_parity(got, ref, cand_step_rel, what=""):
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
     assert rel.max(initial=0.0) <= cand_step_rel, f"{what}: interval rel diff {rel.max():.3e}"
     return int((got != ref).sum())
+
+
+def candidate_grid(eq_alpha, eq_beta, eq_n):
+    """The fp32 multiplier table of the reference (linear.py:544)."""
+    return np.array([eq_alpha + i * (eq_beta - eq_alpha) / eq_n for i in range(eq_n + 1)], dtype=np.float32)
+
+
+def assert_on_candidate_grid(got, ref, mult, what=""):
+    """Every interval is bit-identical to the reference's, or -- where the search settled on a different (near-tied)
+    candidate -- it is another entry of the SAME candidate table: got / ref = mult[a] / mult[b] for some a, b (both are
+    mult[.] * initial interval in fp32).  Returns the number of blocks that differ; nothing else is tolerated."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    m = np.asarray(mult, dtype=np.float64)[:-1]
+    ratios = (m[:, None] / m[None, :]).reshape(-1)
+    differ = 0
+    for j, (g, r) in enumerate(zip(got, ref)):
+        if g == r:
+            continue
+        differ += 1
+        rel = np.abs(ratios - g / r).min() / (g / r)
+        assert rel <= 4e-7, f"{what}: block {j}: interval {g!r} vs reference {r!r} is not on the candidate grid (off by {rel:.2e})"
+    return differ

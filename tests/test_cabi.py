@@ -28,7 +28,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version(lib):
-    assert lib.p4v_version() == 120
+    hdr = open(os.path.join(ROOT, "include", "ptq4vit_hip.h")).read()
+    assert lib.p4v_version() == int(re.search(r"#define P4V_VERSION (\d+)", hdr).group(1)) >= 130
 
 
 def test_workspace_planning_matches_shapes(lib):
@@ -82,6 +83,16 @@ def test_granular_entry_points_validate_arguments(lib):
     assert lib.p4v_conv_search_a(C.byref(c), *([one] * 10), one, 64, null) == -1
     assert b"a_bit >= 32" in lib.p4v_last_error()
     assert lib.p4v_score_argmax_gather(null, 0, 0, null, null, null, null) == -1
+    # the plane / export entry points of version 1.3 (rows a9, f-3)
+    pd = _lib.PlaneDesc(16, 16, 64, 1, 7, -128, 127, 128, 0.0, 0)                       # unknown mode
+    assert lib.p4v_pack_plane_i8(C.byref(pd), one, one, one, null) == -1 and b"unknown mode" in lib.p4v_last_error()
+    pd = _lib.PlaneDesc(16, 16, 64, 1, _lib.PLANE_SOS_HI, 0, 127, 128, 0.0, 0)
+    assert lib.p4v_pack_plane_i8(C.byref(pd), one, null, one, null) == -1 and b"split" in lib.p4v_last_error()
+    ed = _lib.ExportDesc()
+    ed.mode = 9
+    assert lib.p4v_export_quantize(C.byref(ed), one, one, null, one, null) == -1 and b"unknown mode" in lib.p4v_last_error()
+    assert lib.p4v_debug_set_variant(-1, 0) == -1 and lib.p4v_debug_set_tuning(99, 0) == -1
+    assert lib.p4v_debug_set_variant(0, 0) == 0 and lib.p4v_stats_enable(0) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

