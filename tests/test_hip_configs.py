@@ -105,28 +105,30 @@ def _run_config(model, bits, calib, oracle_matmul=None, logits_rel=0.35):
     for n, m in wrapped.items():
         mult = candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n)[:-1].astype(np.float32)
 
-        def on_grid(got, init, what):
+        def on_grid(got, init, what):            # `init`: the block abs-max (signed max for the post-GELU input)
             got = got.detach().float().cpu().numpy().reshape(-1)
             init = init.detach().float().cpu().numpy().reshape(-1)
             assert got.shape == init.shape, (n, what, got.shape, init.shape)
             assert np.isfinite(got).all() and (got > 0).all(), f"{n}.{what}"
+            init = (init / np.float32(q - 0.5)).astype(np.float32)          # IEEE division on the host (torch's GPU kernels turn
+                                                                             # tensor / python-scalar into a multiplication by 1/scalar)
             table = mult[:, None] * init[None, :]                            # fp32 multiply, as the reference builds it
             hit = (table == got[None, :]).any(axis=0)
             assert hit.all(), f"{n}.{what}: {int((~hit).sum())} of {hit.size} intervals are not entries of the candidate table"
             return got.size
         if isinstance(m, MinMaxQuantLinear):
             w = m.weight.data.view(m.n_V, m.crb_rows, m.n_H, m.crb_cols)
-            n_iv += on_grid(m.w_interval, w.abs().amax(dim=(1, 3)) / (q - 0.5), "w_interval")
+            n_iv += on_grid(m.w_interval, w.abs().amax(dim=(1, 3)), "w_interval")
             a_iv = m.a_interval[0] if isinstance(m.a_interval, (list, tuple)) else m.a_interval
-            n_iv += on_grid(a_iv, init_a[n].reshape(1) / (q - 0.5), "a_interval")
+            n_iv += on_grid(a_iv, init_a[n].reshape(1), "a_interval")
         elif isinstance(m, MinMaxQuantConv2d):
-            n_iv += on_grid(m.w_interval, m.weight.data.abs().amax(dim=(1, 2, 3)) / (q - 0.5), "w_interval")
+            n_iv += on_grid(m.w_interval, m.weight.data.abs().amax(dim=(1, 2, 3)), "w_interval")
         else:
-            n_iv += on_grid(m.B_interval, init_a[n][1] / (q - 0.5), "B_interval")
+            n_iv += on_grid(m.B_interval, init_a[n][1], "B_interval")
             if m._sos:
                 assert float(m.split) in splits and float(m.A_interval) == float(np.float32(float(m.split)) / np.float32(q - 1)), n
             else:
-                n_iv += on_grid(m.A_interval, init_a[n][0] / (q - 0.5), "A_interval")
+                n_iv += on_grid(m.A_interval, init_a[n][0], "A_interval")
     print(f"[config] {n_iv} intervals are exact entries of their candidate tables")
 
     # the oracle on the layers it finishes in seconds, same captured tensors
