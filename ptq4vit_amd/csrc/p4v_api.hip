@@ -414,6 +414,55 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     return 0;
 }
 
+// k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)
+template <bool TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds) {
+#define P4V_LAUNCH7(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep7<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep7<TWIN, E>), grid, dim3(512), lds, c.st, p);                                \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH7(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH7(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH7(EPI_ABS); break;
+        default: P4V_LAUNCH7(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH7
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep7(Ctx& c, const Sweep7Params& p, bool twin, int epi, int cgroups) {
+    if (c.dry) return 0;
+    const int nc = p.c1 - p.c0;
+    // the per-candidate tables live behind the ring: at most 160 candidates per workgroup
+    const int per_max = (int)((160 * 1024 - SW7_NS * SW7_STAGE - 1024) / 192);
+    cgroups = std::max(cgroups, cdiv(nc, per_max));
+    const int per = cdiv(nc, cgroups);
+    const size_t lds = (size_t)SW7_NS * SW7_STAGE + (size_t)per * 192 + 1024;
+    dim3 grid(p.rtiles * p.ctiles, 1, cgroups);
+    const bool timed = g_stat_on;
+    StatRec rec{};
+    if (timed) {
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        rec.kind = 3;
+        rec.macs = (double)p.rtiles * 256 * (double)p.ctiles * 256 * (double)p.ldk * nc;   // (twin: 128 samples x 2 planes)
+        rec.alg = g_alg_macs_cand * nc;
+        HIPCHK(hipEventRecord(rec.a, c.st));
+    }
+    CHK(twin ? launch_sweep7_epi<true>(c, p, epi, grid, lds) : launch_sweep7_epi<false>(c, p, epi, grid, lds));
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, c.st));
+        g_stat_recs.push_back(rec);
+    }
+    return 0;
+}
+
 int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
     const bool timed = g_stat_on;
@@ -541,9 +590,18 @@ int run_pass(Ctx& c, Pass& ps) {
     const bool regs6 = stat_ok && sweep6_supported(Kp / SW_BKB) && !(g_variant & 16);   // k_sweep6: stationary operand in registers
     const bool pairs = stat_ok && !regs6 && !(g_variant & 8);                           // k_sweep5: two candidates per pass
     const int PADR = SW_BM;
+    // k_sweep7 (large K): rows = samples, columns = output features of a plain [M][N] layer; features contiguous in
+    // raw_out / raw_grad and a multiple of 32 (dwordx4 epilogue loads, whole 32-feature blocks), every 32-feature block
+    // inside one scale / score block, exactly one operand candidate-expanded, the twin's second plane not expanded
+    const bool big7 = !stat_ok && !ps.store_out && ps.i8 && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 32768) && ps.Z == 1 &&
+                      rup(ps.K, 64) >= 1024 && rup(ps.K, 64) % 256 == 0 && (long)ps.Mrows * ps.o_ms * 4 < (1L << 32) && ps.sb_mode == 1 && (ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
+                      (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0))) &&
+                      ps.row.expanded != ps.col.expanded && !(ps.twin && (ps.row.expanded || ps.row2.expanded)) &&
+                      ps.o_bs == 0 && ps.o_nbs == 0 && ps.o_ns == 1 && ps.Ncols % 32 == 0 && ps.o_ms % 4 == 0 &&
+                      (c.dry || ((((unsigned long long)ps.O) | ((unsigned long long)(ps.G ? ps.G : ps.O))) & 15) == 0) && ps.bias_axis == 0;
     // k_sweep6 tiles the stationary operand (the one that is NOT candidate-expanded) in 256-row slabs
-    const int Mp = (int)rup(ps.Mrows, (regs6 && !ps.row.expanded) ? 256 : PADR);
-    const int Np = (int)rup(ps.Ncols, (regs6 && !ps.col.expanded) ? 256 : PADR);
+    const int Mp = (int)rup(ps.Mrows, big7 ? (ps.twin ? 128 : 256) : (regs6 && !ps.row.expanded) ? 256 : PADR);
+    const int Np = (int)rup(ps.Ncols, big7 ? 256 : (regs6 && !ps.col.expanded) ? 256 : PADR);
     const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
     const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
     const long col_plane1 = ps.col_zs_shared ? (long)Np * Kp * esz : col_plane;
@@ -577,7 +635,8 @@ int run_pass(Ctx& c, Pass& ps) {
     const int s3_gw = 32;                           // streaming rows per wave (column group width of the table)
     const int s3_slabs = (a_search ? Np : Mp) / 64, s3_groups = (a_search ? Mp : Np) / s3_gw;
     const int NpP = stat_ok ? s3_groups : fast ? Np / 32 : Np;          // columns of the partial-sum table
-    const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : (long)MT * NpP * (cosm ? 3 : 1);
+    const int MT7 = big7 ? (Mp / (ps.twin ? 128 : 256)) * 4 : 0;        // k_sweep7: one row per (sample tile, wave column)
+    const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
@@ -642,6 +701,30 @@ int run_pass(Ctx& c, Pass& ps) {
             CHK(launch_sweep4(c, q, ps.epi, cgroups, pairs));
             continue;
         }
+        if (big7) {
+            Sweep7Params q{};
+            q.r_cs = ps.col.expanded ? col_plane1 : 0;
+            q.R = colbuf - (long)c0 * q.r_cs;
+            q.c_cs = ps.row.expanded ? row_plane1 : 0;
+            q.Cp = rowbuf - (long)c0 * q.c_cs;
+            q.C2 = ps.twin ? row2buf : nullptr;
+            q.ldk = Kp; q.ktiles = Kp / SW_BKB;
+            q.S1 = S1; q.S2 = S2; q.s_cs = ps.s_cs; q.sb_div = ps.s_cs > 1 ? std::max(1, ps.sb_div) : (1 << 30);
+            q.bias = ps.bias;
+            q.O = ps.O; q.Wt = ps.G ? ps.G : ps.O; q.wt_mode = ps.wt_mode;
+            q.ldo = ps.o_ms;
+            q.M = ps.Mrows; q.N = ps.Ncols;
+            q.c0 = c0; q.c1 = c0 + nc;
+            q.part = part; q.p_cs = p_cs; q.NG = NpP;
+            q.rtiles = Np / 256; q.ctiles = Mp / (ps.twin ? 128 : 256);
+            // one workgroup per CU; per k-tile ~0.62 us (16 MFMAs per wave, two waves per SIMD), ~3 k-tiles' worth of
+            // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
+            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, 256, 6.0, 0.62);
+            if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
+            if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);
+            CHK(launch_sweep7(c, q, ps.twin, ps.epi, cg7));
+            continue;
+        }
         SweepParams sp{};
         // plane pointers are biased so that the kernel can index them with the absolute candidate id
         sp.a_cs = ps.row.expanded ? row_plane1 : 0;
@@ -692,7 +775,7 @@ int run_pass(Ctx& c, Pass& ps) {
         // (k_sweep6 skips streaming tiles that are pure padding: their table entries are never written)
         const int fin_cols = stat_ok ? (a_search ? (regs6 ? 2 * cdiv(ps.Mrows, 64) : s3_groups) : cdiv(ps.Ncols, s3_gw))
                                      : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
-        FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
+        FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : big7 ? MT7 : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
                         std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));
     } else {

@@ -1879,6 +1879,299 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sweep7: int8 candidate sweep for LARGE K (K >= 1024: fc2 of every ViT, every Linear of ViT-L / Swin stage 4)
+// ------------------------------------------------------------------------------------------
+// At K = 3072 neither operand can be stationary (k_sweep6 holds K <= 768 in registers), so both stream through the LDS.
+// What bounded k_sweep2 / k_sweep2g there (round-1 PMC, profiles/r1_pmc_fc2_v7.txt: matrix pipe 39 % busy, 47 % of the
+// wave cycles in s_waitcnt / s_barrier): a 128 x 128 tile gives every wave only 4 MFMAs (128 clk) between two barriers,
+// against 2-3 LDS-DMA issues, 6 fragment reads and the barrier itself, and moves 1 B from L2 per 64 MACs.  This kernel:
+//   * workgroup tile 256 features x 256 samples (twin: 256 x 128 samples x 2 planes), 8 waves as 2 x 4, wave tile
+//     128 x 64 (twin 128 x 32 x 2 planes): 16 MFMAs (512 clk) per wave and k-tile for 4 LDS-DMA pieces, 12 fragment reads
+//     and one barrier -- 4x the matrix work per synchronisation, half the L2 -> LDS bytes per MAC (1 B / 128 MACs) and
+//     0.75 KB of LDS reads per MFMA instead of 1.5;
+//   * the OUTPUT-CONTIGUOUS dimension (features n: raw_out / raw_grad are [sample][feature]) lies on the MFMA rows, so
+//     the four accumulator rows (r & 3) of a lane are 16 contiguous bytes of raw_out / raw_grad: the epilogue operands of a
+//     candidate -- 128 + 128 values per lane, far more than fit in registers next to 128 accumulators -- are streamed
+//     from L2 with 64 dwordx4 loads per lane and candidate (k_sweep2g: 64 scalar loads per candidate pair for a quarter
+//     of the elements).  Those loads are inline asm with counted vmcnt waits: hipcc drains vmcnt(0) for every ordinary
+//     load while an LDS-DMA is in flight, which would serialise them (cdna_hip_programming.md s5 "Three .s-level traps");
+//   * fragment reads run half a k-tile ahead (two fragment sets of 6), LDS-DMA pieces are issued one at a time between
+//     the MFMAs (a burst behind the barrier stalls the fragment reads), 4-stage ring as in k_sweep2;
+//   * per candidate ONE float per wave and 32-feature block, kept in LDS, written once at the end (k_finish unchanged).
+// Workgroup order: feature tile fastest, then sample tile, candidate group slowest -- the 2-12 workgroups that share a
+// tile of the candidate-expanded operand are neighbours on one XCD and pull it through that L2 once.
+struct Sweep7Params {
+    const void* R;  long r_cs;          // feature-side plane(s) [C or 1][Np][ldk] (weights): rows -> MFMA rows
+    const void* Cp; long c_cs;          // sample-side plane(s)  [C or 1][Mp][ldk] (activations): rows -> MFMA columns
+    const void* C2;                     // twin: second sample-side plane (never candidate-expanded)
+    int ldk, ktiles;
+    const float* S1; const float* S2;   // [candidate][s_cs] scale of plane 1 / 2
+    int s_cs, sb_div;                   // scale block of feature n = min(n / sb_div, s_cs - 1)
+    const float* bias;                  // per feature, or NULL
+    const float* O; const float* Wt; int wt_mode;   // raw_out, metric weight tensor (= O when the metric has none)
+    long ldo;                           // elements between two samples of O / Wt (features are contiguous)
+    int M, N;                           // valid samples / features (N % 32 == 0)
+    int c0, c1;
+    float* part; long p_cs; int NG;     // part[c * p_cs + (ct * 4 + wc) * NG + rt * 8 + wr * 4 + j]
+    int rtiles, ctiles;
+};
+
+static constexpr int SW7_NS = 4;
+static constexpr int SW7_REGION = 256 * 64;       // one operand side of a k-tile: 256 rows x 64 B
+static constexpr int SW7_STAGE = 2 * SW7_REGION;
+
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = reinterpret_cast<float*>(smem + SW7_NS * SW7_STAGE);   // [per][8 waves][4 feature blocks]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;               // wave grid: 2 (features) x 4 (samples)
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.rtiles * p.ctiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int rt = t % p.rtiles, ct = t / p.rtiles;
+    constexpr int CM = TWIN ? 128 : 256;                 // samples per workgroup tile
+    const int r0 = rt * 256, m0 = ct * CM;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo;
+
+    // ---- tables behind the ring: scales per (candidate, 32-feature block), bias of the tile's features -------------
+    float* s1tab = res + per * 32;
+    float* s2tab = s1tab + per * 8;
+    float* btab = s2tab + per * 8;
+    for (int i = tid; i < ncand * 8; i += 512) {
+        const int cc = c_lo + (i >> 3);
+        const int sb = min((r0 + (i & 7) * 32) / p.sb_div, p.s_cs - 1);
+        s1tab[i] = p.S1 ? p.S1[cc * p.s_cs + sb] : 1.0f;
+        if (TWIN) s2tab[i] = p.S2 ? p.S2[cc * p.s_cs + sb] : 1.0f;
+    }
+    if (tid < 256) btab[tid] = (p.bias && r0 + tid < p.N) ? p.bias[r0 + tid] : 0.0f;
+    __syncthreads();                                     // (no LDS-DMA in flight yet: a plain barrier)
+
+    // ---- LDS-DMA: wave w fills rows [32 w, 32 w + 32) of both regions, two 16-row pieces each ------------------------
+    const int ld_row = lane >> 2;
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);          // logical 16-B chunk landing in physical slot lane & 3
+    const unsigned voff0 = (unsigned)(ld_row * p.ldk + ld_chunk * 16);
+    const unsigned voff1 = voff0 + 16u * (unsigned)p.ldk;
+    const char* curR = (const char*)p.R + (long)(r0 + wid * 32) * p.ldk + (long)c_lo * p.r_cs;
+    const char* cbase = (TWIN && wid >= 4) ? (const char*)p.C2 : (const char*)p.Cp;
+    const char* curC = cbase + (long)(m0 + (TWIN ? (wid & 3) * 32 : wid * 32)) * p.ldk + (TWIN ? 0L : (long)c_lo * p.c_cs);
+    const int ktiles = p.ktiles;
+    const long wrapR = p.r_cs - (long)ktiles * SW_BKB, wrapC = (TWIN ? 0L : p.c_cs) - (long)ktiles * SW_BKB;
+    const int total = ncand * ktiles;
+    int ikt = 0;
+    const int lds_w = wid * 2048;
+    auto piece = [&](int stage, auto k_c) __attribute__((always_inline)) {   // k = 0, 1: feature side; 2, 3: sample side
+        constexpr int k = decltype(k_c)::value;
+        char* s = smem + stage * SW7_STAGE + lds_w + (k >> 1) * SW7_REGION + (k & 1) * 1024;
+        glds16((k >> 1 ? curC : curR) + ((k & 1) ? voff1 : voff0), s);
+        if constexpr (k == 3) {
+            curR += SW_BKB; curC += SW_BKB;
+            if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
+        }
+    };
+    auto issue_all = [&](int stage) __attribute__((always_inline)) {
+        piece(stage, std::integral_constant<int, 0>{}); piece(stage, std::integral_constant<int, 1>{});
+        piece(stage, std::integral_constant<int, 2>{}); piece(stage, std::integral_constant<int, 3>{});
+    };
+
+    v16i acc[4][2];                                      // [32-feature block j][sample block q (twin: plane q)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][q][r] = 0;
+
+    // ---- fragment addresses: row R, logical chunk c -> physical chunk c ^ ((R >> 2) & 3); stages 2, 3 lie beyond the
+    // 16-bit offset field of ds_read, hence a second set of bases -----------------------------------------------------
+    const int sw = (l31 >> 2) & 3;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned aR0 = lds0 + (wr * 128 + l31) * 64 + ((g ^ sw) << 4), aR1 = lds0 + (wr * 128 + l31) * 64 + (((2 + g) ^ sw) << 4);
+    const unsigned crow = (TWIN ? wc * 32 : wc * 64) + l31;
+    const unsigned aC0 = lds0 + SW7_REGION + crow * 64 + ((g ^ sw) << 4), aC1 = lds0 + SW7_REGION + crow * 64 + (((2 + g) ^ sw) << 4);
+    const unsigned aR0h = aR0 + 2 * SW7_STAGE, aR1h = aR1 + 2 * SW7_STAGE, aC0h = aC0 + 2 * SW7_STAGE, aC1h = aC1 + 2 * SW7_STAGE;
+    constexpr int QOFF = TWIN ? 128 * 64 : 32 * 64;      // second sample block: the other plane / the next 32 samples
+
+#define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    struct Fr { v4i r[4], c[2]; };
+    auto read_half = [&](Fr& f, auto stage_c, auto half_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value, H = decltype(half_c)::value;
+        constexpr int SO = (ST & 1) * SW7_STAGE;
+        const unsigned bR = (ST >> 1) ? (H ? aR1h : aR0h) : (H ? aR1 : aR0);
+        const unsigned bC = (ST >> 1) ? (H ? aC1h : aC0h) : (H ? aC1 : aC0);
+        P4V_DSR(f.c[0], bC, SO); P4V_DSR(f.r[0], bR, SO); P4V_DSR(f.r[1], bR, SO + 2048);
+        P4V_DSR(f.c[1], bC, SO + QOFF); P4V_DSR(f.r[2], bR, SO + 4096); P4V_DSR(f.r[3], bR, SO + 6144);
+    };
+    auto fence = [&](Fr& f) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.c[0]), "+v"(f.c[1]) :: "memory");
+    };
+    // 8 MFMAs of one k-half; `stage` >= 0: two LDS-DMA pieces (k0, k0 + 1) of the tile being streamed in ride between them
+    auto mma_half = [&](const Fr& f, int stage, auto k0_c) __attribute__((always_inline)) {
+        constexpr int k0 = decltype(k0_c)::value;
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[0], f.c[0], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[1], f.c[0], acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[0], f.c[1], acc[0][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x6);
+        if (stage >= 0) piece(stage, std::integral_constant<int, k0>{});
+        __builtin_amdgcn_sched_barrier(0x6);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[1], f.c[1], acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[2], f.c[0], acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[2], f.c[1], acc[2][1], 0, 0, 0);
+        acc[3][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[3], f.c[0], acc[3][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x6);
+        if (stage >= 0) piece(stage, std::integral_constant<int, k0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0x6);
+        acc[3][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[3], f.c[1], acc[3][1], 0, 0, 0);
+    };
+
+    // ---- epilogue of one candidate ------------------------------------------------------------------------------------
+    // Element (j, q, r) of a lane: feature n = r0 + wr*128 + j*32 + (r&3) + 8*(r>>2) + 4*g, sample m = m0 + crow (+ q*32).
+    // N % 32 == 0 (host): a 32-feature block is valid or padding as a whole; padding blocks / samples read a valid address
+    // and are masked.  Lane base pointers: sample row (clamped) + 4*g features.
+    const bool hess = p.wt_mode == 1;                    // EPI_SQ_W: weight = raw_grad (hessian) or raw_out (square-weighted L2)
+    constexpr int NQ = TWIN ? 1 : 2;                     // sample blocks with their own epilogue elements
+    // byte offset of (sample row, 4*g features) in raw_out / raw_grad, < 4 GB (checked by the host); sample block 1 only
+    // exists without the twin
+    const int ms0 = m0 + (int)crow, ms1 = ms0 + 32;
+    const bool m_ok0 = ms0 < p.M, m_ok1 = ms1 < p.M;
+    const unsigned lane_boff0 = (unsigned)(((long)min(ms0, p.M - 1) * p.ldo + 4 * g) * 4);
+    const unsigned lane_boff1 = (unsigned)(((long)min(ms1, p.M - 1) * p.ldo + 4 * g) * 4);
+    // A sub-block = 8 of a lane's 16 elements of one 32 x 32 block (row quads rq = 2 h2, 2 h2 + 1): 2 + 2 dwordx4 loads.
+    // Loads run two sub-blocks ahead of the arithmetic through a ring of three register sets (48 VGPRs: next to 128
+    // accumulators and the prefetched fragments there is no room for more); wave-uniform base (SGPR pair) + per-lane
+    // 32-bit offset, so no vector address arithmetic at all.
+    struct Hb { v4f u[2], w[2]; };
+#define P4V_GLD(dst, voff, sbase, off) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off) : "memory")
+    constexpr int NSB = 8 * NQ;                          // sub-blocks per candidate
+    auto load_sb = [&](Hb& b, auto sb_c) __attribute__((always_inline)) {
+        constexpr int sb = decltype(sb_c)::value;
+        constexpr int j = sb / (2 * NQ), q = (sb / 2) % NQ, h2 = sb % 2;
+        const int nb = r0 + wr * 128 + j * 32;
+        const int fo = (nb < p.N ? nb : 0) + h2 * 16;
+        const float* su = p.O + fo;
+        const float* sw_ = p.Wt + fo;
+        const unsigned vo = q == 0 ? lane_boff0 : lane_boff1;
+        P4V_GLD(b.u[0], vo, su, 0); P4V_GLD(b.w[0], vo, sw_, 0);
+        P4V_GLD(b.u[1], vo, su, 32); P4V_GLD(b.w[1], vo, sw_, 32);
+    };
+    auto epilogue = [&](int ci) __attribute__((always_inline)) {
+        const v4f s1v = *reinterpret_cast<const v4f*>(s1tab + ci * 8 + wr * 4);
+        v4f s2v = {0.f, 0.f, 0.f, 0.f};
+        if (TWIN) s2v = *reinterpret_cast<const v4f*>(s2tab + ci * 8 + wr * 4);
+        float sumj[4] = {0.f, 0.f, 0.f, 0.f};
+        Hb hb[3];
+        load_sb(hb[0], std::integral_constant<int, 0>{});
+        load_sb(hb[1], std::integral_constant<int, 1>{});
+        auto do_sb = [&](auto sb_c) __attribute__((always_inline)) {
+            constexpr int sb = decltype(sb_c)::value;
+            constexpr int j = sb / (2 * NQ), q = (sb / 2) % NQ, h2 = sb % 2;
+            Hb& cur = hb[sb % 3];
+            if constexpr (sb + 2 < NSB) load_sb(hb[(sb + 2) % 3], std::integral_constant<int, sb + 2>{});
+            constexpr int younger = (sb + 2 < NSB) ? 8 : (sb + 1 < NSB) ? 4 : 0;      // loads issued after this sub-block's
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.u[0]), "+v"(cur.u[1]), "+v"(cur.w[0]), "+v"(cur.w[1]) : "n"(younger) : "memory");
+            const bool blk_ok = (r0 + wr * 128 + j * 32 < p.N) && (q == 0 ? m_ok0 : m_ok1);
+            const float s1 = s1v[j], s2 = s2v[j];
+            // 8 elements -> one partial sum; padding (whole 32-feature blocks, samples >= M: their accumulators are 0 and
+            // their loads hit clamped, valid addresses) is masked once per sub-block, not per element
+            float ps = 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int rq = 2 * h2 + rr;
+                const v4f bv = *reinterpret_cast<const v4f*>(btab + wr * 128 + j * 32 + 8 * rq + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    const float o = cur.u[rr][e];
+                    float d = (o - bv[e]) - (float)acc[j][TWIN ? 0 : q][r] * s1;
+                    if (TWIN) d -= (float)acc[j][1][r] * s2;
+                    if (EPI == EPI_SQ_W) { const float tt = (hess ? cur.w[rr][e] : o) * d; ps = fmaf(tt, tt, ps); }   // hessian: raw_grad; square-weighted: raw_out
+                    else if (EPI == EPI_SQ) ps = fmaf(d, d, ps);
+                    else if (EPI == EPI_ABS) ps += fabsf(d);
+                    else ps = fmaf(fabsf(o) * d, d, ps);                                                             // linear-weighted: |raw_out|
+                }
+            }
+            float sum = sumj[j] + (blk_ok ? ps : 0.0f);
+            // pin the arithmetic of this sub-block HERE: nothing orders it against the asm statements, so the instruction
+            // selector sinks it towards its only use at the end of the epilogue -- every loaded value of the candidate live
+            // at once, 800 B of scratch per lane.  An empty volatile asm that consumes `sum` is chained to the loads.
+            asm volatile("" : "+v"(sum));
+            sumj[j] = sum;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... SB>(std::integer_sequence<int, SB...>) __attribute__((always_inline)) {
+            (do_sb(std::integral_constant<int, SB>{}), ...);
+        }(std::make_integer_sequence<int, NSB>{});
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = wave_sum_dpp(sumj[j]);       // fixed order: deterministic
+            if (lane == 63) res[(ci * 8 + wid) * 4 + j] = s;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][q][r] = 0;
+        }
+    };
+
+    // ---- main loop: flat over (candidate, k-tile); a step = one k-tile = two k-halves -------------------------------
+    const int npre = min(SW7_NS - 1, total);
+    for (int i = 0; i < npre; ++i) issue_all(i);
+    Fr fa, fb;
+    // step `it` (compile-time stage): fa holds k-half 0 of tile it.  Prove tile it+1 landed (own pieces waited for, then
+    // the barrier); the stage of tile it-1 is free for tile it+3; read k-half 1 of tile it, MFMAs of half 0; read k-half
+    // 0 of tile it+1, MFMAs of half 1.
+    // ktiles % 4 == 0 (host): tile `it` always sits in stage it % 4 = k-tile % 4, so the candidate loop stays rolled
+    // and the epilogue exists once in the code.
+    auto step = [&](int it, auto stage_c, bool prefetch) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        if (it + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int fill = (it + SW7_NS - 1 < total) ? (ST + SW7_NS - 1) % SW7_NS : -1;
+        read_half(fb, stage_c, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));               // fa complete; the 6 reads just issued stay in flight
+        fence(fa);
+        mma_half(fa, fill, std::integral_constant<int, 0>{});
+        // the first half of the next tile is prefetched under the MFMAs of this half -- except across a candidate
+        // boundary: the epilogue needs the registers
+        if (prefetch) {
+            read_half(fa, std::integral_constant<int, (ST + 1) % SW7_NS>{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        fence(fb);
+        mma_half(fb, fill, std::integral_constant<int, 2>{});
+    };
+    if (total > 2) wait_vmcnt<8>(); else if (total > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_half(fa, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    int it = 0;
+    for (int ci = 0; ci < ncand; ++ci) {
+        for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
+            step(it, std::integral_constant<int, 0>{}, true);
+            step(it + 1, std::integral_constant<int, 1>{}, true);
+            step(it + 2, std::integral_constant<int, 2>{}, true);
+            step(it + 3, std::integral_constant<int, 3>{}, kq + 4 < ktiles);
+        }
+        epilogue(ci);
+        if (ci + 1 < ncand) read_half(fa, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
+#undef P4V_DSR
+#undef P4V_GLD
+    __syncthreads();
+    // ---- one coalesced write of this workgroup's results ---------------------------------------------------------------
+    for (int i = tid; i < ncand * 32; i += 512) {
+        const int cc = c_lo + (i >> 5), wv = (i >> 2) & 7, j = i & 3;
+        p.part[(long)cc * p.p_cs + (long)(ct * 4 + (wv & 3)) * p.NG + rt * 8 + (wv >> 2) * 4 + j] = res[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_finish / k_select
 // ------------------------------------------------------------------------------------------
 struct FinishParams {

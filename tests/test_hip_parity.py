@@ -171,6 +171,16 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=2, T=70, K=1088, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True, eq_n=37),
     dict(b=2, T=70, K=1024, N=256, n_V=2, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=False, eq_n=51),
     dict(b=2, T=197, K=3072, N=768, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),          # ViT-B fc2 at 2 images
+    # k_sweep7 (K >= 1024, K % 256 == 0, N % 32 == 0): ragged feature tiles (N = 320: 1.25 tiles of 256) and sample tiles,
+    # every epilogue flavour, plain and twin, V blocks, tiny / odd candidate sets
+    dict(b=3, T=131, K=2048, N=320, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False),
+    dict(b=3, T=131, K=1024, N=320, n_V=5, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
+    dict(b=3, T=131, K=1024, N=288, n_V=3, w_bit=6, a_bit=6, metric="L1_norm", postgelu=True),
+    dict(b=2, T=150, K=1536, N=384, n_V=1, w_bit=8, a_bit=8, metric="linear_weighted_L2_norm", postgelu=True),   # ViT-S fc2 geometry
+    dict(b=2, T=150, K=1024, N=256, n_V=2, w_bit=8, a_bit=8, metric="square_weighted_L2_norm", postgelu=False),
+    dict(b=2, T=150, K=1024, N=64, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True, eq_n=37),
+    dict(b=1, T=300, K=4096, N=96, n_V=3, w_bit=8, a_bit=8, metric="hessian", postgelu=False, eq_n=1),
+    dict(b=1, T=257, K=1024, N=1024, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=False, eq_n=9),       # 4 feature tiles
 ], ids=lambda c: f"{c['metric']}-w{c['w_bit']}-{'gelu' if c['postgelu'] else 'plain'}-K{c['K']}-N{c['N']}-nV{c['n_V']}")
 def test_linear_multitile_vs_oracle(eng, cfg):
     from oracle.ptq4vit_oracle import LinearOracle
@@ -342,3 +352,23 @@ def test_pass_memo_is_exact_with_column_blocks_and_activation_groups(eng):
     off = eng.linear_calibrate(**args, **hp, memoize=False)
     torch.cuda.synchronize()
     assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
+
+
+def test_large_k_sweep_matches_the_128_tile_sweeps(eng):
+    """A/B at ViT-B fc2 geometry (8 images): k_sweep7 (256 x 256 tiles, streamed epilogue operands) against k_sweep2 /
+    k_sweep2g (variant 32768) -- same selections, score tables equal to fp32 summation-order noise."""
+    w, bias, x, out, grad = _mk_linear(17, 8, 197, 3072, 768, postgelu=True, gscale=1e-3)
+    hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, n_V=1, n_H=1, n_a=1)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), want_scores=True, postgelu=True)
+    new = eng.linear_calibrate(**args, **hp)
+    again = eng.linear_calibrate(**args, **hp)
+    eng.debug_variant(32768)
+    try:
+        old = eng.linear_calibrate(**args, **hp)
+    finally:
+        eng.debug_variant(0)
+    torch.cuda.synchronize()
+    for a, b in zip(new, again):
+        assert torch.equal(a, b), "k_sweep7 is not run-to-run deterministic"
+    assert_scores_close(new[2].cpu().numpy(), old[2].cpu().numpy(), rtol=2e-5, what="k_sweep7 vs k_sweep2")
+    assert torch.equal(new[3], old[3]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
