@@ -440,10 +440,10 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, bool twin, int epi, int cgroups
     if (c.dry) return 0;
     const int nc = p.c1 - p.c0;
     // the per-candidate tables live behind the ring: at most 160 candidates per workgroup
-    const int per_max = (int)((160 * 1024 - SW7_NS * SW7_STAGE - 1024) / 192);
+    const int per_max = (int)((160 * 1024 - SW7_NS * SW7_STAGE - 256) / 192);
     cgroups = std::max(cgroups, cdiv(nc, per_max));
     const int per = cdiv(nc, cgroups);
-    const size_t lds = (size_t)SW7_NS * SW7_STAGE + (size_t)per * 192 + 1024;
+    const size_t lds = (size_t)SW7_NS * SW7_STAGE + (size_t)per * 192 + 256;
     dim3 grid(p.rtiles * p.ctiles, 1, cgroups);
     const bool timed = g_stat_on;
     StatRec rec{};
@@ -643,7 +643,15 @@ int run_pass(Ctx& c, Pass& ps) {
     float* S2 = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
     float* scores = c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
     float* zero_bias = (stat_ok && !ps.bias) ? c.ws.get<float>((size_t)std::max(Mp, Np)) : nullptr;
+    float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    if (big7 && !c.dry) {
+        PrepEpiParams pe{ps.O, ps.G ? ps.G : ps.O, ps.bias, ps.o_ms, ps.Mrows, ps.Ncols, ps.wt_mode,
+                         Np / 256, Mp / (ps.twin ? 128 : 256), ps.twin ? 1 : 0, epi7};
+        const long chunks = (long)Mp * Np * 2 / 4;
+        hipLaunchKernelGGL(k_prep_epi, dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 16)), dim3(256), 0, c.st, pe);
+        HIPCHK(hipGetLastError());
+    }
 
     if (zero_bias && !c.dry) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
     if (ps.use_s1) {
@@ -710,10 +718,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.C2 = ps.twin ? row2buf : nullptr;
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.S2 = S2; q.s_cs = ps.s_cs; q.sb_div = ps.s_cs > 1 ? std::max(1, ps.sb_div) : (1 << 30);
-            q.bias = ps.bias;
-            q.O = ps.O; q.Wt = ps.G ? ps.G : ps.O; q.wt_mode = ps.wt_mode;
-            q.ldo = ps.o_ms;
-            q.M = ps.Mrows; q.N = ps.Ncols;
+            q.E = epi7;
             q.c0 = c0; q.c1 = c0 + nc;
             q.part = part; q.p_cs = p_cs; q.NG = NpP;
             q.rtiles = Np / 256; q.ctiles = Mp / (ps.twin ? 128 : 256);

@@ -1883,42 +1883,88 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
 // ------------------------------------------------------------------------------------------
 // At K = 3072 neither operand can be stationary (k_sweep6 holds K <= 768 in registers), so both stream through the LDS.
 // What bounded k_sweep2 / k_sweep2g there (round-1 PMC, profiles/r1_pmc_fc2_v7.txt: matrix pipe 39 % busy, 47 % of the
-// wave cycles in s_waitcnt / s_barrier): a 128 x 128 tile gives every wave only 4 MFMAs (128 clk) between two barriers,
-// against 2-3 LDS-DMA issues, 6 fragment reads and the barrier itself, and moves 1 B from L2 per 64 MACs.  This kernel:
+// wave cycles in s_waitcnt / s_barrier; round-2 ablations, profiles/r2_sweep7_ablation.txt): with 128 x 128 tiles a wave
+// has 4 MFMAs (128 clk) per k-tile against 2-3 LDS-DMA issues (60-180 clk EACH, MI355X_MICROARCH.md), 6 fragment reads and
+// a barrier, and the two waves of a SIMD run these phases in lock step -- matrix time, DMA issue time and epilogue time
+// ADD UP instead of overlapping.  This kernel:
 //   * workgroup tile 256 features x 256 samples (twin: 256 x 128 samples x 2 planes), 8 waves as 2 x 4, wave tile
-//     128 x 64 (twin 128 x 32 x 2 planes): 16 MFMAs (512 clk) per wave and k-tile for 4 LDS-DMA pieces, 12 fragment reads
-//     and one barrier -- 4x the matrix work per synchronisation, half the L2 -> LDS bytes per MAC (1 B / 128 MACs) and
-//     0.75 KB of LDS reads per MFMA instead of 1.5;
-//   * the OUTPUT-CONTIGUOUS dimension (features n: raw_out / raw_grad are [sample][feature]) lies on the MFMA rows, so
-//     the four accumulator rows (r & 3) of a lane are 16 contiguous bytes of raw_out / raw_grad: the epilogue operands of a
-//     candidate -- 128 + 128 values per lane, far more than fit in registers next to 128 accumulators -- are streamed
-//     from L2 with 64 dwordx4 loads per lane and candidate (k_sweep2g: 64 scalar loads per candidate pair for a quarter
-//     of the elements).  Those loads are inline asm with counted vmcnt waits: hipcc drains vmcnt(0) for every ordinary
-//     load while an LDS-DMA is in flight, which would serialise them (cdna_hip_programming.md s5 "Three .s-level traps");
-//   * fragment reads run half a k-tile ahead (two fragment sets of 6), LDS-DMA pieces are issued one at a time between
-//     the MFMAs (a burst behind the barrier stalls the fragment reads), 4-stage ring as in k_sweep2;
+//     128 x 64 (twin 128 x 32 x 2 planes): 16 MFMAs (512 clk) per wave and k-tile for 4 LDS-DMA pieces and 12 fragment
+//     reads; half the L2 -> LDS bytes per MAC of k_sweep2 (1 B / 128 MACs);
+//   * PING-PONG: the two waves of a SIMD (waves w and w + 4 = the two feature halves of the tile) alternate roles with two
+//     barriers per k-tile -- while group A issues the 16 MFMAs of k-tile t from registers, group B issues its LDS-DMA pieces
+//     for tile t + 3 and reads its 12 fragments of tile t; then they swap.  Every instruction that is not an MFMA runs in
+//     the shadow of the partner's MFMAs (the "compute segment / load segment" pairing of MI355X_MICROARCH.md, "Two waves
+//     per SIMD"); 4-stage LDS ring, counted vmcnt, raw s_barrier;
+//   * the epilogue operands of a candidate -- raw_out - bias and the metric weight, 128 + 128 values per lane, far more
+//     than fit in registers next to 128 accumulators -- are PRE-PACKED once per pass in fragment order (k_prep_epi: what
+//     k_pack is for the MFMA operands), so that every dwordx4 load of the epilogue is 1 KB contiguous per wave (read in
+//     place from [sample][feature] memory the same load touches 32 cache lines: 26 % of the kernel, measured) and bias,
+//     validity masks and the weight choice of the metric are gone from the inner loop.  The loads are inline asm with
+//     counted vmcnt (hipcc drains vmcnt(0) for every ordinary load while an LDS-DMA is in flight) and run two sub-blocks
+//     ahead of the arithmetic through a ring of three register sets;
 //   * per candidate ONE float per wave and 32-feature block, kept in LDS, written once at the end (k_finish unchanged).
-// Workgroup order: feature tile fastest, then sample tile, candidate group slowest -- the 2-12 workgroups that share a
-// tile of the candidate-expanded operand are neighbours on one XCD and pull it through that L2 once.
+// Workgroup order: feature tile fastest, then sample tile, candidate group slowest -- the workgroups that share a tile
+// of the candidate-expanded operand are neighbours on one XCD and pull it through that L2 once.
 struct Sweep7Params {
     const void* R;  long r_cs;          // feature-side plane(s) [C or 1][Np][ldk] (weights): rows -> MFMA rows
     const void* Cp; long c_cs;          // sample-side plane(s)  [C or 1][Mp][ldk] (activations): rows -> MFMA columns
     const void* C2;                     // twin: second sample-side plane (never candidate-expanded)
-    int ldk, ktiles;
+    int ldk, ktiles;                    // ktiles % 4 == 0
     const float* S1; const float* S2;   // [candidate][s_cs] scale of plane 1 / 2
     int s_cs, sb_div;                   // scale block of feature n = min(n / sb_div, s_cs - 1)
-    const float* bias;                  // per feature, or NULL
-    const float* O; const float* Wt; int wt_mode;   // raw_out, metric weight tensor (= O when the metric has none)
-    long ldo;                           // elements between two samples of O / Wt (features are contiguous)
-    int M, N;                           // valid samples / features (N % 32 == 0)
+    const float* E;                     // pre-packed epilogue operands (k_prep_epi)
     int c0, c1;
     float* part; long p_cs; int NG;     // part[c * p_cs + (ct * 4 + wc) * NG + rt * 8 + wr * 4 + j]
     int rtiles, ctiles;
 };
 
+// timing-only ablation builds (never in production): -DP4V_SW7_DBG=1 no operand stream, 2 no MFMA, 4 no epilogue (bits add)
+#ifndef P4V_SW7_DBG
+#define P4V_SW7_DBG 0
+#endif
 static constexpr int SW7_NS = 4;
 static constexpr int SW7_REGION = 256 * 64;       // one operand side of a k-tile: 256 rows x 64 B
 static constexpr int SW7_STAGE = 2 * SW7_REGION;
+
+// Epilogue operands in fragment order.  For workgroup tile (ct, rt), wave w = wr * 4 + wc, sub-block sb and k = 0..3:
+// chunk ((tile * 8 + w) * NSB + sb) * 4 + k holds, for each of the 64 lanes, the four values of accumulator rows
+// rq * 4 .. rq * 4 + 3 (rq = 2 h2 + (k >> 1)) of block (j, q): k even = raw_out - bias, k odd = the metric weight
+// (raw_grad | raw_out | |raw_out| | 1); zero where the feature or the sample is padding.  NSB = 8 (twin) / 16 sub-blocks:
+// sb = (j * NQ + q) * 2 + h2.
+struct PrepEpiParams {
+    const float* O; const float* G; const float* bias;
+    long ldo; int M, N, wt_mode;
+    int rtiles, ctiles, twin;
+    float* E;
+};
+__global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) {
+    const int NQ = p.twin ? 1 : 2, NSB = 8 * NQ;
+    const long total = (long)p.rtiles * p.ctiles * 8 * NSB * 4 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), k = (int)((i >> 6) & 3);
+        long rest = i >> 8;
+        const int sb = (int)(rest % NSB); rest /= NSB;
+        const int w = (int)(rest & 7); rest >>= 3;
+        const int rt = (int)(rest % p.rtiles), ct = (int)(rest / p.rtiles);
+        const int h2 = sb & 1, q = (sb >> 1) % NQ, j = (sb >> 1) / NQ;
+        const int wr = w >> 2, wc = w & 3, g = lane >> 5, l31 = lane & 31;
+        const int rq = 2 * h2 + (k >> 1);
+        const int n = rt * 256 + wr * 128 + j * 32 + 8 * rq + 4 * g;
+        const int m = ct * (p.twin ? 128 : 256) + (p.twin ? wc * 32 : wc * 64 + q * 32) + l31;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N && m < p.M) {                        // N % 4 == 0: the four features are valid together
+            const v4f o = *reinterpret_cast<const v4f*>(p.O + (long)m * p.ldo + n);
+            if (!(k & 1)) {
+                v = o;
+                if (p.bias) { const v4f b = *reinterpret_cast<const v4f*>(p.bias + n); v = o - b; }
+            } else if (p.wt_mode == 1) v = *reinterpret_cast<const v4f*>(p.G + (long)m * p.ldo + n);
+            else if (p.wt_mode == 2) v = o;
+            else if (p.wt_mode == 3) v = v4f{fabsf(o[0]), fabsf(o[1]), fabsf(o[2]), fabsf(o[3])};
+            else v = v4f{1.f, 1.f, 1.f, 1.f};
+        }
+        reinterpret_cast<v4f*>(p.E)[i] = v;
+    }
+}
 
 template <bool TWIN, int EPI>
 __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
@@ -1927,7 +1973,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;               // wave grid: 2 (features) x 4 (samples)
+    const int wr = wid >> 2, wc = wid & 3;               // wave grid: 2 (features; = ping-pong group) x 4 (samples)
     const int g = lane >> 5, l31 = lane & 31;
 
     const int nwg = p.rtiles * p.ctiles;
@@ -1940,17 +1986,15 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
-    // ---- tables behind the ring: scales per (candidate, 32-feature block), bias of the tile's features -------------
+    // ---- tables behind the ring: scales per (candidate, 32-feature block) ---------------------------------------------
     float* s1tab = res + per * 32;
     float* s2tab = s1tab + per * 8;
-    float* btab = s2tab + per * 8;
     for (int i = tid; i < ncand * 8; i += 512) {
         const int cc = c_lo + (i >> 3);
         const int sb = min((r0 + (i & 7) * 32) / p.sb_div, p.s_cs - 1);
         s1tab[i] = p.S1 ? p.S1[cc * p.s_cs + sb] : 1.0f;
         if (TWIN) s2tab[i] = p.S2 ? p.S2[cc * p.s_cs + sb] : 1.0f;
     }
-    if (tid < 256) btab[tid] = (p.bias && r0 + tid < p.N) ? p.bias[r0 + tid] : 0.0f;
     __syncthreads();                                     // (no LDS-DMA in flight yet: a plain barrier)
 
     // ---- LDS-DMA: wave w fills rows [32 w, 32 w + 32) of both regions, two 16-row pieces each ------------------------
@@ -1966,18 +2010,17 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     const int total = ncand * ktiles;
     int ikt = 0;
     const int lds_w = wid * 2048;
-    auto piece = [&](int stage, auto k_c) __attribute__((always_inline)) {   // k = 0, 1: feature side; 2, 3: sample side
-        constexpr int k = decltype(k_c)::value;
-        char* s = smem + stage * SW7_STAGE + lds_w + (k >> 1) * SW7_REGION + (k & 1) * 1024;
-        glds16((k >> 1 ? curC : curR) + ((k & 1) ? voff1 : voff0), s);
-        if constexpr (k == 3) {
-            curR += SW_BKB; curC += SW_BKB;
-            if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
+    auto issue = [&](auto stage_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        char* s = smem + ST * SW7_STAGE + lds_w;
+        if constexpr (!(P4V_SW7_DBG & 1)) {
+            glds16(curR + voff0, s);
+            glds16(curR + voff1, s + 1024);
+            glds16(curC + voff0, s + SW7_REGION);
+            glds16(curC + voff1, s + SW7_REGION + 1024);
         }
-    };
-    auto issue_all = [&](int stage) __attribute__((always_inline)) {
-        piece(stage, std::integral_constant<int, 0>{}); piece(stage, std::integral_constant<int, 1>{});
-        piece(stage, std::integral_constant<int, 2>{}); piece(stage, std::integral_constant<int, 3>{});
+        curR += SW_BKB; curC += SW_BKB;
+        if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
     };
 
     v16i acc[4][2];                                      // [32-feature block j][sample block q (twin: plane q)]
@@ -1999,67 +2042,61 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     constexpr int QOFF = TWIN ? 128 * 64 : 32 * 64;      // second sample block: the other plane / the next 32 samples
 
 #define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    struct Fr { v4i r[4], c[2]; };
-    auto read_half = [&](Fr& f, auto stage_c, auto half_c) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_c)::value, H = decltype(half_c)::value;
+    struct Fr { v4i r[2][4], c[2][2]; };                 // [k-half][block]: the 12 fragments of one k-tile
+    Fr f;
+    auto read_tile_ = [&](Fr& f, auto stage_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
         constexpr int SO = (ST & 1) * SW7_STAGE;
-        const unsigned bR = (ST >> 1) ? (H ? aR1h : aR0h) : (H ? aR1 : aR0);
-        const unsigned bC = (ST >> 1) ? (H ? aC1h : aC0h) : (H ? aC1 : aC0);
-        P4V_DSR(f.c[0], bC, SO); P4V_DSR(f.r[0], bR, SO); P4V_DSR(f.r[1], bR, SO + 2048);
-        P4V_DSR(f.c[1], bC, SO + QOFF); P4V_DSR(f.r[2], bR, SO + 4096); P4V_DSR(f.r[3], bR, SO + 6144);
+        const unsigned bR0 = (ST >> 1) ? aR0h : aR0, bR1 = (ST >> 1) ? aR1h : aR1;
+        const unsigned bC0 = (ST >> 1) ? aC0h : aC0, bC1 = (ST >> 1) ? aC1h : aC1;
+        P4V_DSR(f.c[0][0], bC0, SO); P4V_DSR(f.r[0][0], bR0, SO); P4V_DSR(f.r[0][1], bR0, SO + 2048);
+        P4V_DSR(f.c[0][1], bC0, SO + QOFF); P4V_DSR(f.r[0][2], bR0, SO + 4096); P4V_DSR(f.r[0][3], bR0, SO + 6144);
+        P4V_DSR(f.c[1][0], bC1, SO); P4V_DSR(f.r[1][0], bR1, SO); P4V_DSR(f.r[1][1], bR1, SO + 2048);
+        P4V_DSR(f.c[1][1], bC1, SO + QOFF); P4V_DSR(f.r[1][2], bR1, SO + 4096); P4V_DSR(f.r[1][3], bR1, SO + 6144);
     };
-    auto fence = [&](Fr& f) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.c[0]), "+v"(f.c[1]) :: "memory");
+    auto read_tile = [&](auto stage_c) __attribute__((always_inline)) { read_tile_(f, stage_c); };
+    // all 12 fragments have landed, and no MFMA below is scheduled above this point
+    auto frags_ready = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.c[0][0]), "+v"(f.c[0][1]),
+                                               "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]), "+v"(f.c[1][0]), "+v"(f.c[1][1]) :: "memory");
     };
-    // 8 MFMAs of one k-half; `stage` >= 0: two LDS-DMA pieces (k0, k0 + 1) of the tile being streamed in ride between them
-    auto mma_half = [&](const Fr& f, int stage, auto k0_c) __attribute__((always_inline)) {
-        constexpr int k0 = decltype(k0_c)::value;
-        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[0], f.c[0], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[1], f.c[0], acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[0], f.c[1], acc[0][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0x6);
-        if (stage >= 0) piece(stage, std::integral_constant<int, k0>{});
-        __builtin_amdgcn_sched_barrier(0x6);
-        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[1], f.c[1], acc[1][1], 0, 0, 0);
-        acc[2][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[2], f.c[0], acc[2][0], 0, 0, 0);
-        acc[2][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[2], f.c[1], acc[2][1], 0, 0, 0);
-        acc[3][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[3], f.c[0], acc[3][0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0x6);
-        if (stage >= 0) piece(stage, std::integral_constant<int, k0 + 1>{});
-        __builtin_amdgcn_sched_barrier(0x6);
-        acc[3][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[3], f.c[1], acc[3][1], 0, 0, 0);
+    auto compute = [&]() __attribute__((always_inline)) {
+        if constexpr (P4V_SW7_DBG & 2) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[j][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[h][j], f.c[h][q], acc[j][q], 0, 0, 0);
+        // MFMAs are register-only instructions: nothing but their operands orders them against barriers and asm statements,
+        // and left alone the instruction selector sinks them below the partner's phases (the ping-pong collapses into
+        // "three load phases, then three compute phases").  An empty volatile asm that consumes the accumulators keeps the
+        // 16 MFMAs of a k-tile between the fragment wait above and the barrier below.
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                          "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
     };
 
     // ---- epilogue of one candidate ------------------------------------------------------------------------------------
-    // Element (j, q, r) of a lane: feature n = r0 + wr*128 + j*32 + (r&3) + 8*(r>>2) + 4*g, sample m = m0 + crow (+ q*32).
-    // N % 32 == 0 (host): a 32-feature block is valid or padding as a whole; padding blocks / samples read a valid address
-    // and are masked.  Lane base pointers: sample row (clamped) + 4*g features.
-    const bool hess = p.wt_mode == 1;                    // EPI_SQ_W: weight = raw_grad (hessian) or raw_out (square-weighted L2)
-    constexpr int NQ = TWIN ? 1 : 2;                     // sample blocks with their own epilogue elements
-    // byte offset of (sample row, 4*g features) in raw_out / raw_grad, < 4 GB (checked by the host); sample block 1 only
-    // exists without the twin
-    const int ms0 = m0 + (int)crow, ms1 = ms0 + 32;
-    const bool m_ok0 = ms0 < p.M, m_ok1 = ms1 < p.M;
-    const unsigned lane_boff0 = (unsigned)(((long)min(ms0, p.M - 1) * p.ldo + 4 * g) * 4);
-    const unsigned lane_boff1 = (unsigned)(((long)min(ms1, p.M - 1) * p.ldo + 4 * g) * 4);
-    // A sub-block = 8 of a lane's 16 elements of one 32 x 32 block (row quads rq = 2 h2, 2 h2 + 1): 2 + 2 dwordx4 loads.
-    // Loads run two sub-blocks ahead of the arithmetic through a ring of three register sets (48 VGPRs: next to 128
-    // accumulators and the prefetched fragments there is no room for more); wave-uniform base (SGPR pair) + per-lane
-    // 32-bit offset, so no vector address arithmetic at all.
+    // A sub-block = 8 of a lane's 16 elements of one 32 x 32 block (row quads rq = 2 h2, 2 h2 + 1): 2 + 2 dwordx4 loads of
+    // 1 KB per wave each (fragment order, see k_prep_epi).  Loads run two sub-blocks ahead of the arithmetic through a ring
+    // of three register sets; wave-uniform base (SGPR pair) + per-lane 32-bit offset: no vector address arithmetic.
+    constexpr int NQ = TWIN ? 1 : 2;
+    constexpr int NSB = 8 * NQ;
+    constexpr bool NEEDW = (EPI == EPI_SQ_W || EPI == EPI_W_SQ);
     struct Hb { v4f u[2], w[2]; };
+    const unsigned e_voff = (unsigned)lane * 16u;
+    const float* e_wave = p.E + ((long)(ct * p.rtiles + rt) * 8 + wid) * (NSB * 4 * 256);   // 256 floats per 1 KB chunk
 #define P4V_GLD(dst, voff, sbase, off) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off) : "memory")
-    constexpr int NSB = 8 * NQ;                          // sub-blocks per candidate
     auto load_sb = [&](Hb& b, auto sb_c) __attribute__((always_inline)) {
         constexpr int sb = decltype(sb_c)::value;
-        constexpr int j = sb / (2 * NQ), q = (sb / 2) % NQ, h2 = sb % 2;
-        const int nb = r0 + wr * 128 + j * 32;
-        const int fo = (nb < p.N ? nb : 0) + h2 * 16;
-        const float* su = p.O + fo;
-        const float* sw_ = p.Wt + fo;
-        const unsigned vo = q == 0 ? lane_boff0 : lane_boff1;
-        P4V_GLD(b.u[0], vo, su, 0); P4V_GLD(b.w[0], vo, sw_, 0);
-        P4V_GLD(b.u[1], vo, su, 32); P4V_GLD(b.w[1], vo, sw_, 32);
+        const float* se = e_wave + sb * 1024;
+        P4V_GLD(b.u[0], e_voff, se, 0);
+        if (NEEDW) P4V_GLD(b.w[0], e_voff, se, 1024);
+        P4V_GLD(b.u[1], e_voff, se, 2048);
+        if (NEEDW) P4V_GLD(b.w[1], e_voff, se, 3072);
     };
+    constexpr int LPS = NEEDW ? 4 : 2;                   // loads per sub-block
     auto epilogue = [&](int ci) __attribute__((always_inline)) {
         const v4f s1v = *reinterpret_cast<const v4f*>(s1tab + ci * 8 + wr * 4);
         v4f s2v = {0.f, 0.f, 0.f, 0.f};
@@ -2073,30 +2110,23 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
             constexpr int j = sb / (2 * NQ), q = (sb / 2) % NQ, h2 = sb % 2;
             Hb& cur = hb[sb % 3];
             if constexpr (sb + 2 < NSB) load_sb(hb[(sb + 2) % 3], std::integral_constant<int, sb + 2>{});
-            constexpr int younger = (sb + 2 < NSB) ? 8 : (sb + 1 < NSB) ? 4 : 0;      // loads issued after this sub-block's
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.u[0]), "+v"(cur.u[1]), "+v"(cur.w[0]), "+v"(cur.w[1]) : "n"(younger) : "memory");
-            const bool blk_ok = (r0 + wr * 128 + j * 32 < p.N) && (q == 0 ? m_ok0 : m_ok1);
+            constexpr int younger = ((sb + 2 < NSB) ? 2 : (sb + 1 < NSB) ? 1 : 0) * LPS;   // loads issued after this sub-block's
+            if constexpr (NEEDW) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.u[0]), "+v"(cur.u[1]), "+v"(cur.w[0]), "+v"(cur.w[1]) : "n"(younger) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur.u[0]), "+v"(cur.u[1]) : "n"(younger) : "memory");
             const float s1 = s1v[j], s2 = s2v[j];
-            // 8 elements -> one partial sum; padding (whole 32-feature blocks, samples >= M: their accumulators are 0 and
-            // their loads hit clamped, valid addresses) is masked once per sub-block, not per element
-            float ps = 0.0f;
+            float sum = sumj[j];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int rq = 2 * h2 + rr;
-                const v4f bv = *reinterpret_cast<const v4f*>(btab + wr * 128 + j * 32 + 8 * rq + 4 * g);
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = rq * 4 + e;
-                    const float o = cur.u[rr][e];
-                    float d = (o - bv[e]) - (float)acc[j][TWIN ? 0 : q][r] * s1;
+                    const int r = (2 * h2 + rr) * 4 + e;
+                    float d = cur.u[rr][e] - (float)acc[j][TWIN ? 0 : q][r] * s1;
                     if (TWIN) d -= (float)acc[j][1][r] * s2;
-                    if (EPI == EPI_SQ_W) { const float tt = (hess ? cur.w[rr][e] : o) * d; ps = fmaf(tt, tt, ps); }   // hessian: raw_grad; square-weighted: raw_out
-                    else if (EPI == EPI_SQ) ps = fmaf(d, d, ps);
-                    else if (EPI == EPI_ABS) ps += fabsf(d);
-                    else ps = fmaf(fabsf(o) * d, d, ps);                                                             // linear-weighted: |raw_out|
+                    if (EPI == EPI_SQ_W) { const float tt = cur.w[rr][e] * d; sum = fmaf(tt, tt, sum); }
+                    else if (EPI == EPI_SQ) sum = fmaf(d, d, sum);
+                    else if (EPI == EPI_ABS) sum += fabsf(d);
+                    else sum = fmaf(cur.w[rr][e] * d, d, sum);
                 }
-            }
-            float sum = sumj[j] + (blk_ok ? ps : 0.0f);
             // pin the arithmetic of this sub-block HERE: nothing orders it against the asm statements, so the instruction
             // selector sinks it towards its only use at the end of the epilogue -- every loaded value of the candidate live
             // at once, 800 B of scratch per lane.  An empty volatile asm that consumes `sum` is chained to the loads.
@@ -2118,48 +2148,65 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         }
     };
 
-    // ---- main loop: flat over (candidate, k-tile); a step = one k-tile = two k-halves -------------------------------
+    // ---- main loop: flat over (candidate, k-tile); tile `it` sits in stage it % 4 = k-tile % 4 (ktiles % 4 == 0) ----------
+    // Per k-tile two barriers B1, B2 and two phases.  Group A (waves 0-3): MFMAs of tile `it` | B1 | DMA of tile it+3, fragments
+    // of tile it+1 | B2.  Group B (waves 4-7): DMA of tile it+3, fragments of tile `it` | B1 | MFMAs of tile `it` | B2.
+    //   landed:  every wave waits for its own pieces of tile it+1 before B1(it), so behind B1(it) tile it+1 is in the LDS for
+    //            everybody (A reads it in the second phase of `it`, B in the first phase of it+1);
+    //   free:    tile it+3 goes into the stage of tile it-1, whose last fragment reads (A: second phase of it-2, B: first
+    //            phase of it-1) were waited for before B1(it-1).
+    // The younger pieces in flight at the landed-wait are tile it+2 (A) and tiles it+2, it+3 (B has just issued it+3).
     const int npre = min(SW7_NS - 1, total);
-    for (int i = 0; i < npre; ++i) issue_all(i);
-    Fr fa, fb;
-    // step `it` (compile-time stage): fa holds k-half 0 of tile it.  Prove tile it+1 landed (own pieces waited for, then
-    // the barrier); the stage of tile it-1 is free for tile it+3; read k-half 1 of tile it, MFMAs of half 0; read k-half
-    // 0 of tile it+1, MFMAs of half 1.
-    // ktiles % 4 == 0 (host): tile `it` always sits in stage it % 4 = k-tile % 4, so the candidate loop stays rolled
-    // and the epilogue exists once in the code.
-    auto step = [&](int it, auto stage_c, bool prefetch) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_c)::value;
-        if (it + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const int fill = (it + SW7_NS - 1 < total) ? (ST + SW7_NS - 1) % SW7_NS : -1;
-        read_half(fb, stage_c, std::integral_constant<int, 1>{});
-        __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));               // fa complete; the 6 reads just issued stay in flight
-        fence(fa);
-        mma_half(fa, fill, std::integral_constant<int, 0>{});
-        // the first half of the next tile is prefetched under the MFMAs of this half -- except across a candidate
-        // boundary: the epilogue needs the registers
-        if (prefetch) {
-            read_half(fa, std::integral_constant<int, (ST + 1) % SW7_NS>{}, std::integral_constant<int, 0>{});
-            __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));
-        } else {
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-        }
-        fence(fb);
-        mma_half(fb, fill, std::integral_constant<int, 2>{});
-    };
+    if (npre > 0) issue(std::integral_constant<int, 0>{});
+    if (npre > 1) issue(std::integral_constant<int, 1>{});
+    if (npre > 2) issue(std::integral_constant<int, 2>{});
     if (total > 2) wait_vmcnt<8>(); else if (total > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    read_half(fa, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     int it = 0;
-    for (int ci = 0; ci < ncand; ++ci) {
-        for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
-            step(it, std::integral_constant<int, 0>{}, true);
-            step(it + 1, std::integral_constant<int, 1>{}, true);
-            step(it + 2, std::integral_constant<int, 2>{}, true);
-            step(it + 3, std::integral_constant<int, 3>{}, kq + 4 < ktiles);
+    if (wr == 0) {
+        read_tile(std::integral_constant<int, 0>{});
+        // second phase of a k-tile for group A
+        auto second = [&](int it_, auto stage_c) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stage_c)::value;
+            if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                                     // B1
+            if (it_ + 3 < total) issue(std::integral_constant<int, (ST + 3) % SW7_NS>{});
+            if (it_ + 1 < total) read_tile(std::integral_constant<int, (ST + 1) % SW7_NS>{});
+            frags_ready();
+            __builtin_amdgcn_s_barrier();                                                     // B2
+        };
+        frags_ready();
+        for (int ci = 0; ci < ncand; ++ci) {
+            for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
+                compute(); second(it, std::integral_constant<int, 0>{});
+                compute(); second(it + 1, std::integral_constant<int, 1>{});
+                compute(); second(it + 2, std::integral_constant<int, 2>{});
+                compute();
+                if (kq + 4 < ktiles) second(it + 3, std::integral_constant<int, 3>{});
+            }
+            if constexpr (!(P4V_SW7_DBG & 4)) epilogue(ci);
+            second(it - 1, std::integral_constant<int, 3>{});
         }
-        epilogue(ci);
-        if (ci + 1 < ncand) read_half(fa, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    } else {
+        auto first = [&](int it_, auto stage_c) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stage_c)::value;
+            if (it_ + 3 < total) issue(std::integral_constant<int, (ST + 3) % SW7_NS>{});
+            read_tile(stage_c);
+            if (it_ + 3 < total) wait_vmcnt<8>(); else if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            frags_ready();
+            __builtin_amdgcn_s_barrier();                                                     // B1
+        };
+        for (int ci = 0; ci < ncand; ++ci) {
+            for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
+                first(it, std::integral_constant<int, 0>{}); compute(); __builtin_amdgcn_s_barrier();
+                first(it + 1, std::integral_constant<int, 1>{}); compute(); __builtin_amdgcn_s_barrier();
+                first(it + 2, std::integral_constant<int, 2>{}); compute(); __builtin_amdgcn_s_barrier();
+                first(it + 3, std::integral_constant<int, 3>{}); compute();
+                if (kq + 4 < ktiles) __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (!(P4V_SW7_DBG & 4)) epilogue(ci);
+            __builtin_amdgcn_s_barrier();                                                     // B2 of the candidate's last tile
+        }
     }
 #undef P4V_DSR
 #undef P4V_GLD
