@@ -335,6 +335,8 @@ typedef struct p4v_kernel_stats {
     int64_t sweep7_launches;
     double sweep7_macs;
     double sweep7_alg_macs;
+    double sweep7_twin_ms;     /* the twin (two-plane) launches of k_sweep7 alone (also included in sweep7_*) */
+    int64_t sweep7_twin_launches;
 } p4v_kernel_stats;
 
 int p4v_stats_enable(int enable);   /* 1 / 0: launch timing on the calling thread */
@@ -346,7 +348,7 @@ int p4v_stats_get(p4v_kernel_stats* out);
  * through the generic kernel.  Process-wide, relaxed atomics: set them while no call is in flight. */
 int p4v_debug_set_variant(int variant, int force_generic);
 /* Overrides of launch heuristics: key 0 / 1 / 2 / 3 = candidate groups of k_sweep6 / k_sweep2 / k_sweep2g / k_sweep7
- * (0 = cost model), key 4 = print the launch plans to stderr. */
+ * (0 = cost model), key 4 = print the launch plans to stderr, key 5 = workgroup order of k_sweep7 + 1. */
 int p4v_debug_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -44,7 +44,8 @@ class KernelStats(C.Structure):
                 ("sweep_i8_alg_macs", C.c_double), ("sweep_f32_alg_macs", C.c_double),
                 ("sweep6_ms", C.c_double), ("sweep6_launches", C.c_int64), ("sweep6_macs", C.c_double), ("sweep6_alg_macs", C.c_double),
                 ("memo_hits", C.c_int64), ("memo_misses", C.c_int64),
-                ("sweep7_ms", C.c_double), ("sweep7_launches", C.c_int64), ("sweep7_macs", C.c_double), ("sweep7_alg_macs", C.c_double)]
+                ("sweep7_ms", C.c_double), ("sweep7_launches", C.c_int64), ("sweep7_macs", C.c_double), ("sweep7_alg_macs", C.c_double),
+                ("sweep7_twin_ms", C.c_double), ("sweep7_twin_launches", C.c_int64)]
 
 
 class PlaneDesc(C.Structure):

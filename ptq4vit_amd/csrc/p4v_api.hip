@@ -102,7 +102,7 @@ std::atomic<int> g_variant_word{0};
 #define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[8];
-enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4 };
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5 };
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -444,18 +444,20 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, bool twin, int epi, int cgroups
     cgroups = std::max(cgroups, cdiv(nc, per_max));
     const int per = cdiv(nc, cgroups);
     const size_t lds = (size_t)SW7_NS * SW7_STAGE + (size_t)per * 192 + 256;
-    dim3 grid(p.rtiles * p.ctiles, 1, cgroups);
+    Sweep7Params q = p;
+    q.cgroups = cgroups;
+    dim3 grid(p.rtiles * p.ctiles * cgroups, 1, 1);
     const bool timed = g_stat_on;
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 3;
+        rec.kind = twin ? 4 : 3;
         rec.macs = (double)p.rtiles * 256 * (double)p.ctiles * 256 * (double)p.ldk * nc;   // (twin: 128 samples x 2 planes)
         rec.alg = g_alg_macs_cand * nc;
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
-    CHK(twin ? launch_sweep7_epi<true>(c, p, epi, grid, lds) : launch_sweep7_epi<false>(c, p, epi, grid, lds));
+    CHK(twin ? launch_sweep7_epi<true>(c, q, epi, grid, lds) : launch_sweep7_epi<false>(c, q, epi, grid, lds));
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
         g_stat_recs.push_back(rec);
@@ -726,6 +728,7 @@ int run_pass(Ctx& c, Pass& ps) {
             // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
             int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, 256, 6.0, 0.62);
             if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
+            q.order = tune(TUNE_ORDER7) > 0 ? tune(TUNE_ORDER7) - 1 : 1;
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);
             CHK(launch_sweep7(c, q, ps.twin, ps.epi, cg7));
             continue;
@@ -1688,9 +1691,10 @@ static int stats_drain() {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        if (r.kind == 0 || r.kind == 2 || r.kind == 3) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || r.kind == 2 || r.kind == 3 || r.kind == 4) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
-        if (r.kind == 3) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
+        if (r.kind == 3 || r.kind == 4) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
+        if (r.kind == 4) { g_stats.sweep7_twin_ms += ms; g_stats.sweep7_twin_launches++; }
         if (r.kind == 1) { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);

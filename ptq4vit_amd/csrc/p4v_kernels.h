@@ -1915,7 +1915,8 @@ struct Sweep7Params {
     const float* E;                     // pre-packed epilogue operands (k_prep_epi)
     int c0, c1;
     float* part; long p_cs; int NG;     // part[c * p_cs + (ct * 4 + wc) * NG + rt * 8 + wr * 4 + j]
-    int rtiles, ctiles;
+    int rtiles, ctiles, cgroups;
+    int order;                          // workgroup order on the 1-D grid (see the kernel)
 };
 
 // timing-only ablation builds (never in production): -DP4V_SW7_DBG=1 no operand stream, 2 no MFMA, 4 no epilogue (bits add)
@@ -1976,13 +1977,27 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     const int wr = wid >> 2, wc = wid & 3;               // wave grid: 2 (features; = ping-pong group) x 4 (samples)
     const int g = lane >> 5, l31 = lane & 31;
 
-    const int nwg = p.rtiles * p.ctiles;
+    // 1-D grid of rtiles x ctiles x cgroups workgroups; block b runs on XCD b % 8 and xcd_remap hands every XCD a
+    // contiguous run of the order below, so the ~32 workgroups resident on an XCD at any time are neighbours in it:
+    //   order 0: feature tile fastest, then sample tile, candidate group slowest
+    //   order 1: feature tile fastest, then candidate group, sample tile slowest -- the workgroups of one sample tile
+    //            (all feature tiles x all candidate groups) run together: they share the fixed operand's tiles, the epilogue
+    //            operands and, per candidate group, the expanded tile of the sample side
+    //   order 2: candidate group fastest, then feature tile, then sample tile
+    //   order 3: feature tile, then 4 sample tiles, then candidate group, then groups of 4 sample tiles
+    const int nwg = p.rtiles * p.ctiles * p.cgroups;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int rt = t % p.rtiles, ct = t / p.rtiles;
+    int rt, ct, cg;
+    if (p.order == 1) { rt = t % p.rtiles; cg = (t / p.rtiles) % p.cgroups; ct = t / (p.rtiles * p.cgroups); }
+    else if (p.order == 2) { cg = t % p.cgroups; rt = (t / p.cgroups) % p.rtiles; ct = t / (p.rtiles * p.cgroups); }
+    else if (p.order == 3) {
+        const int grp = 4 * p.rtiles * p.cgroups, g0 = (t / grp) * 4, gsz = min(4, p.ctiles - g0), tt = t % grp;
+        rt = tt % p.rtiles; ct = g0 + (tt / p.rtiles) % gsz; cg = tt / (p.rtiles * gsz);
+    } else { rt = t % p.rtiles; ct = (t / p.rtiles) % p.ctiles; cg = t / (p.rtiles * p.ctiles); }
     constexpr int CM = TWIN ? 128 : 256;                 // samples per workgroup tile
     const int r0 = rt * 256, m0 = ct * CM;
-    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    const int per = (p.c1 - p.c0 + p.cgroups - 1) / p.cgroups;
+    const int c_lo = p.c0 + cg * per, c_hi = min(p.c1, c_lo + per);
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
@@ -2010,17 +2025,19 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     const int total = ncand * ktiles;
     int ikt = 0;
     const int lds_w = wid * 2048;
-    auto issue = [&](auto stage_c) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_c)::value;
-        char* s = smem + ST * SW7_STAGE + lds_w;
-        if constexpr (!(P4V_SW7_DBG & 1)) {
-            glds16(curR + voff0, s);
-            glds16(curR + voff1, s + 1024);
-            glds16(curC + voff0, s + SW7_REGION);
-            glds16(curC + voff1, s + SW7_REGION + 1024);
+    // the four pieces of a tile: k = 0, 1 feature side, k = 2, 3 sample side (the cursors advance behind the last one)
+    auto piece = [&](auto stage_c, auto k_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value, k = decltype(k_c)::value;
+        char* s = smem + ST * SW7_STAGE + lds_w + (k >> 1) * SW7_REGION + (k & 1) * 1024;
+        if constexpr (!(P4V_SW7_DBG & 1)) glds16((k >> 1 ? curC : curR) + ((k & 1) ? voff1 : voff0), s);
+        if constexpr (k == 3) {
+            curR += SW_BKB; curC += SW_BKB;
+            if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
         }
-        curR += SW_BKB; curC += SW_BKB;
-        if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
+    };
+    auto issue = [&](auto stage_c) __attribute__((always_inline)) {
+        piece(stage_c, std::integral_constant<int, 0>{}); piece(stage_c, std::integral_constant<int, 1>{});
+        piece(stage_c, std::integral_constant<int, 2>{}); piece(stage_c, std::integral_constant<int, 3>{});
     };
 
     v16i acc[4][2];                                      // [32-feature block j][sample block q (twin: plane q)]
@@ -2060,15 +2077,26 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.c[0][0]), "+v"(f.c[0][1]),
                                                "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]), "+v"(f.c[1][0]), "+v"(f.c[1][1]) :: "memory");
     };
-    auto compute = [&]() __attribute__((always_inline)) {
-        if constexpr (P4V_SW7_DBG & 2) return;
+    // The 16 MFMAs of a k-tile.  `fill` (compile-time stage, or none): pieces k0, k0 + 1 of the tile being streamed in are
+    // issued between them -- an LDS-DMA issue costs a wave ~60 clk next to bare MFMAs but 100-185 clk in a phase that also
+    // carries fragment reads (MI355X_MICROARCH.md), so two of a wave's four pieces ride here and only two in its load phase.
+    auto compute = [&](bool fill, auto stage_c, auto k0_c) __attribute__((always_inline)) {
+        constexpr int k0 = decltype(k0_c)::value;
+        if constexpr (P4V_SW7_DBG & 2) { if (fill) { piece(stage_c, std::integral_constant<int, k0>{}); piece(stage_c, std::integral_constant<int, k0 + 1>{}); } return; }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q) {
                     acc[j][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[h][j], f.c[h][q], acc[j][q], 0, 0, 0);
+                    if (j == 1 && q == 1) {              // behind the 4th / 12th MFMA
+                        __builtin_amdgcn_sched_barrier(0x6);
+                        if (fill) { if (h == 0) piece(stage_c, std::integral_constant<int, k0>{}); else piece(stage_c, std::integral_constant<int, k0 + 1>{}); }
+                        __builtin_amdgcn_sched_barrier(0x6);
+                    }
+                }
+        }
         // MFMAs are register-only instructions: nothing but their operands orders them against barriers and asm statements,
         // and left alone the instruction selector sinks them below the partner's phases (the ping-pong collapses into
         // "three load phases, then three compute phases").  An empty volatile asm that consumes the accumulators keeps the
@@ -2102,15 +2130,21 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         v4f s2v = {0.f, 0.f, 0.f, 0.f};
         if (TWIN) s2v = *reinterpret_cast<const v4f*>(s2tab + ci * 8 + wr * 4);
         float sumj[4] = {0.f, 0.f, 0.f, 0.f};
-        Hb hb[3];
-        load_sb(hb[0], std::integral_constant<int, 0>{});
-        load_sb(hb[1], std::integral_constant<int, 1>{});
+        // ring of RD register sets, loads RD - 1 sub-blocks ahead of the arithmetic: the 48 fragment registers are dead during
+        // the epilogue, so six sets (96 VGPRs) fit next to the 128 accumulators; the operands come from L2 / Infinity Cache
+        // at ~1-2 us per access and only the depth of this ring hides that
+        constexpr int RD = 3;
+        Hb hb[RD];
+        [&]<int... SB>(std::integer_sequence<int, SB...>) __attribute__((always_inline)) {
+            (load_sb(hb[SB], std::integral_constant<int, SB>{}), ...);
+        }(std::make_integer_sequence<int, (RD - 1 < NSB ? RD - 1 : NSB)>{});
         auto do_sb = [&](auto sb_c) __attribute__((always_inline)) {
             constexpr int sb = decltype(sb_c)::value;
             constexpr int j = sb / (2 * NQ), q = (sb / 2) % NQ, h2 = sb % 2;
-            Hb& cur = hb[sb % 3];
-            if constexpr (sb + 2 < NSB) load_sb(hb[(sb + 2) % 3], std::integral_constant<int, sb + 2>{});
-            constexpr int younger = ((sb + 2 < NSB) ? 2 : (sb + 1 < NSB) ? 1 : 0) * LPS;   // loads issued after this sub-block's
+            Hb& cur = hb[sb % RD];
+            if constexpr (sb + RD - 1 < NSB) load_sb(hb[(sb + RD - 1) % RD], std::integral_constant<int, sb + RD - 1>{});
+            constexpr int ahead = (NSB - 1 - sb < RD - 1) ? NSB - 1 - sb : RD - 1;             // sub-blocks loaded after this one
+            constexpr int younger = ahead * LPS;
             if constexpr (NEEDW) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.u[0]), "+v"(cur.u[1]), "+v"(cur.w[0]), "+v"(cur.w[1]) : "n"(younger) : "memory");
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur.u[0]), "+v"(cur.u[1]) : "n"(younger) : "memory");
             const float s1 = s1v[j], s2 = s2v[j];
@@ -2162,46 +2196,70 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     if (npre > 2) issue(std::integral_constant<int, 2>{});
     if (total > 2) wait_vmcnt<8>(); else if (total > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    // Tile it+3 is streamed in during k-tile `it`, two pieces under each group's MFMAs and two in its load phase (A: feature
+    // side while computing, then sample side; B: feature side in its load phase, sample side while computing).  At the
+    // landed-wait before B1(it) the younger pieces of a wave are therefore tile it+2 (4) and the first two of tile it+3.
     int it = 0;
+    auto wait_landed = [&](int it_) __attribute__((always_inline)) {      // own pieces of tile it_+1
+        if (it_ + 3 < total) wait_vmcnt<6>(); else if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    };
     if (wr == 0) {
         read_tile(std::integral_constant<int, 0>{});
-        // second phase of a k-tile for group A
-        auto second = [&](int it_, auto stage_c) __attribute__((always_inline)) {
+        // k-tile of group A: MFMAs (+ 2 pieces) | B1 | fragments of the next tile, 2 pieces | B2
+        auto first = [&](int it_, auto stage_c) __attribute__((always_inline)) {
             constexpr int ST = decltype(stage_c)::value;
-            if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            compute(it_ + 3 < total, std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 0>{});
+        };
+        auto second = [&](int it_, auto stage_c, int epi_ci = -1) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stage_c)::value;
+            wait_landed(it_);
             __builtin_amdgcn_s_barrier();                                                     // B1
-            if (it_ + 3 < total) issue(std::integral_constant<int, (ST + 3) % SW7_NS>{});
+            // a candidate's epilogue runs HERE, in the phase in which group B computes the candidate's last tile and then
+            // runs its own epilogue: the two groups' epilogues (memory-latency bound) overlap instead of following each other
+            if constexpr (!(P4V_SW7_DBG & 4)) if (epi_ci >= 0) epilogue(epi_ci);
+            // fragment reads FIRST: their LDS latency passes under the DMA issues behind them
             if (it_ + 1 < total) read_tile(std::integral_constant<int, (ST + 1) % SW7_NS>{});
+            if (it_ + 3 < total) {
+                piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 2>{});
+                piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 3>{});
+            }
             frags_ready();
             __builtin_amdgcn_s_barrier();                                                     // B2
         };
         frags_ready();
         for (int ci = 0; ci < ncand; ++ci) {
             for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
-                compute(); second(it, std::integral_constant<int, 0>{});
-                compute(); second(it + 1, std::integral_constant<int, 1>{});
-                compute(); second(it + 2, std::integral_constant<int, 2>{});
-                compute();
+                first(it, std::integral_constant<int, 0>{}); second(it, std::integral_constant<int, 0>{});
+                first(it + 1, std::integral_constant<int, 1>{}); second(it + 1, std::integral_constant<int, 1>{});
+                first(it + 2, std::integral_constant<int, 2>{}); second(it + 2, std::integral_constant<int, 2>{});
+                first(it + 3, std::integral_constant<int, 3>{});
                 if (kq + 4 < ktiles) second(it + 3, std::integral_constant<int, 3>{});
             }
-            if constexpr (!(P4V_SW7_DBG & 4)) epilogue(ci);
-            second(it - 1, std::integral_constant<int, 3>{});
+            second(it - 1, std::integral_constant<int, 3>{}, ci);
         }
     } else {
+        // k-tile of group B: fragments of this tile, 2 pieces | B1 | MFMAs (+ 2 pieces) | B2
         auto first = [&](int it_, auto stage_c) __attribute__((always_inline)) {
             constexpr int ST = decltype(stage_c)::value;
-            if (it_ + 3 < total) issue(std::integral_constant<int, (ST + 3) % SW7_NS>{});
             read_tile(stage_c);
-            if (it_ + 3 < total) wait_vmcnt<8>(); else if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            if (it_ + 3 < total) {
+                piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 0>{});
+                piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 1>{});
+            }
+            wait_landed(it_);
             frags_ready();
             __builtin_amdgcn_s_barrier();                                                     // B1
         };
+        auto second = [&](int it_, auto stage_c) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stage_c)::value;
+            compute(it_ + 3 < total, std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 2>{});
+        };
         for (int ci = 0; ci < ncand; ++ci) {
             for (int kq = 0; kq < ktiles; kq += 4, it += 4) {
-                first(it, std::integral_constant<int, 0>{}); compute(); __builtin_amdgcn_s_barrier();
-                first(it + 1, std::integral_constant<int, 1>{}); compute(); __builtin_amdgcn_s_barrier();
-                first(it + 2, std::integral_constant<int, 2>{}); compute(); __builtin_amdgcn_s_barrier();
-                first(it + 3, std::integral_constant<int, 3>{}); compute();
+                first(it, std::integral_constant<int, 0>{}); second(it, std::integral_constant<int, 0>{}); __builtin_amdgcn_s_barrier();
+                first(it + 1, std::integral_constant<int, 1>{}); second(it + 1, std::integral_constant<int, 1>{}); __builtin_amdgcn_s_barrier();
+                first(it + 2, std::integral_constant<int, 2>{}); second(it + 2, std::integral_constant<int, 2>{}); __builtin_amdgcn_s_barrier();
+                first(it + 3, std::integral_constant<int, 3>{}); second(it + 3, std::integral_constant<int, 3>{});
                 if (kq + 4 < ktiles) __builtin_amdgcn_s_barrier();
             }
             if constexpr (!(P4V_SW7_DBG & 4)) epilogue(ci);

@@ -16,6 +16,9 @@ from ptq4vit_amd import engine  # noqa: E402
 SHAPES = {  # name: (K, N, n_V, postgelu)
     "qkv": (768, 2304, 3, False), "proj": (768, 768, 1, False), "fc1": (768, 3072, 1, False),
     "fc2": (3072, 768, 1, True), "head": (768, 1000, 1, False),
+    # ViT-L / Swin-B stage 4 (dim 1024) and ViT-S fc2: the other large-K layers (k_sweep7)
+    "l_qkv": (1024, 3072, 3, False), "l_proj": (1024, 1024, 1, False), "l_fc1": (1024, 4096, 1, False),
+    "l_fc2": (4096, 1024, 1, True), "s_fc2": (1536, 384, 1, True),
 }
 
 
@@ -87,7 +90,11 @@ def one(a):
     dt = (time.time() - t) / a.reps
     if a.kernel_stats:
         st = engine.stats_get()
-        for k in ("sweep6", "sweep_i8", "sweep_f32"):
+        if st["sweep7_launches"]:
+            nt, mt = st["sweep7_twin_launches"], st["sweep7_twin_ms"]
+            n1, m1 = st["sweep7_launches"] - nt, st["sweep7_ms"] - mt
+            print(f"{a.layer}: sweep7 plain: {n1} launches, {m1 / max(n1, 1) * 1e3:.1f} us each; twin: {nt} launches, {mt / max(nt, 1) * 1e3:.1f} us each")
+        for k in ("sweep6", "sweep7", "sweep_i8", "sweep_f32"):
             n = st[k + "_launches"]
             if n:
                 print(f"{a.layer}: {k}: {n} launches, {st[k + '_ms'] / n * 1e3:.1f} us each, "
