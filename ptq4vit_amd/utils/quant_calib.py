@@ -160,11 +160,26 @@ class HessianQuantCalibrator(QuantCalibrator):
     """Reference quant_calib.py:203-378."""
 
     def __init__(self, net, wrapped_modules, calib_loader, sequential=False, batch_size=1,
-                 cache_budget_bytes=96 << 30):
+                 cache_budget_bytes=None):
         super().__init__(net, wrapped_modules, calib_loader, sequential=sequential)
         self.batch_size = batch_size
+        # bytes of captured tensors kept resident at a time; None = what the GPU has free minus head room for the search
+        # workspaces and the capture pass itself (288 GB of HBM3E hold the 207 GB of Swin-B/384 x 128 images in ONE group;
+        # every further group repeats the whole capture pass)
         self.cache_budget_bytes = cache_budget_bytes
         self.timings = {}
+
+    SEARCH_HEADROOM_BYTES = 44 << 30
+
+    def _resolve_budget(self):
+        if self.cache_budget_bytes is not None:
+            return int(self.cache_budget_bytes)
+        dev = _dev_of(self.net)
+        if dev.type != "cuda":
+            return 96 << 30
+        free, _total = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)    # cached by torch's allocator: reusable
+        return max(8 << 30, int(free) - self.SEARCH_HEADROOM_BYTES)
 
     # ---- capture ------------------------------------------------------------------------------------
     def _raw_pred_softmax(self):
@@ -181,13 +196,11 @@ class HessianQuantCalibrator(QuantCalibrator):
         per-sub-batch pieces on the modules as lists (sub-batch sharded capture, shard.exchange_captures)."""
         dev = _dev_of(self.net)
         bs = getattr(self, "batch_size", None) or self.calib_loader.batch_size
-        hooks = []
         for n in names:
             m = self.wrapped_modules[n]
             m.raw_input = m.raw_out = None
             if hasattr(m, "metric"):
                 m.raw_grad = None   # step 2 deletes the caches (reference linear.py:554): re-create for re-calibration
-            hooks += _register(m, with_grad and hasattr(m, "metric"))
         # Only gradients w.r.t. ACTIVATIONS are captured (grad_hook): no parameter gradient is ever looked at.  For the
         # duration of the capture NO parameter requires grad (no weight-gradient GEMMs -- a third of the backward pass --
         # no bias / LayerNorm reductions, no .grad accumulation); the graph hangs off the input images instead, which
@@ -199,51 +212,44 @@ class HessianQuantCalibrator(QuantCalibrator):
                     prm.requires_grad_(False)
                     frozen.append(prm)
         try:
-            done = False
-            if stride is not None:
+            if stride is None and with_grad and dev.type == "cuda" and not self.sequential:
+                if self._capture_passes_graph(names, dev, bs, raw_pred_softmax):
+                    return
+            hooks = []
+            for n in names:
+                m = self.wrapped_modules[n]
+                hooks += _register(m, with_grad and hasattr(m, "metric"))
+            try:
                 self._capture_passes(dev, bs, raw_pred_softmax, with_grad, stride)
-                done = True
-            if not done and with_grad and dev.type == "cuda" and not self.sequential:
-                # recording + instantiating the graph costs about five eager passes: worth it from ~24 sub-batches on
-                # (use_graph = True / False forces the choice)
-                n_sub = sum(-(-inp.shape[0] // bs) for inp, _ in self.calib_loader)
-                use_graph = getattr(self, "use_graph", None)
-                if use_graph or (use_graph is None and n_sub >= 24):
-                    done = self._capture_passes_graph(names, dev, bs, raw_pred_softmax)
-            if not done:
-                self._capture_passes(dev, bs, raw_pred_softmax, with_grad)
+            finally:
+                for h in hooks:
+                    h.remove()
         finally:
             for wt in frozen:
                 wt.requires_grad_(True)
-        for h in hooks:
-            h.remove()
         if stride is not None:
             return
         for n in names:
             m = self.wrapped_modules[n]
             _concat(m, with_grad and hasattr(m, "metric"))
 
-    def _capture_passes_graph(self, names, dev, bs, raw_pred_softmax):
-        """The sub-batch forward + KL backward replayed from ONE HIP graph.
+    # ---- the capture pass as a HIP graph, kept with the network ---------------------------------------------------------
+    def _graph_key(self, dev, bs, inp):
+        """What a recorded pass depends on: sub-batch geometry and the storage of every parameter (the graph replays
+        kernels on those addresses).  Quantisation settings do not enter: during a non-sequential capture every wrapped
+        module runs its RAW forward, so the same graph serves W8A8, W6A6, ... calibrations of one network -- the grid the
+        reference's experiment driver walks (example/test_all.py:83-103)."""
+        return (str(dev), int(bs), tuple(inp.shape[1:]), str(inp.dtype), tuple(self.wrapped_modules),
+                tuple(p.data_ptr() for p in self.net.parameters()))
 
-        With batch_size=4 (the reference's setting) the eager pass is bound by launch overhead, not by the GPU
-        (~130 ms of Python / dispatcher time for ~70 ms of kernels on ViT-B, tools/prof_capture.py).  All modules run
-        in "raw" mode during a non-sequential capture, so every sub-batch executes the same kernel sequence: it is
-        recorded once (hooks included -- they see the graph's static tensors) and replayed per sub-batch; after each
-        replay the hooked tensors are copied into their slice of the preallocated caches (the copy torch.cat would
-        have done).  Returns False -- caller falls back to the eager pass -- if the loader is not a single batch
-        divisible into equal sub-batches or if graph capture is not available.
-        """
-        batches = [inp for inp, _ in self.calib_loader]
-        if len(batches) != 1 or batches[0].shape[0] % bs != 0 or batches[0].shape[0] // bs < 2:
-            return False
-        inp = batches[0]
-        total = inp.shape[0]
-        n_sub = total // bs
-        mods = [self.wrapped_modules[n] for n in names]
+    def _build_graph(self, dev, bs, inp, raw_pred_softmax):
+        """Record ONE sub-batch forward + KL backward with hooks on EVERY wrapped module (so that any group of modules, on
+        any later calibration, can be served from it).  Returns the cache entry or None when graph capture is unavailable."""
+        mods = self.wrapped_modules
+        saved = {n: (m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for n, m in mods.items()}
 
         def reset():
-            for m in mods:
+            for m in mods.values():
                 m.raw_input = m.raw_out = None
                 if hasattr(m, "metric"):
                     m.raw_grad = None
@@ -254,6 +260,10 @@ class HessianQuantCalibrator(QuantCalibrator):
             loss = F.kl_div(F.log_softmax(pred, dim=-1), tgt, reduction="batchmean")
             loss.backward()
 
+        hooks = []
+        for m in mods.values():
+            hooks += _register(m, hasattr(m, "metric"))
+        entry = None
         try:
             static_in = inp[:bs].to(dev).clone().requires_grad_(True)
             static_tgt = raw_pred_softmax[:bs].clone()
@@ -266,31 +276,81 @@ class HessianQuantCalibrator(QuantCalibrator):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 one_pass(static_in, static_tgt)
+            # the hooks ran once, during capture: what they appended are the graph's static output tensors
+            statics = {}
+            for n, m in mods.items():
+                with_g = hasattr(m, "metric") and m.raw_grad is not None
+                if isinstance(m, MinMaxQuantMatMul):
+                    stat = [m.raw_input[0][0], m.raw_input[1][0], m.raw_out[0]]
+                else:
+                    stat = [m.raw_input[0], m.raw_out[0]]
+                if with_g:
+                    stat.append(m.raw_grad[0])
+                statics[n] = (stat, with_g)
+            entry = {"graph": graph, "in": static_in, "tgt": static_tgt, "statics": statics}
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[ptq4vit_amd] graph capture unavailable ({type(e).__name__}: {e}); eager capture")
-            reset()
+        finally:
+            for h in hooks:
+                h.remove()
+            for n, m in mods.items():
+                m.raw_input, m.raw_out = saved[n][0], saved[n][1]
+                if hasattr(m, "metric"):
+                    m.raw_grad = saved[n][2]
+        return entry
+
+    def _capture_passes_graph(self, names, dev, bs, raw_pred_softmax):
+        """The sub-batch forward + KL backward replayed from ONE HIP graph.
+
+        With batch_size=4 (the reference's setting) the eager pass is bound by launch overhead, not by the GPU
+        (~130 ms of Python / dispatcher time for ~70 ms of kernels on ViT-B, tools/prof_capture.py).  All modules run
+        in "raw" mode during a non-sequential capture, so every sub-batch executes the same kernel sequence: it is
+        recorded once (hooks included -- they see the graph's static tensors) and replayed per sub-batch; after each
+        replay the hooked tensors are copied into their slice of the preallocated caches (the copy torch.cat would
+        have done).  The instantiated graph stays with the network (`net._p4v_capture_graphs`): the capture of a second
+        group of modules (cache larger than the budget), and every later calibration of the same network, replays it.
+
+        When it is used (`use_graph` = True / False forces the choice): a graph is already cached; or the calibration
+        has >= 24 sub-batches (recording + instantiating costs about five eager passes); or this network has been
+        calibrated before (from the second calibration on the graph is recorded and kept).  Returns False -- caller
+        falls back to the eager pass -- if the loader is not a single batch divisible into equal sub-batches or if graph
+        capture is not available."""
+        batches = [inp for inp, _ in self.calib_loader]
+        if len(batches) != 1 or batches[0].shape[0] % bs != 0 or batches[0].shape[0] // bs < 2:
             return False
-        # the hooks ran once, during capture: what they appended are the graph's static output tensors
-        srcs, dsts = [], []
-        for m in mods:
-            with_g = hasattr(m, "metric") and m.raw_grad is not None
-            if isinstance(m, MinMaxQuantMatMul):
-                stat = [m.raw_input[0][0], m.raw_input[1][0], m.raw_out[0]]
-            else:
-                stat = [m.raw_input[0], m.raw_out[0]]
-            if with_g:
-                stat.append(m.raw_grad[0])
+        inp = batches[0]
+        total = inp.shape[0]
+        n_sub = total // bs
+        use_graph = getattr(self, "use_graph", None)
+        if use_graph is False:
+            return False
+        cache = self.net.__dict__.setdefault("_p4v_capture_graphs", {})
+        key = self._graph_key(dev, bs, inp)
+        entry = cache.get(key)
+        if entry is None:
+            seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
+            if not (use_graph or n_sub >= 24 or seen_before):
+                return False
+            entry = self._build_graph(dev, bs, inp, raw_pred_softmax)
+            if entry is None:
+                return False
+            cache.clear()                      # one geometry per network at a time: a graph pins its activations' memory
+            cache[key] = entry
+        srcs, flat_dsts = [], []
+        for n in names:
+            m = self.wrapped_modules[n]
+            stat, with_g = entry["statics"][n]
             # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
             full = [torch.empty((n_sub * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in stat]
             if isinstance(m, MinMaxQuantMatMul):
-                m.raw_input, m.raw_out = [[full[0]], [full[1]]], [full[2]]
+                m.raw_input, m.raw_out = [full[0], full[1]], full[2]
             else:
-                m.raw_input, m.raw_out = [full[0]], [full[1]]
-            if with_g:
-                m.raw_grad = [full[-1]]
+                m.raw_input, m.raw_out = full[0], full[1]
+            if hasattr(m, "metric"):
+                m.raw_grad = full[-1] if with_g else None
             srcs += stat
-            dsts.append(full)
-        flat_dsts = [t for f in dsts for t in f]
+            flat_dsts += full
+        static_in, static_tgt, graph = entry["in"], entry["tgt"], entry["graph"]
         for i, st in enumerate(range(0, total, bs)):
             with torch.no_grad():
                 static_in.copy_(inp[st:st + bs])
@@ -431,28 +491,26 @@ class HessianQuantCalibrator(QuantCalibrator):
         if want_shard is None:
             want_shard = os.environ.get("P4V_SHARD_CAPTURE", "0") == "1"
         shard_cap = False
-        if world > 1 and not self.sequential and want_shard:
-            per_rank = [sum(all_sizes.get(n, 0) for n in names if owner[n] == r) for r in range(world)]
-            during = sum(all_sizes.values()) / world          # every rank holds all modules x its share of sub-batches
-            shard_cap = (n_sub >= world and max(per_rank) + during <= self.cache_budget_bytes
-                         and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
-        if self.sequential:
-            groups = [[n] for n in mine]  # predecessors must already run quantised: one capture per module
-        elif shard_cap:
-            groups = [mine]               # one exchange, then everything this rank owns (possibly nothing)
-        else:
-            sizes = all_sizes if all_sizes is not None else self._estimate_cache_bytes(mine)
-            groups, cur, acc = [], [], 0
-            for n in mine:
-                if cur and acc + sizes.get(n, 0) > self.cache_budget_bytes:
-                    groups.append(cur)
+        budget = self._resolve_budget()
+
+        def plan(todo, budget_):
+            if self.sequential:
+                return [[n] for n in todo]  # predecessors must already run quantised: one capture per module
+            if shard_cap:
+                return [todo]               # one exchange, then everything this rank owns (possibly nothing)
+            sizes = all_sizes if all_sizes is not None else self._estimate_cache_bytes(todo)
+            out, cur, acc = [], [], 0
+            for n in todo:
+                if cur and acc + sizes.get(n, 0) > budget_:
+                    out.append(cur)
                     cur, acc = [], 0
                 cur.append(n)
                 acc += sizes.get(n, 0)
             if cur:
-                groups.append(cur)
-        t_cap = t_cal = 0.0
-        for grp in groups:
+                out.append(cur)
+            return out
+
+        def run_group(grp):
             t1 = time.time()
             if shard_cap:
                 self._capture(names, raw_pred_softmax, with_grad, stride=(rank, world))
@@ -479,12 +537,49 @@ class HessianQuantCalibrator(QuantCalibrator):
                     module.mode = "quant_forward" if self.sequential else "raw"
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
-            t_cap += t2 - t1
-            t_cal += time.time() - t2
+            return t2 - t1, time.time() - t2
+
+        if world > 1 and not self.sequential and want_shard:
+            per_rank = [sum(all_sizes.get(n, 0) for n in names if owner[n] == r) for r in range(world)]
+            during = sum(all_sizes.values()) / world          # every rank holds all modules x its share of sub-batches
+            shard_budget = self.cache_budget_bytes if self.cache_budget_bytes is not None else (200 << 30)   # NOT the locally
+            shard_cap = (n_sub >= world and max(per_rank) + during <= shard_budget                            # measured one
+                         and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
+        groups = plan(mine, budget)
+        t_cap = t_cal = 0.0
+        done = set()
+        while groups:
+            grp = groups.pop(0)
+            try:
+                dc, ds = run_group(grp)
+            except torch.cuda.OutOfMemoryError:
+                # the budget was an estimate (allocator fragmentation, another tenant on the GPU): drop this group's caches
+                # and scratch, halve the budget and re-plan what is not calibrated yet.  (Not possible mid-collective.)
+                if shard_cap or budget <= (4 << 30):
+                    raise
+                from .. import engine
+                for n in grp:
+                    m = self.wrapped_modules[n]
+                    if n not in done and not (hasattr(m, "calibrated") and not hasattr(m, "raw_out")):
+                        m.raw_input = m.raw_out = None
+                        if hasattr(m, "metric"):
+                            m.raw_grad = None
+                engine.release_workspace()
+                torch.cuda.empty_cache()
+                budget //= 2
+                print(f"[ptq4vit_amd] out of memory with {len(grp)} modules resident: retrying with a cache budget of {budget >> 30} GiB")
+                left = [n for n in grp if not (hasattr(self.wrapped_modules[n], "calibrated") and not hasattr(self.wrapped_modules[n], "raw_out"))]
+                left += [n for g in groups for n in g]
+                groups = plan(left, budget)
+                continue
+            done.update(grp)
+            t_cap += dc
+            t_cal += ds
         if world > 1 and not self.sequential:
             shard.exchange_intervals(self.wrapped_modules, owner)
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
+        self.net.__dict__["_p4v_calibrations"] = self.net.__dict__.get("_p4v_calibrations", 0) + 1
         self.timings = {"capture_s": t_cap, "search_s": t_cal, "total_s": time.time() - t0,
                         "modules": len(names), "owned": len(mine)}
         self.calibrated = True

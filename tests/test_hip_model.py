@@ -494,3 +494,70 @@ def test_full_size_proj_layer_against_the_oracle():
     if flips == 0:
         np.testing.assert_array_equal(w_iv.cpu().numpy(), want["w_interval"].reshape(-1))
         np.testing.assert_array_equal(a_iv.cpu().numpy(), want["a_interval"].reshape(-1))
+
+
+def _intervals(wrapped):
+    out = {}
+    for n, m in wrapped.items():
+        out[n] = [torch.as_tensor(getattr(m, a)).detach().clone() for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split")
+                  if getattr(m, a, None) is not None and not isinstance(getattr(m, a), (list, tuple))]
+    return out
+
+
+def test_cached_capture_graph_groups_and_oom_replan_reproduce_the_intervals():
+    """One network, calibrated four ways -- eager capture (first calibration), cached HIP graph (second calibration on),
+    a cache budget that forces several capture groups (all served by the one cached graph), and an out-of-memory error
+    in the middle of a group (budget halved, the rest re-planned) -- ends with bit-identical intervals."""
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    g, net, wrapped = _mini()
+    images = torch.from_numpy(g["images"]).cuda()
+
+    class Loader:
+        batch_size = images.shape[0]
+
+        def __iter__(self):
+            yield images, None
+
+    def calibrate(**attrs):
+        for m in wrapped.values():
+            m.mode = "raw"
+        cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2)
+        for k, v in attrs.items():
+            setattr(cal, k, v)
+        cal.batching_quant_calib()
+        torch.cuda.synchronize()
+        return cal, _intervals(wrapped)
+
+    _, first = calibrate()
+    assert not net.__dict__.get("_p4v_capture_graphs")                 # 4 sub-batches, first calibration: eager
+    _, second = calibrate()
+    graphs = net.__dict__["_p4v_capture_graphs"]
+    assert len(graphs) == 1                                              # recorded on the second calibration ...
+    entry = next(iter(graphs.values()))
+    _, third = calibrate()
+    assert next(iter(net.__dict__["_p4v_capture_graphs"].values())) is entry   # ... and replayed on the third
+    sizes = HessianQuantCalibrator(net, wrapped, Loader(), batch_size=2)._estimate_cache_bytes(list(wrapped))
+    cal4, fourth = calibrate(cache_budget_bytes=int(sum(sizes.values()) / 3.5))
+    assert next(iter(net.__dict__["_p4v_capture_graphs"].values())) is entry
+
+    # out of memory while the second module of a group is searched
+    calls = {"n": 0}
+    victim = list(wrapped)[1]
+    orig = wrapped[victim].calibration_step2
+
+    def boom():
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise torch.cuda.OutOfMemoryError("simulated")
+        return orig()
+    wrapped[victim].calibration_step2 = boom
+    try:
+        _, fifth = calibrate(search_streams=1, cache_budget_bytes=int(sum(sizes.values()) * 2))
+    finally:
+        del wrapped[victim].calibration_step2
+    assert calls["n"] == 2
+    for other in (second, third, fourth, fifth):
+        assert set(other) == set(first)
+        for n in first:
+            for a, b in zip(first[n], other[n]):
+                assert torch.equal(a, b), n
