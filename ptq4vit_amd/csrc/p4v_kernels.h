@@ -236,10 +236,25 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         float x[16];
         int blk[16];
         const bool per_k_blk = (p.blk_mode == 1 && p.blk_div2);
+        // a whole 16-element run of a K-contiguous, 16-byte aligned source: four dwordx4 loads (the scalar path below costs
+        // 16 load instructions per thread, each touching 32 cache lines per wave)
+        const bool vec = !p.conv && p.s_k == 1 && r < p.R && kc * 16 + 16 <= p.K && (p.s_r & 3) == 0 &&
+                         ((((unsigned long long)zbase) & 15) == 0);
+        if (vec) {
+            const v4f* src4 = reinterpret_cast<const v4f*>(zbase + (long)r * p.s_r + kc * 16);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            x[e] = pack_load(p, zbase, r, kc * 16 + e);
-            blk[e] = per_k_blk ? pack_blk(p, z, r, min(kc * 16 + e, p.K - 1)) : 0;
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = src4[q];
+                x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) blk[e] = per_k_blk ? pack_blk(p, z, r, kc * 16 + e) : 0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                x[e] = pack_load(p, zbase, r, kc * 16 + e);
+                blk[e] = per_k_blk ? pack_blk(p, z, r, min(kc * 16 + e, p.K - 1)) : 0;
+            }
         }
         const int blk0 = pack_blk(p, z, r, 0);
         const bool live = (r < p.R);

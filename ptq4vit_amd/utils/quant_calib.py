@@ -555,7 +555,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             except torch.cuda.OutOfMemoryError:
                 # the budget was an estimate (allocator fragmentation, another tenant on the GPU): drop this group's caches
                 # and scratch, halve the budget and re-plan what is not calibrated yet.  (Not possible mid-collective.)
-                if shard_cap or budget <= (4 << 30):
+                if shard_cap or len(grp) <= 1:      # a single module that does not fit cannot be split any further
                     raise
                 from .. import engine
                 for n in grp:
