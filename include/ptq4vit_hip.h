@@ -313,6 +313,12 @@ int p4v_matmul_quant_forward(const p4v_matmul_desc* desc, const float* d_A, cons
                              const float* d_B_interval, const float* d_split, float* d_out, void* d_workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Capture helper (reference utils/quant_calib.py:343-354 concatenates the hooked per-sub-batch tensors with torch.cat):
+ * ONE launch copies n device buffers into slice `index` of their destinations.  d_table is a DEVICE array of n triples
+ * {src pointer, dst base pointer, bytes}; dst = dst base + index * bytes; bytes must be a multiple of 4; max_bytes = the largest
+ * entry (sizes the grid).  Never synchronises. */
+int p4v_multi_copy(const int64_t* d_table, int32_t n, int64_t index, int64_t max_bytes, void* stream);
+
 /* Launch timing used by bench.py's roofline: while enabled on the CALLING THREAD, every sweep launch that thread
  * enqueues is bracketed by a HIP event pair on its stream; p4v_stats_get waits for those events and returns the
  * thread's totals.  Other threads / streams are not affected. */

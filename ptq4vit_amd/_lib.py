@@ -77,7 +77,7 @@ EXPORTS = [
     "p4v_amax_init_matmul", "p4v_matmul_search_A", "p4v_sos_search_split", "p4v_matmul_search_B",
     "p4v_amax_init_conv", "p4v_conv_search_w_channelwise", "p4v_conv_search_w_layerwise", "p4v_conv_search_a",
     "p4v_score_argmax_gather",
-    "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize",
+    "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize", "p4v_multi_copy",
     "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
     "p4v_debug_set_variant", "p4v_debug_set_tuning",
 ]
@@ -146,6 +146,8 @@ def load():
     lib.p4v_pack_plane_i8.argtypes = [C.POINTER(PlaneDesc), fp, fp, vp, vp]
     lib.p4v_export_quantize.restype = C.c_int
     lib.p4v_export_quantize.argtypes = [C.POINTER(ExportDesc), fp, fp, fp, vp, vp]
+    lib.p4v_multi_copy.restype = C.c_int
+    lib.p4v_multi_copy.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp]
     lib.p4v_debug_set_variant.restype = C.c_int
     lib.p4v_debug_set_variant.argtypes = [C.c_int, C.c_int]
     lib.p4v_debug_set_tuning.restype = C.c_int

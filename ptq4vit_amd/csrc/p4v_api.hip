@@ -94,7 +94,7 @@ thread_local long g_memo_hits = 0, g_memo_misses = 0;
 //   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
 //   8192 no candidate groups for the generic k_sweep
 //   16384 k_sweep6 without the separate launch of the last, partial wave of workgroups
-//   32768 no k_sweep7 (K >= 1024 sweeps on k_sweep2 / k_sweep2g)
+//   32768 no k_sweep7 (K >= 1024 sweeps on k_sweep2 / k_sweep2g)      65536 no k_sweep8 (single-k-tile sweeps on k_sweep2)
 //   1, 2: kernel debug flags (SweepParams::dbg)
 //   bit 30: route every int8 sweep through the generic k_sweep
 std::atomic<int> g_variant_word{0};
@@ -414,6 +414,36 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     return 0;
 }
 
+// k_sweep8: single k-tile (K <= 64) int8 sweep with the fixed operand's fragments in registers: q.k^T of every ViT / Swin
+bool sweep8_ok(const SweepParams& p, bool twin, int epi) {
+    return p.ktiles == 1 && !twin && (p.a_cs == 0) != (p.b_cs == 0) && epi != EPI_STORE && epi != EPI_FWD && epi != EPI_COS &&
+           !(g_variant & 65536);
+}
+
+template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)SW8_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2;
+    dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
+#define P4V_LAUNCH8(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep8<ROWS_FIXED, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep8<ROWS_FIXED, E>), grid, block, lds, c.st, p);                              \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH8(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH8(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH8(EPI_ABS); break;
+        default: P4V_LAUNCH8(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH8
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)
 template <bool TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds) {
 #define P4V_LAUNCH7(E)                                                                                         \
@@ -479,7 +509,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
-    if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
+    if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
+    else if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
     else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
     else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups);
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
@@ -1677,6 +1708,15 @@ int p4v_fake_quant(const float* d_x, int64_t rows, int64_t cols, const float* d_
     const long n = rows * cols;
     hipLaunchKernelGGL(k_fake_quant_rows, dim3((unsigned)std::min<long>(cdiv(n, 256), 65536)), dim3(256), 0,
                        (hipStream_t)stream, d_x, (long)rows, (long)cols, d_scales, (long)rows_per_scale, (float)lo, (float)hi, d_y);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int p4v_multi_copy(const int64_t* d_table, int32_t n, int64_t index, int64_t max_bytes, void* stream) {
+    if (!d_table || n <= 0 || index < 0 || max_bytes <= 0) return fail(P4V_ERR_INVALID, "p4v_multi_copy: bad argument");
+    static_assert(sizeof(long) == sizeof(int64_t), "table entries are 64-bit");
+    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>(cdiv(max_bytes / 16, 256 * 8), 256));
+    hipLaunchKernelGGL(k_multi_copy, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const long*)d_table, (long)index);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -341,6 +341,29 @@ __global__ void k_fake_quant_rows(const float* x, long rows, long cols, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// k_multi_copy: the capture pass's "append to the cache" for ALL hooked tensors of a sub-batch in one launch
+// ------------------------------------------------------------------------------------------
+// After each replay of the captured sub-batch pass ~280 tensors (inputs, outputs, output gradients of every wrapped
+// module) are copied from the graph's static buffers into slice i of their caches.  torch does that with one memcpy
+// per tensor (2 260 copy kernels per ViT-B calibration); here a device table {src, dst base, bytes} drives one grid:
+// blockIdx.y = tensor, blockIdx.x strides over its 16-byte words.  dst = dst base + index * bytes.
+__global__ __launch_bounds__(256) void k_multi_copy(const long* table, long index) {
+    const long* e = table + 3 * (long)blockIdx.y;
+    const char* src = reinterpret_cast<const char*>(e[0]);
+    const long bytes = e[2];
+    char* dst = reinterpret_cast<char*>(e[1]) + index * bytes;
+    if (((e[0] | (long)(size_t)dst | bytes) & 15) == 0) {
+        const long n = bytes >> 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+            reinterpret_cast<v4i*>(dst)[i] = reinterpret_cast<const v4i*>(src)[i];
+    } else {                                             // fp32 tensors: 4-byte granularity is always possible
+        const long n = bytes >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+            reinterpret_cast<int*>(dst)[i] = reinterpret_cast<const int*>(src)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_export: integer image of a calibrated operand (the reference's utils/integer.py formats)
 // ------------------------------------------------------------------------------------------
 // One kernel for every export format: the source is a logical 4-D tensor [d0][d1][d2][d3] read through element
@@ -936,6 +959,192 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     if constexpr (STORES) return;
     // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
+        const int cc = c_lo + i / 8, wv = i % 8;
+        p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep8: k_sweep2 for K <= 64 (ONE k-tile: the q.k^T matmuls of every ViT / DeiT / Swin, head_dim <= 64)
+// ------------------------------------------------------------------------------------------
+// With a single k-tile a candidate is one ring step of k_sweep2: 16 KB of LDS-DMA, a barrier, 6 fragment reads, 4 MFMAs and a
+// 32-element epilogue per lane -- and the step time is the DMA latency divided by the three tiles the ring keeps in flight
+// (measured: 1.8 us per candidate and workgroup, two workgroups per CU; the matrix pipe idles).  Here the FIXED operand's
+// fragments (8 or 16 VGPRs) are loaded once and stay in registers, only the candidate-expanded operand streams (8 KB per
+// candidate: one piece per wave), and the ring is 8 candidates deep: half the bytes, 2.3x the steps per DMA latency.
+// Same tile (128 x 128, 8 waves x (64 x 32)), same epilogue, same partial-sum table as k_sweep2.
+static constexpr int SW8_NS = 8;
+
+template <bool ROWS_FIXED, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = reinterpret_cast<float*>(smem + SW8_NS * SW2_TILE);   // [per][8 waves]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int g = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int mt = t % p.mtiles, nt = t / p.mtiles;
+    const int z = blockIdx.y;
+    const int m0 = mt * SW_BM, n0 = nt * SW_BN;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo;
+
+    // ---- candidate-invariant epilogue operands (as k_sweep2) --------------------------------------------------------------
+    float u[2][16], w[2][16];
+    const int n = n0 + wc * 32 + l31;
+    const bool ncol_ok = n < p.N;
+    const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
+    const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
+    {
+        const int nc = min(n, p.N - 1);
+        const long ncol_off = (long)z * p.o_zs + (long)(nc / p.o_ninner) * p.o_nbs + (long)(nc % p.o_ninner) * p.o_ns;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mc = min(m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.M - 1);
+                const long idx = ncol_off + (long)(mc / p.o_inner) * p.o_bs + (long)(mc % p.o_inner) * p.o_ms;
+                u[i][r] = p.O[idx];
+                w[i][r] = p.Wt[idx];   // host passes Wt = O when the metric has no weight tensor
+            }
+        const int wm = p.wt_mode;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const bool ok = ncol_ok && m < p.M;
+                const float o = u[i][r], gw = w[i][r];
+                float wv;
+                if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+                u[i][r] = ok ? o - bias_n : 0.0f;
+                w[i][r] = ok ? wv : 0.0f;
+            }
+    }
+    const int nw0 = n0 + wc * 32;
+    const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
+    float* s1tab = res + per * 8;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+
+    // ---- the fixed operand's fragments: registers for the whole sweep (ldk = 64: one k-tile) ----------------------------------
+    v4i fx[2][2];                                        // [32-row block (row side only)][k-half]
+    if (ROWS_FIXED) {
+        const char* gA = (const char*)p.A + (long)z * p.a_zs + (long)(m0 + wr * 64 + l31) * SW_BKB + g * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) fx[i][h] = *reinterpret_cast<const v4i*>(gA + i * 32 * SW_BKB + h * 32);
+    } else {
+        const char* gB = (const char*)p.B + (long)z * p.b_zs + (long)(n0 + wc * 32 + l31) * SW_BKB + g * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { fx[0][h] = *reinterpret_cast<const v4i*>(gB + h * 32); fx[1][h] = fx[0][h]; }
+    }
+
+    // ---- the expanded operand streams: wave `wid` moves rows [16 wid, 16 wid + 16) of the 128-row tile, one candidate per stage ---
+    const int ld_row = wid * 16 + (lane >> 2);
+    const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    const unsigned voff = (unsigned)(ld_row * SW_BKB + ld_chunk * 16);
+    const long t_cs = ROWS_FIXED ? p.b_cs : p.a_cs;
+    const char* cur = ROWS_FIXED ? (const char*)p.B + (long)z * p.b_zs + (long)n0 * SW_BKB + (long)c_lo * p.b_cs
+                                 : (const char*)p.A + (long)z * p.a_zs + (long)m0 * SW_BKB + (long)c_lo * p.a_cs;
+    const int lds_wave = wid * 1024;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        glds16(cur + voff, smem + stage * SW2_TILE + lds_wave);
+        cur += t_cs;
+    };
+
+    v16i acc[2];
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // a candidate is ONE k-tile: its first MFMAs start from zero
+
+    // swizzled fragment addresses of the streamed tile: row side two 32-row blocks, column side one
+    const int rs0 = ROWS_FIXED ? wc * 32 + l31 : wr * 64 + l31, rs1 = rs0 + 32;
+    const int ss0 = (rs0 >> 2) & 3, ss1 = (rs1 >> 2) & 3;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned a00 = lds0 + rs0 * 64 + ((g ^ ss0) << 4), a01 = lds0 + rs0 * 64 + (((2 + g) ^ ss0) << 4);
+    const unsigned a10 = lds0 + rs1 * 64 + ((g ^ ss1) << 4), a11 = lds0 + rs1 * 64 + (((2 + g) ^ ss1) << 4);
+#define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    struct Fr { v4i t00, t01, t10, t11; };               // [block][k-half] of the streamed operand (column side: block 0 only)
+    constexpr int NRD = ROWS_FIXED ? 2 : 4;
+    auto read_fr = [&](Fr& f, auto stage_c) __attribute__((always_inline)) {
+        constexpr int SO = decltype(stage_c)::value * SW2_TILE;
+        const unsigned b00 = a00, b01 = a01, b10 = a10, b11 = a11;   // (locals: clang rejects captured names that appear only in asm operands)
+        P4V_DSR(f.t00, b00, SO); P4V_DSR(f.t01, b01, SO);
+        if constexpr (!ROWS_FIXED) { P4V_DSR(f.t10, b10, SO); P4V_DSR(f.t11, b11, SO); }
+    };
+
+    const int npre = min(SW8_NS - 1, ncand);
+    for (int i = 0; i < npre; ++i) issue(i);
+    Fr fa, fb;
+    int c = c_lo;
+    // step `it` (compile-time stage): `cur` holds candidate it (read during step it-1).  Prove candidate it+1 landed (own piece
+    // waited for, then the barrier), refill the stage of candidate it-1 with candidate it+7, start the reads of it+1, run the
+    // MFMAs and the epilogue of candidate it.
+    auto step = [&](int it, auto stage_c, Fr& curf, Fr& nxt) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        if (it + SW8_NS - 1 < ncand) wait_vmcnt<SW8_NS - 2>(); else wait_vmcnt<0>();   // (tail: no younger pieces are counted on)
+        __builtin_amdgcn_s_barrier();
+        if (it + SW8_NS - 1 < ncand) issue((ST + SW8_NS - 1) % SW8_NS);
+        if (it + 1 < ncand) {
+            read_fr(nxt, std::integral_constant<int, (ST + 1) % SW8_NS>{});
+            __builtin_amdgcn_s_waitcnt(0xC07F | (NRD << 8));
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        asm volatile("" : "+v"(curf.t00), "+v"(curf.t01) :: "memory");
+        if (!ROWS_FIXED) asm volatile("" : "+v"(curf.t10), "+v"(curf.t11));
+        if (ROWS_FIXED) {      // A (rows) in registers, B (columns) streamed
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][0], curf.t00, zero16, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][0], curf.t00, zero16, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][1], curf.t01, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][1], curf.t01, acc[1], 0, 0, 0);
+        } else {               // A (rows) streamed, B (columns) in registers
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t00, fx[0][0], zero16, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t10, fx[0][0], zero16, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t01, fx[0][1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t11, fx[0][1], acc[1], 0, 0, 0);
+        }
+        // ---- fused similarity epilogue of candidate c: one float per wave -----------------------------------------------
+        const float s1 = s1tab[(c - c_lo) * 8 + wid];
+        v2f sum2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const v2f a = {(float)acc[i][r], (float)acc[i][r + 1]};
+                const v2f uu = {u[i][r], u[i][r + 1]};
+                const v2f ww = {w[i][r], w[i][r + 1]};
+                const v2f d = uu - a * s1;
+                if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                else if (EPI == EPI_SQ) sum2 = d * d + sum2;
+                else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
+                else sum2 = (ww * d) * d + sum2;
+            }
+        const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
+        if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
+        ++c;
+    };
+    if (ncand >= SW8_NS) wait_vmcnt<SW8_NS - 2>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_fr(fa, std::integral_constant<int, 0>{});
+    for (int it = 0; it < ncand; it += SW8_NS) {
+        step(it, std::integral_constant<int, 0>{}, fa, fb);
+        if (it + 1 < ncand) step(it + 1, std::integral_constant<int, 1>{}, fb, fa);
+        if (it + 2 < ncand) step(it + 2, std::integral_constant<int, 2>{}, fa, fb);
+        if (it + 3 < ncand) step(it + 3, std::integral_constant<int, 3>{}, fb, fa);
+        if (it + 4 < ncand) step(it + 4, std::integral_constant<int, 4>{}, fa, fb);
+        if (it + 5 < ncand) step(it + 5, std::integral_constant<int, 5>{}, fb, fa);
+        if (it + 6 < ncand) step(it + 6, std::integral_constant<int, 6>{}, fa, fb);
+        if (it + 7 < ncand) step(it + 7, std::integral_constant<int, 7>{}, fb, fa);
+    }
+#undef P4V_DSR
+    __syncthreads();
+    for (int i = tid; i < ncand * 8; i += 512) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }

@@ -498,6 +498,15 @@ def export_quantize(src, *, mode, scale1, scale1_stride, scale1_div, lo1=0, hi1=
     return out
 
 
+def multi_copy(table, n, index, max_bytes, dev):
+    """One launch: for each of the `n` {src, dst base, bytes} triples of the device int64 `table`, copy `bytes` from src
+    to dst base + index * bytes (p4v_multi_copy: the capture pass appends a sub-batch to every cache at once)."""
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.p4v_multi_copy(ptr(table), int(n), int(index), int(max_bytes), stream_ptr(dev))
+    _lib.check(rc, "p4v_multi_copy")
+
+
 def stats_enable(flag):
     """Launch timing of the sweep kernels on the CALLING thread (bench.py roofline)."""
     _lib.load().p4v_stats_enable(int(bool(flag)))

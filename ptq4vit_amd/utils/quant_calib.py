@@ -99,6 +99,39 @@ def _concat(module, with_grad):
         module.raw_grad = cat(module.raw_grad)
 
 
+def _cache_like(t, n_sub):
+    """Cache for `n_sub` sub-batch pieces shaped like `t`, concatenated on dim 0 -- with t's memory layout when t is a dense
+    permutation whose batch dim is outermost in memory (e.g. the k.transpose(-2, -1) view the attention passes to matmul1):
+    sub-batch i is then ONE contiguous block of the cache, and the consumer reads the view in place as before."""
+    shape = (n_sub * t.shape[0],) + tuple(t.shape[1:])
+    if t.is_contiguous() or t.dim() < 2:
+        return torch.empty(shape, dtype=t.dtype, device=t.device)
+    order = sorted(range(t.dim()), key=lambda k: (-t.stride(k), k))           # outermost -> innermost in memory
+    dense, expect = order[0] == 0, 1
+    for k in reversed(order):
+        dense &= t.stride(k) == expect
+        expect *= t.shape[k]
+    if not dense:
+        return torch.empty(shape, dtype=t.dtype, device=t.device)
+    strides, acc = [0] * t.dim(), 1
+    for k in reversed(order):
+        strides[k] = acc
+        acc *= shape[k]
+    return torch.empty_strided(shape, strides, dtype=t.dtype, device=t.device)
+
+
+def _same_dense_block(cache, t):
+    """True when piece i of `cache` (rows [i*t.shape[0], (i+1)*t.shape[0])) and `t` are the same dense memory block layout,
+    i.e. a flat copy of t's storage block is the copy of the piece."""
+    if t.element_size() != 4 or cache.dtype != t.dtype:
+        return False
+    if tuple(cache.stride()[1:]) != tuple(t.stride()[1:]) or cache.stride(0) != t.stride(0):
+        return False
+    # dense: the block spans exactly numel elements
+    span = 1 + sum((t.shape[k] - 1) * t.stride(k) for k in range(t.dim()))
+    return span == t.numel() and t.stride(0) == max(t.stride())
+
+
 class QuantCalibrator:
     """Reference quant_calib.py:9-171: forward-mode calibration (calibration_step1 / calibration_step2(x))."""
 
@@ -341,7 +374,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             m = self.wrapped_modules[n]
             stat, with_g = entry["statics"][n]
             # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
-            full = [torch.empty((n_sub * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in stat]
+            full = [_cache_like(t, n_sub) for t in stat]
             if isinstance(m, MinMaxQuantMatMul):
                 m.raw_input, m.raw_out = [full[0], full[1]], full[2]
             else:
@@ -350,13 +383,27 @@ class HessianQuantCalibrator(QuantCalibrator):
                 m.raw_grad = full[-1] if with_g else None
             srcs += stat
             flat_dsts += full
+        # every (static tensor -> slice i of its cache) whose memory is one dense block goes through ONE launch per
+        # sub-batch (p4v_multi_copy); anything else (overlapping / gapped views) keeps torch's copy
+        from .. import engine
+        block, other = [], []
+        for d, t in zip(flat_dsts, srcs):
+            (block if _same_dense_block(d, t) else other).append((d, t))
+        table = None
+        if block:
+            rows = [[t.data_ptr(), d.data_ptr(), t.numel() * t.element_size()] for d, t in block]
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            max_bytes = max(r[2] for r in rows)
         static_in, static_tgt, graph = entry["in"], entry["tgt"], entry["graph"]
         for i, st in enumerate(range(0, total, bs)):
             with torch.no_grad():
                 static_in.copy_(inp[st:st + bs])
             static_tgt.copy_(raw_pred_softmax[st:st + bs])
             graph.replay()
-            torch._foreach_copy_([d[i * s.shape[0]:(i + 1) * s.shape[0]] for d, s in zip(flat_dsts, srcs)], srcs)
+            if table is not None:
+                engine.multi_copy(table, len(block), i, max_bytes, dev)
+            for d, t in other:
+                d[i * t.shape[0]:(i + 1) * t.shape[0]].copy_(t)
         return True
 
     def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad, stride=None):

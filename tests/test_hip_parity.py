@@ -372,3 +372,26 @@ def test_large_k_sweep_matches_the_128_tile_sweeps(eng):
         assert torch.equal(a, b), "k_sweep7 is not run-to-run deterministic"
     assert_scores_close(new[2].cpu().numpy(), old[2].cpu().numpy(), rtol=2e-5, what="k_sweep7 vs k_sweep2")
     assert torch.equal(new[3], old[3]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
+
+
+def test_single_ktile_sweep_matches_the_streaming_sweep(eng):
+    """A/B at ViT-B q.k^T geometry (4 images x 12 heads, 197 x 64 x 197): k_sweep8 (fixed operand in registers, 8-deep ring)
+    against k_sweep2 (variant 65536), both searches -- identical selections, tables equal to summation-order noise (the
+    epilogue arithmetic is the same code)."""
+    A, B, out, grad = _mk_attention(23, 4, 12, 197, 64, "qk")
+    hp = dict(A_bit=8, B_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1)
+    args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(grad), want_scores=True)
+    new = eng.matmul_calibrate(**args, **hp)
+    again = eng.matmul_calibrate(**args, **hp)
+    eng.debug_variant(65536)
+    try:
+        old = eng.matmul_calibrate(**args, **hp)
+    finally:
+        eng.debug_variant(0)
+    torch.cuda.synchronize()
+    for a, b in zip(new, again):
+        if a is not None:
+            assert torch.equal(a, b), "k_sweep8 is not run-to-run deterministic"
+    assert_scores_close(new[3].cpu().numpy(), old[3].cpu().numpy(), rtol=1e-6, what="k_sweep8 vs k_sweep2")
+    assert torch.equal(new[4], old[4]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])

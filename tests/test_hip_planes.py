@@ -222,3 +222,27 @@ def test_minivit_quantised_logits_vs_reference():
     print(f"[quant_logits] fp32 fake-quant path vs reference: {err_fq:.2e}")
     assert err_fq <= 2e-3
     assert any(isinstance(m, MinMaxQuantConv2d) for m in wrapped.values())
+
+
+# ---- the capture pass's append: many (tensor -> slot of its cache) copies in one launch -----------------------------------
+@pytest.mark.parametrize("index", [0, 2])
+def test_multi_copy_appends_every_block_in_one_launch(eng, index):
+    """p4v_multi_copy: block t of the table goes to dst base + index * bytes, bit-exact, nothing else written; sizes that
+    are whole 16-byte runs, ragged (4-byte path), one element, and a source whose address is only 4-byte aligned."""
+    g = torch.Generator().manual_seed(11)
+    sizes = [4096, 1000003, 1, 7, 16 * 333, 250001]
+    backing = torch.randn(sum(sizes) + len(sizes) + 1, generator=g).cuda()
+    srcs, off = [], 1                                     # start 4 bytes into the allocation: not 16-byte aligned
+    for s in sizes:
+        srcs.append(backing[off:off + s])
+        off += s + 1
+    dsts = [torch.full((3 * s,), -7.0, device="cuda") for s in sizes]
+    rows = [[s.data_ptr(), d.data_ptr(), s.numel() * 4] for s, d in zip(srcs, dsts)]
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    eng.multi_copy(table, len(rows), index, max(r[2] for r in rows), torch.device("cuda:0"))
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        n = s.numel()
+        assert torch.equal(d[index * n:(index + 1) * n], s)
+        rest = torch.cat([d[:index * n], d[(index + 1) * n:]])
+        assert bool((rest == -7.0).all())
