@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="also run BASELINE config 0 (DeiT-tiny/224 BasePTQ x 4 images) through the CPU oracle, in full")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--capture-batch", type=int, default=0,
+                    help="images per capture pass of the timed steps (0 = batch_size = 4, the reference's passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -281,10 +283,11 @@ def main():
     loader = SyntheticLoader(images)
     shapes = probe_shapes(net, wrapped, images[:1])
 
-    def one_step(search_streams=None):
+    def one_step(search_streams=None, capture_batch=None):
         for m in wrapped.values():
             m.mode = "raw"
-        cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4)
+        cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4,
+                                     capture_batch_size=capture_batch or args.capture_batch or None)
         if search_streams:
             cal.search_streams = search_streams
         cal.batching_quant_calib()
@@ -317,6 +320,14 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the same calibration with ONE capture pass over all images (opt-in `capture_batch_size`: not part of `value`)
+    with quiet:
+        one_step(capture_batch=args.calib)
+        sync()
+        t_big = time.time()
+        cal_big = one_step(capture_batch=args.calib)
+        sync()
+        big_s = time.time() - t_big
     n_mod = len(wrapped)
     value = n_mod * args.steps / elapsed
 
@@ -396,6 +407,12 @@ def main():
                                    "HessianQuantCalibrator.batching_quant_calib (capture + search)",
                        "global_batch": args.calib, "parallelism": f"layers sharded over {world} GPU(s)"},
             "breakdown": {"capture_s": t["capture_s"], "search_s": t["search_s"]},
+            # images per capture pass of the timed steps (batch_size = 4: the reference's passes), and the same calibration
+            # with one pass over all images (opt-in, utils/quant_calib.py: see the caveat on raw_grad there)
+            "capture": {"images_per_pass": cals[-1]._capture_bs(),
+                        "opt_in_single_pass": {"images_per_pass": cal_big._capture_bs(), "calibration_wall_clock_s": big_s,
+                                               "capture_s": cal_big.timings["capture_s"],
+                                               "search_s": cal_big.timings["search_s"]}},
             # the timed steps re-calibrate the SAME network object: from its second calibration on the capture pass is replayed
             # from a HIP graph kept with the network (utils/quant_calib.py); the first calibration in this process, untimed:
             "first_calibration_s": cold,

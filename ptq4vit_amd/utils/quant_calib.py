@@ -193,9 +193,18 @@ class HessianQuantCalibrator(QuantCalibrator):
     """Reference quant_calib.py:203-378."""
 
     def __init__(self, net, wrapped_modules, calib_loader, sequential=False, batch_size=1,
-                 cache_budget_bytes=None):
+                 cache_budget_bytes=None, capture_batch_size=None):
         super().__init__(net, wrapped_modules, calib_loader, sequential=sequential)
         self.batch_size = batch_size
+        # images per capture pass; None = `batch_size`, the reference's passes (quant_calib.py:333-339).  A larger value
+        # (a multiple of batch_size) runs fewer, larger passes -- a pass of 4 images is launch-bound on this GPU (8 ms for
+        # 2 ms of arithmetic on ViT-B) -- with the KL loss weighted per sample by 1 / (rows of the reference sub-batch the
+        # sample belongs to), i.e. what "batchmean" over that sub-batch divides by: raw_input / raw_out and, for a given
+        # target distribution, raw_grad are those of the reference's passes up to GEMM rounding.  It is NOT the default
+        # because of what the target is: with every module in raw mode the prediction equals the target up to rounding, so
+        # raw_grad of a non-sequential calibration is rounding noise of the (batch_size-image pass) - (whole-batch pass)
+        # logit difference, in the reference as here, and its realisation changes with the shape of the passes.
+        self.capture_batch_size = capture_batch_size
         # bytes of captured tensors kept resident at a time; None = what the GPU has free minus head room for the search
         # workspaces and the capture pass itself (288 GB of HBM3E hold the 207 GB of Swin-B/384 x 128 images in ONE group;
         # every further group repeats the whole capture pass)
@@ -215,6 +224,30 @@ class HessianQuantCalibrator(QuantCalibrator):
         return max(8 << 30, int(free) - self.SEARCH_HEADROOM_BYTES)
 
     # ---- capture ------------------------------------------------------------------------------------
+    def _ref_bs(self):
+        return getattr(self, "batch_size", None) or self.calib_loader.batch_size
+
+    def _capture_bs(self):
+        """Images per capture pass: the reference sub-batch, or the multiple of it asked for by `capture_batch_size`."""
+        bs = self._ref_bs()
+        cbs = getattr(self, "capture_batch_size", None)
+        return bs if not cbs else max(bs, (int(cbs) // bs) * bs)
+
+    @staticmethod
+    def _kl_loss(pred, target, inv_n):
+        """Sum over samples of KL(target || softmax(pred)) / n(sample), n = rows of the reference sub-batch the sample is
+        in: the gradients of the reference's per-sub-batch F.kl_div(..., reduction="batchmean") (quant_calib.py:333-339)
+        for all of its sub-batches at once."""
+        kl = F.kl_div(F.log_softmax(pred, dim=-1), target, reduction="none").sum(dim=-1)
+        return (kl * inv_n).sum()
+
+    @staticmethod
+    def _inv_rows(total, st, n, ref_bs, dev):
+        """1 / (rows of the reference sub-batch) for samples st .. st+n of a loader batch of `total` images."""
+        j = torch.arange(st, st + n, device=dev)
+        rows = torch.clamp(total - (j // ref_bs) * ref_bs, max=ref_bs)
+        return 1.0 / rows.to(torch.float32)
+
     def _raw_pred_softmax(self):
         dev = _dev_of(self.net)
         with torch.no_grad():
@@ -228,7 +261,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         with hooks on `names` only.  `stride = (r, w)`: run only the sub-batches i with i % w == r and leave the
         per-sub-batch pieces on the modules as lists (sub-batch sharded capture, shard.exchange_captures)."""
         dev = _dev_of(self.net)
-        bs = getattr(self, "batch_size", None) or self.calib_loader.batch_size
+        bs = self._capture_bs()
         for n in names:
             m = self.wrapped_modules[n]
             m.raw_input = m.raw_out = None
@@ -287,11 +320,11 @@ class HessianQuantCalibrator(QuantCalibrator):
                 if hasattr(m, "metric"):
                     m.raw_grad = None
 
+        inv_n = torch.full((bs,), 1.0 / min(bs, self._ref_bs()), device=dev)      # graph passes are whole sub-batches
+
         def one_pass(x, tgt):
             x.grad = None
-            pred = self.net(x)
-            loss = F.kl_div(F.log_softmax(pred, dim=-1), tgt, reduction="batchmean")
-            loss.backward()
+            self._kl_loss(self.net(x), tgt, inv_n).backward()
 
         hooks = []
         for m in mods.values():
@@ -320,7 +353,8 @@ class HessianQuantCalibrator(QuantCalibrator):
                 if with_g:
                     stat.append(m.raw_grad[0])
                 statics[n] = (stat, with_g)
-            entry = {"graph": graph, "in": static_in, "tgt": static_tgt, "statics": statics}
+            entry = {"graph": graph, "in": static_in, "tgt": static_tgt, "statics": statics,
+                     "inv_n": inv_n}          # read by every replay: must live as long as the graph
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[ptq4vit_amd] graph capture unavailable ({type(e).__name__}: {e}); eager capture")
         finally:
@@ -417,9 +451,8 @@ class HessianQuantCalibrator(QuantCalibrator):
                 inp_ = inp[st:st + bs].to(dev)
                 if with_grad:
                     inp_ = inp_.detach().requires_grad_(True)     # root of the autograd graph (parameters are frozen)
-                    pred = self.net(inp_)
-                    loss = F.kl_div(F.log_softmax(pred, dim=-1), raw_pred_softmax[st:st + bs], reduction="batchmean")
-                    loss.backward()
+                    inv_n = self._inv_rows(total, st, inp_.shape[0], self._ref_bs(), dev)
+                    self._kl_loss(self.net(inp_), raw_pred_softmax[st:st + bs], inv_n).backward()
                 else:
                     with torch.no_grad():
                         self.net(inp_)
@@ -532,7 +565,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         # (shard.exchange_captures).  Whether that collective is entered must be the SAME decision on every rank, so it
         # is derived from rank-invariant quantities only (all_sizes covers every module on every rank; a rank that owns
         # nothing, or whose own cache would need several groups, decides exactly like the others).
-        bs_ = getattr(self, "batch_size", None) or self.calib_loader.batch_size
+        bs_ = self._capture_bs()
         n_sub = sum(-(-inp.shape[0] // bs_) for inp, _ in self.calib_loader)
         want_shard = getattr(self, "shard_capture", None)
         if want_shard is None:

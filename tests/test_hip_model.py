@@ -321,7 +321,7 @@ def test_graph_capture_equals_eager_capture(model, side, kw):
     x = torch.randn(8, 3, side, side, generator=torch.Generator().manual_seed(5)).to(dev)
     caps = []
     for use_graph in (True, False):
-        cal = HessianQuantCalibrator(net, wrapped, L(x), sequential=False, batch_size=2)
+        cal = HessianQuantCalibrator(net, wrapped, L(x), sequential=False, batch_size=2, capture_batch_size=2)
         cal.use_graph = use_graph
         sm = cal._raw_pred_softmax()
         cal._capture(list(wrapped), sm, True)
@@ -521,7 +521,7 @@ def test_cached_capture_graph_groups_and_oom_replan_reproduce_the_intervals():
     def calibrate(**attrs):
         for m in wrapped.values():
             m.mode = "raw"
-        cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2)
+        cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2, capture_batch_size=2)
         for k, v in attrs.items():
             setattr(cal, k, v)
         cal.batching_quant_calib()
@@ -561,3 +561,44 @@ def test_cached_capture_graph_groups_and_oom_replan_reproduce_the_intervals():
         for n in first:
             for a, b in zip(first[n], other[n]):
                 assert torch.equal(a, b), n
+
+
+def test_capture_pass_size_does_not_change_the_captured_tensors():
+    """DeiT-tiny/224, 14 images (ragged last reference sub-batch): capture passes of 8 images (`capture_batch_size`,
+    opt-in) against the reference's passes of batch_size = 4 (quant_calib.py:309-356) for a FIXED random target
+    distribution (with the network's own prediction as the target, raw_grad is rounding noise in the reference as here):
+    raw_input / raw_out / raw_grad agree to GEMM rounding."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    net = models.get_net("deit_tiny_patch16_224", seed=2, device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.randn(14, 3, 224, 224, generator=torch.Generator().manual_seed(4)).cuda()
+    target = torch.softmax(torch.randn(14, 1000, generator=torch.Generator().manual_seed(5)), dim=-1).cuda()
+
+    class Loader:
+        batch_size = 14
+
+        def __iter__(self):
+            yield images, None
+
+    caps = []
+    for cbs in (None, 8):
+        cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4, capture_batch_size=cbs)
+        assert cal._capture_bs() == (8 if cbs else 4)
+        cal._capture(list(wrapped), target, True)
+        torch.cuda.synchronize()
+        cap = {}
+        for n, m in wrapped.items():
+            ri = m.raw_input if isinstance(m.raw_input, list) else [m.raw_input]
+            cap[n] = [t.clone() for t in ri] + [m.raw_out.clone(), m.raw_grad.clone()]
+        caps.append(cap)
+    worst = 0.0
+    for n in caps[0]:
+        for a, b in zip(caps[0][n], caps[1][n]):
+            assert a.shape == b.shape and float(a.abs().max()) > 0
+            worst = max(worst, float((a - b).abs().max() / a.abs().max()))
+    print(f"[capture] passes of 8 vs 4 images, fixed target: captured tensors within {worst:.1e} of the tensor maximum")
+    assert worst <= 5e-5, worst

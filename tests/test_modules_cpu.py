@@ -177,7 +177,8 @@ def test_one_pass_capture_equals_reference_capture(budget):
             _m.calibrated = True
         m.calibration_step2 = rec
     cal = quant_calib.HessianQuantCalibrator(net, wrapped, _Loader(torch.from_numpy(g["images"])), sequential=False,
-                                             batch_size=4, cache_budget_bytes=budget)
+                                             batch_size=4, cache_budget_bytes=budget,
+                                             capture_batch_size=4)      # the reference's passes: bit-identical
     cal.batching_quant_calib()
     assert all(m.mode == "quant_forward" for m in wrapped.values())
     for n in wrapped:
@@ -190,6 +191,39 @@ def test_one_pass_capture_equals_reference_capture(budget):
             np.testing.assert_array_equal(ri.numpy(), g[f"{key}::x"])
         np.testing.assert_array_equal(ro.numpy(), g[f"{key}::out"])
         np.testing.assert_array_equal(rg.numpy(), g[f"{key}::grad"])
+
+
+@pytest.mark.parametrize("n_images", [8, 7])
+def test_large_capture_passes_equal_the_reference_sub_batches(n_images):
+    """`capture_batch_size` (opt-in: fewer, larger capture passes; per-sample KL weights 1 / rows of the reference
+    sub-batch) records the tensors of the reference's passes of `batch_size` images (quant_calib.py:309-356, loss :333-339)
+    up to the rounding of differently blocked GEMMs -- also when the last reference sub-batch is ragged (7 images at
+    batch_size 4: its three samples get gradients divided by 3, not 4).  The target distribution here is NOT the network's
+    own prediction (for which the gradients are rounding noise, see HessianQuantCalibrator.__init__) but a fixed random
+    one, so that raw_grad is a well-defined quantity."""
+    g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
+    kw = json.loads(str(g["model_kwargs"]))
+    net = _mini_net(kw)
+    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.from_numpy(g["images"])
+    images = torch.cat([images, images.flip(0)])[:n_images]
+    target = torch.softmax(torch.randn(n_images, kw["num_classes"], generator=torch.Generator().manual_seed(3)), dim=-1)
+    caps = []
+    for cbs in (None, 8):
+        cal = quant_calib.HessianQuantCalibrator(net, wrapped, _Loader(images), sequential=False, batch_size=4,
+                                                 capture_batch_size=cbs)
+        assert cal._capture_bs() == (8 if cbs else 4)
+        cal._capture(list(wrapped), target, True)
+        cap = {}
+        for n, m in wrapped.items():
+            ri = m.raw_input if isinstance(m.raw_input, list) else [m.raw_input]
+            cap[n] = [t.clone() for t in ri] + [m.raw_out.clone(), m.raw_grad.clone()]
+        caps.append(cap)
+    for n in caps[0]:
+        for a, b in zip(caps[0][n], caps[1][n]):
+            assert a.shape == b.shape
+            scale = float(a.abs().max())
+            assert scale > 0 and float((a - b).abs().max()) <= 2e-6 * scale, n
 
 
 def test_fold_bn_into_conv_matches_conv_then_bn():

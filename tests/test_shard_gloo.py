@@ -134,7 +134,8 @@ def _capture_worker(rank, world, port, q, sharded=True):
             _m.calibrated = True
             _m.w_interval = torch.zeros(1)
         m.calibration_step2 = rec
-    cal = quant_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2)   # 4 sub-batches
+    cal = quant_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2,
+                                             capture_batch_size=2)   # 4 sub-batches
     cal.shard_capture = sharded          # opt-in: sub-batch sharded capture + exchange_captures; default = replicated capture
     with contextlib.redirect_stdout(io.StringIO()):
         cal.batching_quant_calib()
