@@ -393,8 +393,8 @@ class HessianQuantCalibrator(QuantCalibrator):
             return False
         cache = self.net.__dict__.setdefault("_p4v_capture_graphs", {})
         key = self._graph_key(dev, bs, inp)
-        entry = cache.get(key)
-        if entry is None:
+        lanes = cache.get(key)
+        if lanes is None:
             seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
             if not (use_graph or n_sub >= 24 or seen_before):
                 return False
@@ -402,42 +402,67 @@ class HessianQuantCalibrator(QuantCalibrator):
             if entry is None:
                 return False
             cache.clear()                      # one geometry per network at a time: a graph pins its activations' memory
-            cache[key] = entry
-        srcs, flat_dsts = [], []
-        for n in names:
-            m = self.wrapped_modules[n]
-            stat, with_g = entry["statics"][n]
-            # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
-            full = [_cache_like(t, n_sub) for t in stat]
-            if isinstance(m, MinMaxQuantMatMul):
-                m.raw_input, m.raw_out = [full[0], full[1]], full[2]
-            else:
-                m.raw_input, m.raw_out = full[0], full[1]
-            if hasattr(m, "metric"):
-                m.raw_grad = full[-1] if with_g else None
-            srcs += stat
-            flat_dsts += full
-        # every (static tensor -> slice i of its cache) whose memory is one dense block goes through ONE launch per
-        # sub-batch (p4v_multi_copy); anything else (overlapping / gapped views) keeps torch's copy
+            lanes = cache[key] = [entry]
+        # A pass at 4 images is a chain of ~1500 kernels of a few microseconds each: the GPU is mostly idle while it runs.
+        # `capture_lanes` instances of the graph (own static tensors each) replay different sub-batches on different
+        # streams at the same time; every sub-batch still runs exactly the recorded kernels, so the caches do not change.
+        want = int(getattr(self, "capture_lanes", None) or os.environ.get("P4V_CAPTURE_LANES", "2"))
+        while len(lanes) < max(1, min(want, n_sub)):
+            entry = self._build_graph(dev, bs, inp, raw_pred_softmax)
+            if entry is None:
+                break
+            lanes.append(entry)
+        n_lanes = max(1, min(want, n_sub, len(lanes)))
         from .. import engine
-        block, other = [], []
-        for d, t in zip(flat_dsts, srcs):
-            (block if _same_dense_block(d, t) else other).append((d, t))
-        table = None
-        if block:
-            rows = [[t.data_ptr(), d.data_ptr(), t.numel() * t.element_size()] for d, t in block]
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            max_bytes = max(r[2] for r in rows)
-        static_in, static_tgt, graph = entry["in"], entry["tgt"], entry["graph"]
+        flat_dsts, plans = [], []
+        for li in range(n_lanes):
+            statics = lanes[li]["statics"]
+            srcs = []
+            for n in names:
+                srcs += statics[n][0]
+            if li == 0:
+                for n in names:
+                    m = self.wrapped_modules[n]
+                    stat, with_g = statics[n]
+                    # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
+                    full = [_cache_like(t, n_sub) for t in stat]
+                    if isinstance(m, MinMaxQuantMatMul):
+                        m.raw_input, m.raw_out = [full[0], full[1]], full[2]
+                    else:
+                        m.raw_input, m.raw_out = full[0], full[1]
+                    if hasattr(m, "metric"):
+                        m.raw_grad = full[-1] if with_g else None
+                    flat_dsts += full
+            # every (static tensor -> slice i of its cache) whose memory is one dense block goes through ONE launch per
+            # sub-batch (p4v_multi_copy); anything else (overlapping / gapped views) keeps torch's copy
+            block, other = [], []
+            for d, t in zip(flat_dsts, srcs):
+                (block if _same_dense_block(d, t) else other).append((d, t))
+            table, max_bytes = None, 0
+            if block:
+                rows = [[t.data_ptr(), d.data_ptr(), t.numel() * t.element_size()] for d, t in block]
+                table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                max_bytes = max(r[2] for r in rows)
+            plans.append((lanes[li], table, len(block), max_bytes, other))
+        main = torch.cuda.current_stream(dev)
+        streams = [main] if n_lanes == 1 else engine.side_streams(dev, n_lanes)
+        for s_ in streams:
+            if s_ is not main:
+                s_.wait_stream(main)          # the caches / tables / targets were produced on the current stream
         for i, st in enumerate(range(0, total, bs)):
-            with torch.no_grad():
-                static_in.copy_(inp[st:st + bs])
-            static_tgt.copy_(raw_pred_softmax[st:st + bs])
-            graph.replay()
-            if table is not None:
-                engine.multi_copy(table, len(block), i, max_bytes, dev)
-            for d, t in other:
-                d[i * t.shape[0]:(i + 1) * t.shape[0]].copy_(t)
+            entry, table, n_block, max_bytes, other = plans[i % n_lanes]
+            with torch.cuda.stream(streams[i % n_lanes]):
+                with torch.no_grad():
+                    entry["in"].copy_(inp[st:st + bs])
+                entry["tgt"].copy_(raw_pred_softmax[st:st + bs])
+                entry["graph"].replay()
+                if table is not None:
+                    engine.multi_copy(table, n_block, i, max_bytes, dev)
+                for d, t in other:
+                    d[i * t.shape[0]:(i + 1) * t.shape[0]].copy_(t)
+        for s_ in streams:
+            if s_ is not main:
+                main.wait_stream(s_)
         return True
 
     def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad, stride=None):

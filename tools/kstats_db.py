@@ -4,7 +4,7 @@ import glob
 import sqlite3
 import sys
 
-for path in sys.argv[1:]:
+for path in ([] if (len(sys.argv) > 1 and sys.argv[1] == "--busy") else sys.argv[1:]):
     for db in sorted(glob.glob(path) if any(ch in path for ch in "*?") else [path]):
         con = sqlite3.connect(db)
         rows = con.execute("select name, count(*), avg(end-start), sum(end-start), min(end-start), max(end-start) from kernels "
@@ -13,3 +13,35 @@ for path in sys.argv[1:]:
         print(f"== {db}: {tot / 1e6:.2f} ms of kernels")
         for r in rows[:14]:
             print(f"  {r[0][:84]:84s} n={r[1]:5d} avg={r[2] / 1e3:9.1f} us  {100 * r[3] / tot:5.1f} %")
+
+
+def busy(db, t_from_first=None):
+    """GPU occupancy of a trace: union of the kernel intervals against the wall-clock they span, the idle gaps by the kernel
+    that ends before them, and how many kernels overlap on average (python tools/kstats_db.py --busy <db>)."""
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end from kernels order by start").fetchall()
+    first = next((r[1] for r in rows if "k_sweep" in r[0]), rows[0][1])      # from the first search kernel on
+    rows = [r for r in rows if r[1] >= first]
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    union = 0
+    cur_s, cur_e, last_name = rows[0][1], rows[0][2], rows[0][0]
+    gaps = {}
+    for name, s, e in rows[1:]:
+        if s > cur_e:
+            union += cur_e - cur_s
+            gaps[last_name[:60]] = gaps.get(last_name[:60], 0) + (s - cur_e)
+            cur_s, cur_e, last_name = s, e, name
+        elif e > cur_e:
+            cur_e, last_name = e, name
+    union += cur_e - cur_s
+    ksum = sum(r[2] - r[1] for r in rows)
+    print(f"== {db}: wall {1e-6 * (t1 - t0):.1f} ms, some kernel running {1e-6 * union:.1f} ms ({100.0 * union / (t1 - t0):.1f} %), "
+          f"sum of kernel times {1e-6 * ksum:.1f} ms (x{ksum / union:.2f} overlap)")
+    for k, v in sorted(gaps.items(), key=lambda kv: -kv[1])[:10]:
+        print(f"   idle after {k:60s} {1e-6 * v:8.2f} ms")
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--busy":
+    for path in sys.argv[2:]:
+        for db in sorted(glob.glob(path)):
+            busy(db)
