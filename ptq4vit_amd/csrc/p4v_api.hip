@@ -102,7 +102,7 @@ std::atomic<int> g_variant_word{0};
 #define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[8];
-enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5 };
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6 };   // P6: k_sweep6 prologue, 0.1 us
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -346,7 +346,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (c.dry) return 0;
     const int tiles = p.stiles * p.ttiles, nc = p.c1 - p.c0;
     const int full = tiles / 256 * 256, rem = tiles - full;
-    const double P = 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
+    const double P = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
     auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
     int q_best = 0;
     if (rem > 0 && full > 0 && !(g_variant & 16384)) {
@@ -556,6 +556,9 @@ struct PlaneCache {
     char* buf = nullptr;
     bool assigned = false, valid = false;
 };
+// The same for the epilogue operands of k_sweep6 in fragment order (k_prep_epi6): raw_out, raw_grad and the bias are fixed
+// for the whole call, so the tile image of one search orientation is built by its first pass and read by the later rounds.
+typedef PlaneCache EpiCache;
 
 struct Operand {
     PackParams pk;        // src/strides/sizes/scales/mode filled by the caller (dst, C, Rp, Kp set by run_pass)
@@ -590,6 +593,7 @@ struct Pass {
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
+    EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
 };
 
 static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
@@ -677,7 +681,29 @@ int run_pass(Ctx& c, Pass& ps) {
     float* scores = c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
     float* zero_bias = (stat_ok && !ps.bias) ? c.ws.get<float>((size_t)std::max(Mp, Np)) : nullptr;
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
+    // k_sweep6: epilogue operands in fragment order, one image per 256 x 64 tile (8 bytes per output element)
+    const int s6_stiles = (a_search ? Np : Mp) / 256, s6_ttiles = (int)cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
+    const size_t epi6_bytes = regs6 ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
+    EpiCache* ec = (regs6 && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
+    if (ec && !ec->assigned) {
+        ec->buf = c.ws.get_top(epi6_bytes);
+        ec->assigned = true; ec->valid = false;
+    }
+    float* epi6 = !regs6 ? nullptr : ec ? reinterpret_cast<float*>(ec->buf) : c.ws.get<float>(epi6_bytes / 4);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    if (regs6 && !c.dry && !(ec && ec->valid)) {
+        PrepEpi6Params pe{};
+        pe.O = ps.O; pe.Wt = ps.G ? ps.G : ps.O; pe.bias = ps.bias ? ps.bias : zero_bias;
+        pe.o_ss = a_search ? ps.o_ns : ps.o_ms; pe.o_ts = a_search ? ps.o_ms : ps.o_ns;
+        pe.SR = a_search ? ps.Ncols : ps.Mrows; pe.TR = a_search ? ps.Mrows : ps.Ncols;
+        pe.bias_on_t = a_search ? 0 : 1; pe.wt_mode = ps.wt_mode;
+        pe.stiles = s6_stiles; pe.ttiles = s6_ttiles; pe.E = epi6;
+        if (zero_bias) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
+        const long chunks = (long)(epi6_bytes / 16);
+        hipLaunchKernelGGL(k_prep_epi6, dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 32)), dim3(256), 0, c.st, pe);
+        HIPCHK(hipGetLastError());
+    }
+    if (ec) ec->valid = true;
     if (big7 && !c.dry) {
         PrepEpiParams pe{ps.O, ps.G ? ps.G : ps.O, ps.bias, ps.o_ms, ps.Mrows, ps.Ncols, ps.wt_mode,
                          Np / 256, Mp / (ps.twin ? 128 : 256), ps.twin ? 1 : 0, epi7};
@@ -698,6 +724,7 @@ int run_pass(Ctx& c, Pass& ps) {
         pk.Z = shared ? 1 : ps.Z;
         pk.C = op.expanded ? nc : 1;
         pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
+        if (regs6 && !op.expanded) pk.c_inner = 3;                     // k_sweep6: stationary operand in MFMA-fragment order
         if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
         return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
     };
@@ -730,8 +757,8 @@ int run_pass(Ctx& c, Pass& ps) {
             q.dbg = g_variant & 3;
             if (regs6) {
                 // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
-                q.stiles = (a_search ? Np : Mp) / 256; q.ttiles = cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
-                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, 25.0, 0.14);
+                q.stiles = s6_stiles; q.ttiles = s6_ttiles; q.E = epi6;
+                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, tune(TUNE_P6) > 0 ? 0.125 * tune(TUNE_P6) : 25.0, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
                 CHK(launch_sweep6(c, q, ps.epi, cg6));
@@ -988,6 +1015,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
     PlaneCache plane_w, plane_a;
+    EpiCache epi_w, epi_a;
     const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int n_rounds = sg.full() ? d->search_round : 1;
@@ -1022,6 +1050,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 wc = w_mix;
             }
             ps.cache = (keep_planes && nH == 1) ? &plane_w : nullptr;   // (n_H > 1: the table mixes in the current interval)
+            ps.ecache = keep_planes ? &epi_w : nullptr;
             ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
             ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
             ps.scores_out = scores_out ? scores_out + ((long)slot(round, 0) * d->eq_n) * nV : nullptr;
@@ -1077,6 +1106,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ac = a_mix;
             }
             ps.cache = (keep_planes && nA == 1) ? &plane_a : nullptr;
+            ps.ecache = keep_planes ? &epi_a : nullptr;
             ps.nj = 1; ps.cands = a_cands; ps.cand_cs = nA; ps.cand_js = 0; ps.cand_off = a;
             ps.interval = a_iv; ps.out_js = 0; ps.out_off = a;
             ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)slot(round, 1) * d->eq_n) * nV : nullptr;

@@ -132,7 +132,10 @@ struct PackParams {
     long s_z2; int zdiv;  // two-level batch: offset = (z / zdiv) * s_z2 + (z % zdiv) * s_z  (zdiv <= 0: single level)
     int Z, R, K;
     int Rp, Kp;           // padded plane: dst is [C][Z][Rp][Kp], [Z][Rp][C][Kp] when c_inner == 1,
-                          // [Z][Rp][C/2][Kp/64][2][64] (candidate pairs interleaved per k-tile) when c_inner == 2
+                          // [Z][Rp][C/2][Kp/64][2][64] (candidate pairs interleaved per k-tile) when c_inner == 2,
+                          // MFMA-fragment order of k_sweep6's register-stationary operand when c_inner == 3 (C == 1):
+                          // 16-byte chunk ((((r / 64) * Kp/64 + k-tile) * 2 + (r / 32) % 2) * 2 + half) * 64 + g * 32 + r % 32
+                          // for bytes [k-tile * 64 + half * 32 + g * 16, + 16) of row r -- one dwordx4 of a wave is 1 KB contiguous
     int c_inner;
     void* dst;
     int C;
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         for (int j = 0; j < PACK_CG; ++j) {     // not unrolled: one candidate's body is already ~150 instructions
             const int c = cbeg + j;
             if (c >= cend) break;
-            const long o = p.c_inner == 2 ? ((((long)z * p.Rp + r) * ((p.C + 1) & ~1) + (c & ~1)) * p.Kp + (long)(kc >> 2) * 128 + (c & 1) * 64 + (kc & 3) * 16)
+            const long o = p.c_inner == 3 ? ((long)z * p.Rp * p.Kp + (((((long)(r >> 6) * (p.Kp >> 6) + (kc >> 2)) * 2 + ((r >> 5) & 1)) * 2 + ((kc >> 1) & 1)) * 64 + (kc & 1) * 32 + (r & 31)) * 16)
+                         : p.c_inner == 2 ? ((((long)z * p.Rp + r) * ((p.C + 1) & ~1) + (c & ~1)) * p.Kp + (long)(kc >> 2) * 128 + (c & 1) * 64 + (kc & 3) * 16)
                          : p.c_inner ? ((((long)z * p.Rp + r) * p.C + c) * p.Kp + (long)kc * 16)
                                      : ((((long)c * p.Z + z) * p.Rp + r) * p.Kp + (long)kc * 16);
             if constexpr (sizeof(T) == 1) {
@@ -1385,6 +1389,7 @@ struct Sweep3Params {
     int stiles, ttiles;
     int dbg;
     int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them)
+    const float* E;                     // k_sweep6: epilogue operands in fragment order (k_prep_epi6); S is in fragment order too
 #ifdef P4V_TRACE
     unsigned long long* trace;          // tuning builds only: [workgroup][8] timestamps (100 MHz) + hw id
 #endif
@@ -1804,6 +1809,52 @@ __global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
 // RB = 32-row blocks of the stationary operand per wave: RB = 2 -> 4 waves (one per SIMD, 512 registers each);
 // RB = 1 -> 8 waves (two per SIMD, 256 registers each): half the rows per wave, so one wave's epilogue VALU work and
 // LDS waits hide under the other wave's MFMAs, at twice the fragment reads per MFMA.
+// Epilogue operands of k_sweep6 in fragment order, written once per (module, search orientation) and read by every pass
+// of that orientation (raw_out, raw_grad and the bias do not change during calibration_step2).  For tile t = tt * stiles + st,
+// 32-row block b (of the tile's 256 stationary rows), column block cb, quarter q and lane (g, l31): the four values of
+// stationary rows st * 256 + b * 32 + 8 q + 4 g + 0..3 at streaming row tt * 64 + cb * 32 + l31 -- chunk
+// ((((t * 8 + b) * 2 + cb) * 4 + q) * 2 + k) * 64 + lane of 16 bytes, k = 0: raw_out - bias, k = 1: the metric weight
+// (raw_grad | raw_out | |raw_out| | 1), zero where either row is padding.  The sweep's prologue is then 64 dwordx4 loads
+// of 1 KB contiguous per wave; gathered in place (k_sweep6 until round 2) every load touched 32-64 cache lines and the
+// prologue took 10 % of the launch (profiles/r2_sweep6_ablation.txt).
+struct PrepEpi6Params {
+    const float* O; const float* Wt; const float* bias;
+    long o_ss, o_ts; int SR, TR, bias_on_t, wt_mode;
+    int stiles, ttiles;
+    float* E;
+};
+__global__ __launch_bounds__(256) void k_prep_epi6(PrepEpi6Params p) {
+    const long total = (long)p.stiles * p.ttiles * 8 * 2 * 4 * 2 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), k = (int)((i >> 6) & 1), q = (int)((i >> 7) & 3), cb = (int)((i >> 9) & 1), b = (int)((i >> 10) & 7);
+        const long t = i >> 13;
+        const int st = (int)(t % p.stiles), tt = (int)(t / p.stiles);
+        const int g = lane >> 5, l31 = lane & 31;
+        const int tr = tt * 64 + cb * 32 + l31;
+        const int sr0 = st * 256 + b * 32 + 8 * q + 4 * g;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (tr < p.TR) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sr = sr0 + e;
+                if (sr < p.SR) {
+                    const long idx = (long)sr * p.o_ss + (long)tr * p.o_ts;
+                    const float o = p.O[idx];
+                    if (k == 0) v[e] = o - p.bias[p.bias_on_t ? tr : sr];
+                    else v[e] = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+                }
+            }
+        }
+        reinterpret_cast<v4f*>(p.E)[i] = v;
+    }
+}
+
+// Timing-only ablations (tools/build_ablation_libs.sh, never shipped): -DP4V_SW6_DBG = 1 no operand stream in the loop,
+// 2 no MFMAs, 4 no epilogue, 8 no fragment reads, 16 no epilogue-operand loads in the prologue, 32 no stationary-operand
+// loads (bit mask).
+#ifndef P4V_SW6_DBG
+#define P4V_SW6_DBG 0
+#endif
 template <int EPI, int KT, int RB>
 __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Params p) {
     constexpr int NW = 8 / RB;                           // waves per workgroup
@@ -1860,72 +1911,40 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     // ---- stationary operand: 64 rows x K bytes of this wave, MFMA A-fragments, registers for the whole kernel -----
     v4i sfr[KT][RB][2];   // [k-tile][32-row block][32-byte half]
     {
-        const char* gS = (const char*)p.S + (long)(s0 + l31) * p.ldk + g * 16;
+        // fragment order (k_pack c_inner == 3): every load of a wave is 1 KB contiguous
+        const v4i* gS = reinterpret_cast<const v4i*>(p.S) + (long)(s0 >> 6) * (KT * 4 * 64) + lane;
+        const int ib = (s0 >> 5) & 1;                        // RB == 1: the wave's single 32-row block within its 64-row slab
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    sfr[kt][i][h] = *reinterpret_cast<const v4i*>(gS + (long)i * 32 * p.ldk + kt * SW_BKB + h * 32);
+                for (int h = 0; h < 2; ++h) {
+                    if constexpr ((P4V_SW6_DBG & 32) != 0) sfr[kt][i][h] = v4i{lane, kt, i, h};     // ablation: no stationary loads
+                    else sfr[kt][i][h] = gS[((kt * 2 + (RB == 2 ? i : ib)) * 2 + h) * 64];
+                }
     }
 
-    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming) --
+    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming), in
+    // fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in) ---------------------
     float u[RB][2][16], w[RB][2][16];
-    // activation search: the tile is transposed (stationary rows = output features = the contiguous dimension), so
-    // the four rows (r & 3) of one lane are 16 contiguous bytes -> one dwordx4 load instead of four scattered dwords
-    const bool vec_ok = p.o_ss == 1 && (p.SR & 3) == 0 && (p.o_ts & 3) == 0 &&
-                        ((((unsigned long long)p.O) | ((unsigned long long)p.Wt) | ((unsigned long long)p.bias)) & 15) == 0;
-    // weight = raw_grad (mode 1) | raw_out (2) | |raw_out| (3) | 1 (0), selected with bit masks
-    const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
-    const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
-    const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
-    // two phases per column block: every load is issued unconditionally (clamped addresses) before anything is
-    // consumed -- a conditional load costs a branch and a full vmcnt(0) per element
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int tr = t0 + cb * 32 + l31;
-        const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
-        const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
-        const bool t_ok = tr < p.TR;
-        float bs[RB][16];
-        if (vec_ok) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int src = min(s0 + i * 32 + 8 * q + 4 * g, p.SR - 4);
-                    const v4f o4 = *reinterpret_cast<const v4f*>(p.O + toff + src);
-                    const v4f g4 = *reinterpret_cast<const v4f*>(p.Wt + toff + src);
-                    const v4f b4 = *reinterpret_cast<const v4f*>(p.bias + (p.bias_on_t ? 0 : src));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = o4[e]; w[i][cb][q * 4 + e] = g4[e]; bs[i][q * 4 + e] = b4[e]; }
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int src = min(s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1);
-                    const long idx = toff + (long)src * p.o_ss;
-                    u[i][cb][r] = p.O[idx];
-                    w[i][cb][r] = p.Wt[idx];
-                    bs[i][r] = p.bias[p.bias_on_t ? 0 : src];
-                }
-        }
+    {
+        const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = t_ok && (s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
-                const float o = u[i][cb][r], gw = w[i][cb][r];
-                const float b = p.bias_on_t ? bias_t : bs[i][r];
-                // branch-free weight selection (a uniform if-chain becomes scalar branches that split the block and
-                // turn every later wait into vmcnt(0))
-                const unsigned wbits = (__builtin_bit_cast(unsigned, gw) & m_g) | (__builtin_bit_cast(unsigned, o) & m_o) | m_1;
-                u[i][cb][r] = ok ? o - b : 0.0f;
-                w[i][cb][r] = ok ? __builtin_bit_cast(float, wbits) : 0.0f;
-            }
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f u4, w4;
+                    if constexpr ((P4V_SW6_DBG & 16) != 0) { u4 = v4f{(float)lane, 1.f, 2.f, 3.f}; w4 = v4f{1.f, 1.f, 1.f, 1.f}; }
+                    else {
+                        u4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 0) * 64];
+                        w4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 1) * 64];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = u4[e]; w[i][cb][q * 4 + e] = w4[e]; }
+                }
     }
     const int blk_row = p.sb_on_t ? t0 : s0;
     const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
@@ -1979,6 +1998,13 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     // epilogue slice `sl` of column block cbE; result goes to res slot `slot` (= candidate + 1)
     auto epi_slice = [&](auto sl_c, auto cb_c, int slot) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_c)::value, cbE = decltype(cb_c)::value;
+        if constexpr ((P4V_SW6_DBG & 4) != 0) {     // keep the accumulators (and with them the MFMAs) alive
+            if constexpr (sl == 0) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) asm volatile("" : "+v"(acc[i][cbE]));
+            }
+            return;
+        }
         if constexpr (sl == 0) { esum0 = 0.0f; esum1 = 0.0f; }
         if constexpr (sl < NSL) {
 #pragma unroll
@@ -2008,12 +2034,15 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
         TF2& cur = tf[s % NB];
         TF2& pre = tf[(s + PD) % NB];
         constexpr int t = s + PD;
-        if constexpr (t < NSTEP) {
+        if constexpr ((P4V_SW6_DBG & 8) != 0) {
+        } else if constexpr (t < NSTEP) {
             P4V_DSR(pre.f[0], ad0, (t % KT) * KT_TILE + (t / KT) * 2048); P4V_DSR(pre.f[1], ad1, (t % KT) * KT_TILE + (t / KT) * 2048);
         } else {   // first PD steps of the next candidate (its stage landed before the barrier of the previous phase 1)
             P4V_DSR(pre.f[0], adn0, (t - NSTEP) * KT_TILE); P4V_DSR(pre.f[1], adn1, (t - NSTEP) * KT_TILE);
         }
-        if constexpr (s == 0) {   // scale of this candidate for the epilogues that start in phase 1
+        if constexpr ((P4V_SW6_DBG & 8) != 0) {
+            if constexpr (s == 0) { asm volatile("ds_read_b32 %0, %1" : "=v"(es1_next) : "v"(s1addr0 + ci * (4 * NW))); __builtin_amdgcn_s_waitcnt(0xC07F); }
+        } else if constexpr (s == 0) {   // scale of this candidate for the epilogues that start in phase 1
             asm volatile("ds_read_b32 %0, %1" : "=v"(es1_next) : "v"(s1addr0 + ci * (4 * NW)));
             __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * PD + 1) << 8));   // the scale read is newer than the fragments of this step
         } else {
@@ -2026,7 +2055,8 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+                if constexpr ((P4V_SW6_DBG & 2) == 0)
+                    acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
                 if (h == 1 && i == 0) {
                     // the streamed tile of candidate ci+2 trickles in one 1 KB piece per wave and step (a burst right after
                     // the barrier stalls the fragment reads).  Issue point: after the third MFMA of the step, fenced so that
@@ -2035,7 +2065,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
                     constexpr int P1 = NSTEP - SBAR;                                // steps left in this candidate after the barrier
                     constexpr int j = (s >= SBAR) ? s - SBAR : s + P1;              // piece index of this wave
                     __builtin_amdgcn_sched_barrier(0x6);
-                    if constexpr (j < PPW) piece(fillT, fill_stage, std::integral_constant<int, j>{});
+                    if constexpr (j < PPW && (P4V_SW6_DBG & 1) == 0) piece(fillT, fill_stage, std::integral_constant<int, j>{});
                     __builtin_amdgcn_sched_barrier(0x6);
                 }
             }
