@@ -857,6 +857,75 @@ int run_pass(Ctx& c, Pass& ps) {
     return 0;
 }
 
+// ---- split search of the split-of-softmax matmul in one kernel (k_sos_split) -------------------------------------------------
+struct SosSplitJob {
+    SosSplitParams kp;
+    int epi; double norm;
+    const float* cands; float* split; float* A_iv; float aux_div;
+    float* scores_out; int scores_out_ld; int32_t* best_out;
+};
+bool sos_split_ok(int M, int K, int N, bool cosm) {
+    return !cosm && K <= 200 && M <= 256 && N <= 64 && !(g_variant & 131072);
+}
+template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int epi) {
+    const dim3 grid(kp.halves, kp.Z), block(256);
+    const size_t lds = (size_t)2 * KS * 64 * sizeof(float);
+#define P4V_LAUNCH9(E)                                                                                         \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sos_split<KS, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sos_split<KS, E>), grid, block, lds, c.st, kp);                                  \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH9(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH9(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH9(EPI_ABS); break;
+        default: P4V_LAUNCH9(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH9
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int run_sos_split(Ctx& c, SosSplitJob& j) {
+    SosSplitParams& kp = j.kp;
+    const size_t mark = c.ws.off;
+    const int slots = kp.halves * 4;
+    float* part = c.ws.get<float>((size_t)kp.C * kp.Z * slots);
+    float* scores = c.ws.get<float>((size_t)kp.C);
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    kp.part = part;
+    if (!c.dry) {
+        HIPCHK(hipMemsetAsync(part, 0, sizeof(float) * (size_t)kp.C * kp.Z * slots, c.st));   // slots of all-padding waves
+        const bool timed = g_stat_on;
+        StatRec rec{};
+        const int KS = kp.K <= 64 ? 32 : kp.K <= 144 ? 72 : 100;
+        if (timed) {
+            HIPCHK(hipEventCreate(&rec.a));
+            HIPCHK(hipEventCreate(&rec.b));
+            rec.kind = 1;
+            rec.macs = (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C;
+            rec.alg = (double)kp.Z * kp.M * kp.K * kp.N * kp.C;
+            HIPCHK(hipEventRecord(rec.a, c.st));
+        }
+        if (KS == 32) CHK(launch_sos_split_ks<32>(c, kp, j.epi));
+        else if (KS == 72) CHK(launch_sos_split_ks<72>(c, kp, j.epi));
+        else CHK(launch_sos_split_ks<100>(c, kp, j.epi));
+        if (timed) {
+            HIPCHK(hipEventRecord(rec.b, c.st));
+            g_stat_recs.push_back(rec);
+        }
+    }
+    FinishParams fp{part, (long)kp.Z * slots, (long)slots, slots, 1, kp.Z, slots, kp.C, 0, 1, 1, j.norm, scores};
+    CHK(launch_finish(c, fp));
+    SelectParams sl{scores, kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
+    CHK(launch_select(c, sl));
+    c.ws.off = mark;
+    return 0;
+}
+
 // ---- exact memoisation of search passes ---------------------------------------------------------------------
 // Every candidate table is built once from the initial interval (reference linear.py:544-545), so a search pass
 // is a deterministic function of the counterpart's CURRENT interval only.  Rounds 2-3 often see an interval that
@@ -1297,6 +1366,22 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.cache = keep_planes ? &plane_A : nullptr;
             ps.scores_out = so; ps.scores_out_ld = H; ps.best_out = bo;
             CHK(run_pass(c, ps));
+        } else if (sos_split_ok(M, K, N, cosm)) {
+            // ---- split search against the UNQUANTISED B (matmul.py:600-631): A quantised in registers, one kernel ----
+            SosSplitJob j{};
+            j.kp.A = A; j.kp.a_z2 = d->a_stride[0]; j.kp.a_z = d->a_stride[1]; j.kp.a_r = d->a_stride[2]; j.kp.a_k = d->a_stride[3];
+            j.kp.zdiv = H;
+            j.kp.B = B; j.kp.b_z2 = d->b_stride[0]; j.kp.b_z = d->b_stride[1]; j.kp.b_k = d->b_stride[2]; j.kp.b_n = d->b_stride[3];
+            j.kp.O = O; j.kp.G = G ? G : O;
+            j.kp.Z = Z; j.kp.M = M; j.kp.K = K; j.kp.N = N; j.kp.wt_mode = wt_mode; j.kp.C = NSPLIT;
+            j.kp.splits = split_cands;
+            j.kp.qm1 = (float)(Aq - 1); j.kp.c_inv = 1.0f / (float)(Aq - 1);
+            j.kp.lo_top = std::min(std::nearbyintf(1.0f / j.kp.c_inv), (float)(Aq - 1));
+            j.kp.halves = cdiv(M, 128);
+            j.epi = epi; j.norm = 1.0 / ((double)H * M * N);
+            j.cands = split_cands; j.split = split; j.A_iv = A_iv; j.aux_div = (float)(Aq - 1);   // A_interval = split/(qmax-1) (matmul.py:629)
+            j.scores_out = (d->eq_n >= NSPLIT) ? so : nullptr; j.scores_out_ld = H; j.best_out = bo;
+            CHK(run_sos_split(c, j));
         } else {
             // ---- split search against the UNQUANTISED B (matmul.py:600-631): fp32 operands ----
             Pass ps{};

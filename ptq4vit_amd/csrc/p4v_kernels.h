@@ -2531,6 +2531,138 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sos_split: the split search of the split-of-softmax matmul (reference matmul.py:600-631) in one kernel
+// ------------------------------------------------------------------------------------------
+// For each of the 20 splits s = 2^-i the reference quantises the post-softmax operand A to
+//     A_sim = clamp(rint(clamp(A, s, 1) * (q-1)), 0, q-1) / (q-1)  +  clamp(rint(clamp(A, 0, s) / a), 0, q-1) * a,   a = s / (q-1)
+// and scores A_sim @ B against raw_out with the UNQUANTISED B -- fp32 by definition.  Through the generic path this is 20
+// fp32 planes of A (2 GB for ViT-B, 32 images) written by k_pack<float> and streamed back by the fp32 sweep, 1.9 ms per module.
+// Here A never leaves the registers: a wave owns 32 rows of one (image, head) for the whole K (K <= 2 KS), as operands of
+// mfma_f32_32x32x2 (lane (g, l31): row l31, k = 2 ks + g), B lies in the LDS, and the 20 candidates are quantised in place.
+// What makes that cheap is that every rounding step above is monotone, so clamps commute with them exactly:
+//     high part = med3(hv, fl(rint(fl(s (q-1))) / (q-1)), 1)        hv = fl(rint(fl(A (q-1))) / (q-1))   -- per element, once
+//     low index = med3(rint(y * 2^i), 0, min(rint(fl(1 / c)), q-1))   y = fl(A / c), c = fl(1 / (q-1))    -- per element, once
+// (a = 2^-i c exactly, so A / a = (A / c) 2^i exactly; fl(s / a) = fl(1 / c)), i.e. the two IEEE divisions per element are
+// candidate-invariant and one candidate costs 6 VALU operations per element next to its two MFMAs.  mul and add of the low part
+// stay separate instructions: the reference rounds the product before the sum.
+// Workgroup = 4 waves = 128 rows of one z; 512 registers per wave (one wave per SIMD); scores leave as one float per
+// (candidate, wave) and go through k_finish / k_select like every other sweep.
+struct SosSplitParams {
+    const float* A; long a_z2, a_z, a_r, a_k; int zdiv;
+    const float* B; long b_z2, b_z, b_k, b_n;
+    const float* O; const float* G;        // [Z][M][N] contiguous
+    int Z, M, K, N, wt_mode, C;
+    const float* splits;                   // [C], powers of two
+    float qm1, c_inv, lo_top;              // q-1, fl(1 / (q-1)), min(rint(fl(1 / c_inv)), q-1)
+    float* part;                           // [C][Z][halves * 4]
+    int halves;
+};
+
+#ifndef P4V_SOS_DBG
+#define P4V_SOS_DBG 0          // timing-only ablations: 1 no quantisation arithmetic, 2 no B fragment reads, 4 no MFMAs
+#endif
+template <int KS, int EPI>
+__global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Bt = reinterpret_cast<float*>(smem);                    // [2 KS][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const int half = blockIdx.x, z = blockIdx.y;
+    const long zoffA = p.zdiv > 0 ? (long)(z / p.zdiv) * p.a_z2 + (long)(z % p.zdiv) * p.a_z : (long)z * p.a_z;
+    const long zoffB = p.zdiv > 0 ? (long)(z / p.zdiv) * p.b_z2 + (long)(z % p.zdiv) * p.b_z : (long)z * p.b_z;
+
+    // ---- B tile -> LDS, zero padded -------------------------------------------------------------------------------
+    for (int i = tid; i < 2 * KS * 64; i += 256) {
+        const int k = i >> 6, n = i & 63;
+        Bt[i] = (k < p.K && n < p.N) ? p.B[zoffB + (long)k * p.b_k + (long)n * p.b_n] : 0.0f;
+    }
+    // ---- this wave's 32 rows: the two candidate-invariant images of every element ----------------------------------
+    const int row0 = half * 128 + wid * 32;
+    const int row = row0 + l31;
+    float hv[KS], yv[KS];
+    {
+        const float* ap = p.A + zoffA + (long)min(row, p.M - 1) * p.a_r;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 2 * ks + g;
+            const float x = (row < p.M && k < p.K) ? ap[(long)k * p.a_k] : 0.0f;
+            hv[ks] = rintf(x * p.qm1) / p.qm1;
+            yv[ks] = x / p.c_inv;
+        }
+    }
+    // ---- raw_out / metric weight of the wave's 32 x 64 outputs, accumulator layout -----------------------------------
+    float u[2][16], w[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = row0 + (r & 3) + 8 * (r >> 2) + 4 * g, n = cb * 32 + l31;
+            const bool ok = m < p.M && n < p.N;
+            const long idx = ((long)z * p.M + min(m, p.M - 1)) * p.N + min(n, p.N - 1);
+            const float o = p.O[idx];
+            const float gw = p.wt_mode == 1 ? p.G[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
+            u[cb][r] = ok ? o : 0.0f;
+            w[cb][r] = ok ? gw : 0.0f;         // also the validity mask of the unweighted metrics (padding rows quantise to != 0)
+        }
+    __syncthreads();
+    if (row0 >= p.M) return;                  // a wave of pure padding (no barrier below)
+
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    const float* b0 = Bt + g * 64 + l31;      // B fragment of k-step ks, column block cb: b0[ks * 128 + cb * 32]
+    for (int c = 0; c < p.C; ++c) {
+        const float s = p.splits[c];
+        const float inv_s = 1.0f / s;                           // 2^i, exact
+        const float a_int = s / p.qm1;                          // matmul.py:609
+        const float cl = rintf(s * p.qm1) / p.qm1;
+        v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        // B fragments and the quantised A value run two k-steps ahead of their MFMAs (the LDS latency and the VALU work pass
+        // under the matrix pipe's 128 cycles per k-step; a wave is alone on its SIMD)
+        float bq0[3], bq1[3], aq[3];
+        auto stage = [&](auto ks_c) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ks_c)::value;
+            if constexpr (ks < KS) {
+                if constexpr ((P4V_SOS_DBG & 2) != 0) { bq0[ks % 3] = cl; bq1[ks % 3] = inv_s; }
+                else { bq0[ks % 3] = b0[ks * 128]; bq1[ks % 3] = b0[ks * 128 + 32]; }
+                if constexpr ((P4V_SOS_DBG & 1) != 0) { aq[ks % 3] = hv[ks] + yv[ks]; return; }
+                const float hi = __builtin_amdgcn_fmed3f(hv[ks], cl, 1.0f);
+                const float li = __builtin_amdgcn_fmed3f(rintf(yv[ks] * inv_s), 0.0f, p.lo_top);
+                float lo = li * a_int;
+                asm volatile("" : "+v"(lo));                      // the product is rounded before the sum (no fma contraction)
+                aq[ks % 3] = hi + lo;
+            }
+        };
+        stage(std::integral_constant<int, 0>{});
+        stage(std::integral_constant<int, 1>{});
+        [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
+            ([&] {
+                stage(std::integral_constant<int, S + 2>{});
+                if constexpr ((P4V_SOS_DBG & 4) != 0) { acc0[S % 16] += aq[S % 3] * bq0[S % 3]; acc1[S % 16] += aq[S % 3] * bq1[S % 3]; }
+                else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[S % 3], bq0[S % 3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[S % 3], bq1[S % 3], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, KS>{});
+        float sum = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = u[cb][r] - (cb ? acc1[r] : acc0[r]);
+                const float ww = w[cb][r];
+                if (EPI == EPI_SQ_W) { const float t2 = ww * d; sum = fmaf(t2, t2, sum); }
+                else if (EPI == EPI_SQ) sum = fmaf(ww * d, d, sum);
+                else if (EPI == EPI_ABS) sum = fmaf(ww, fabsf(d), sum);
+                else sum = fmaf(ww * d, d, sum);
+            }
+        sum = wave_sum_dpp(sum);
+        if (lane == 63) p.part[((long)c * p.Z + z) * (p.halves * 4) + half * 4 + wid] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_finish / k_select
 // ------------------------------------------------------------------------------------------
 struct FinishParams {

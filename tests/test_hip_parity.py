@@ -395,3 +395,32 @@ def test_single_ktile_sweep_matches_the_streaming_sweep(eng):
             assert torch.equal(a, b), "k_sweep8 is not run-to-run deterministic"
     assert_scores_close(new[3].cpu().numpy(), old[3].cpu().numpy(), rtol=1e-6, what="k_sweep8 vs k_sweep2")
     assert torch.equal(new[4], old[4]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
+
+
+@pytest.mark.parametrize("shape,metric", [((4, 12, 197, 64), "hessian"), ((16, 4, 144, 32), "hessian"),
+                                          ((8, 3, 49, 32), "L2_norm"), ((2, 12, 197, 64), "linear_weighted_L2_norm")],
+                         ids=["vit-b", "swin-w12", "swin-w7-l2", "vit-b-linear-weighted"])
+def test_split_search_kernel_matches_the_generic_fp32_sweep(eng, shape, metric):
+    """A/B of the split-of-softmax split search (matmul.py:600-631): k_sos_split (A quantised in registers from two
+    candidate-invariant images per element, one kernel) against 20 fp32 planes through k_pack + the generic fp32 sweep
+    (variant 131072): same split, same A_interval, same B_interval afterwards, score tables equal to summation-order noise."""
+    b, H, S, D = shape
+    A, B, out, grad = _mk_attention(31, b, H, S, D, "sv")
+    hp = dict(A_bit=8, B_bit=8, metric=metric, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=1, sos=True)
+    args = dict(A=_t(A), B=_t(B), out=_t(out), grad=_t(grad), want_scores=True)
+    new = eng.matmul_calibrate(**args, **hp)
+    again = eng.matmul_calibrate(**args, **hp)
+    eng.debug_variant(131072)
+    try:
+        old = eng.matmul_calibrate(**args, **hp)
+    finally:
+        eng.debug_variant(0)
+    torch.cuda.synchronize()
+    for a, b_ in zip(new, again):
+        if a is not None:
+            assert torch.equal(a, b_), "k_sos_split is not run-to-run deterministic"
+    assert torch.equal(new[2], old[2]) and torch.equal(new[0], old[0]), (new[2], old[2])       # split, A_interval
+    sn, so = new[3].cpu().numpy(), old[3].cpu().numpy()       # (round, search, eq_n, H): the split table is [0, 0, :20, 0]
+    assert_scores_close(sn[0, 0, :20, 0], so[0, 0, :20, 0], rtol=2e-5, what="k_sos_split vs fp32 sweep (split table)")
+    assert_scores_close(sn[0, 1], so[0, 1], rtol=1e-6, what="B search after the split search")
+    assert torch.equal(new[1], old[1]) and torch.equal(new[4], old[4])
