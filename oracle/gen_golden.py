@@ -158,8 +158,40 @@ def gen_conv(name, *, b, ic, hw, oc, k, stride, channelwise=True, grad_scale=1e-
     _save(name, dict(kind="conv", channelwise=channelwise, stride=stride, **kw), arrays, rec.tables)
 
 
+def gen_ptqsl_conv(name, *, b, ic, hw, oc, k, stride, grad_scale=1e-3, seed=0, **kw):
+    """PTQSLQuantConv2d's own (non-batching) search, conv.py:126-277: calibration_step2(x)."""
+    from quant_layers.conv import PTQSLQuantConv2d
+
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(oc, ic, k, k, generator=g) * 0.05 * torch.linspace(0.5, 2.0, oc).view(-1, 1, 1, 1)
+    bias = torch.randn(oc, generator=g) * 0.1
+    x = torch.randn(b, ic, hw, hw, generator=g)
+    out = F.conv2d(x, w, bias, stride)
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    m = PTQSLQuantConv2d(ic, oc, k, stride, parallel_eq_n=10, **kw)
+    m.weight.data = w.clone()
+    m.bias.data = bias.clone()
+    m.raw_input, m.raw_out = x.clone(), out.clone()
+    m.raw_grad = grad.clone() if kw.get("metric") == "hessian" else None
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        qf = m.calibration_step2(x)
+    arrays = dict(weight=w.numpy(), bias=bias.numpy(), x=x.numpy(), out=out.numpy(), grad=grad.numpy(),
+                  w_interval=np.asarray(m.w_interval), a_interval=np.asarray(m.a_interval), quant_forward=qf.numpy())
+    _save(name, dict(kind="ptqsl_conv", stride=stride, **kw), arrays, rec.tables)
+
+
 PTQ4VIT = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3)
 BASEPTQ = dict(metric="cosine", eq_alpha=0.5, eq_beta=1.2, eq_n=100, search_round=1)
+
+
+def gen_ptqsl_convs():
+    # ---- PTQSLQuantConv2d's own search (conv.py:126-277; SURVEY.md s8 row f-4) --------
+    gen_ptqsl_conv("ptqslconv_hessian_v2h2", b=4, ic=3, hw=32, oc=12, k=8, stride=8, w_bit=8, a_bit=8, n_V=2, n_H=2, seed=40,
+                   metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    gen_ptqsl_conv("ptqslconv_l2_v3h1_overlap", b=3, ic=3, hw=20, oc=12, k=5, stride=3, w_bit=6, a_bit=6, n_V=3, n_H=1, seed=41,
+                   metric="L2_norm", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=1)
+    gen_ptqsl_conv("ptqslconv_cosine_v1h3", b=4, ic=3, hw=32, oc=12, k=8, stride=8, w_bit=8, a_bit=8, n_V=1, n_H=3, seed=42,
+                   metric="cosine", eq_alpha=0.5, eq_beta=1.2, eq_n=100, search_round=1)
 
 
 def main(only=None):
@@ -167,6 +199,8 @@ def main(only=None):
     os.chdir(REF)
     if only == "minivit":
         return gen_mini_vit()
+    if only == "ptqslconv":
+        return gen_ptqsl_convs()
     # ---- Linear (quant_layers/linear.py:349-642) ---------------------------------
     gen_linear("linear_qkv_hessian_w8a8", shape_x=(4, 13, 48), oc=36, n_V=3, w_bit=8, a_bit=8, **PTQ4VIT)
     gen_linear("linear_hessian_w6a6_tinygrad", shape_x=(4, 13, 48), oc=24, n_V=1, w_bit=6, a_bit=6,
@@ -201,6 +235,7 @@ def main(only=None):
     # IndexError), so it is only usable with a_bit=32, as both shipped configs do (configs/BasePTQ.py:50).
     gen_conv("conv_layerwise_hessian_w6", b=4, ic=3, hw=32, oc=12, k=8, stride=8, channelwise=False, w_bit=6, a_bit=32,
              seed=33, **PTQ4VIT)
+    gen_ptqsl_convs()
     gen_conv("conv_channelwise_hessian_a8_overlap", b=3, ic=3, hw=20, oc=8, k=5, stride=3, w_bit=8, a_bit=8, seed=34,
              metric="hessian", eq_alpha=0.3, eq_beta=1.2, eq_n=30, search_round=2)
 

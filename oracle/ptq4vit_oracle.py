@@ -601,3 +601,88 @@ class ConvOracle:
             if self.a_bit < 32:
                 self.search_a(x, out, grad, a_cands)
         return {"w_interval": self.w_interval, "a_interval": self.a_interval}
+
+
+class PTQSLConvOracle(ConvOracle):
+    """PTQSLQuantConv2d (conv.py:126-277): the non-batching sub-layerwise conv search, `calibration_step2(x)`.
+
+    Weight blocks (n_V, oc/n_V, n_H, ic*kh*kw/n_H) searched one (v, h) at a time with the score taken over the WHOLE output
+    (conv.py:191-220), one activation interval (conv.py:222-244); `_get_similarity(dim=2)` = mean over oc, then the mean
+    over (b, fh, fw).  raw_grad is optional (hessian only).
+    """
+
+    def __init__(self, weight, bias, *, n_V=1, n_H=1, **kw):
+        kw.setdefault("a_bit", 8)
+        super().__init__(weight, bias, channelwise=False, **kw)
+        self.n_V, self.n_H = n_V, n_H
+
+    def _wview(self, w):
+        return w.reshape(self.n_V, self.oc // self.n_V, self.n_H, -1)
+
+    def quant_weight(self):
+        """conv.py:183-189."""
+        return fake_quant(self._wview(self.weight), self.w_interval, -self.w_qmax, self.w_qmax - 1).reshape(self.weight.shape)
+
+    def initialize_intervals(self, x):
+        """conv.py:246-251."""
+        self.a_interval = np.array([np.abs(x).max() / F32(self.a_qmax - 0.5)], dtype=F32)
+        wq = F32(self.w_qmax - 0.5)
+        if self.init_layerwise:
+            self.w_interval = np.full((self.n_V, 1, self.n_H, 1), np.abs(self.weight).max() / wq, dtype=F32)
+        else:
+            self.w_interval = (np.abs(self._wview(self.weight)).max(axis=(1, 3), keepdims=True) / wq).astype(F32)
+
+    def _sim(self, raw, sim, grad):
+        """conv.py:157-181 with dim=2: raw (b,1,oc,fh,fw) / sim (b,p,oc,fh,fw) -> (b,p,fh,fw)."""
+        if self.metric == "cosine":
+            return _cosine(raw, sim, 2)
+        return elementwise_similarity(raw, sim, self.metric, grad).mean(axis=2, dtype=F32)
+
+    def search_w(self, x, out, grad, w_cands):
+        cols, fh, fw = im2col(self.quant_input(x), self.ksize, self.stride, self.padding, self.dilation)
+        b = x.shape[0]
+        raw = out[:, None]
+        g = None if grad is None else grad[:, None]
+        tmp = self.w_interval.copy()
+        for v in range(self.n_V):
+            for h in range(self.n_H):
+                scores = np.empty((self.eq_n,), dtype=F32)
+                for p0 in range(0, self.eq_n, self.chunk):
+                    p1 = min(self.eq_n, p0 + self.chunk)
+                    p = p1 - p0
+                    cur = np.repeat(tmp[None], p, axis=0)
+                    cur[:, v:v + 1, :, h:h + 1, :] = w_cands[p0:p1, v:v + 1, :, h:h + 1, :]
+                    w_sim = fake_quant(self._wview(self.weight)[None], cur, -self.w_qmax, self.w_qmax - 1)
+                    bias_rep = None if self.bias is None else np.tile(self.bias, p)
+                    o = self._conv(cols, w_sim.reshape(p * self.oc, -1), bias_rep, fh, fw).reshape(b, p, self.oc, fh, fw)
+                    scores[p0:p1] = self._sim(raw, o, g).mean(axis=(0, 2, 3), dtype=F32)
+                self.trace.append(("w", scores))
+                tmp[v, :, h, :] = w_cands[int(_argmax0(scores)), v, :, h, :]
+        self.w_interval = tmp
+
+    def search_a(self, x, out, grad, a_cands):
+        raw = out[:, None]
+        g = None if grad is None else grad[:, None]
+        wmat = self.quant_weight().reshape(self.oc, -1)
+        scores = np.empty((self.eq_n,), dtype=F32)
+        for c in range(self.eq_n):
+            xs = fake_quant(x, a_cands[c], -self.a_qmax, self.a_qmax - 1)
+            cols, fh, fw = im2col(xs, self.ksize, self.stride, self.padding, self.dilation)
+            o = self._conv(cols, wmat, self.bias, fh, fw)[:, None]
+            scores[c] = self._sim(raw, o, g).mean(dtype=F32)
+        self.trace.append(("a", scores))
+        self.a_interval = np.array([a_cands[int(_argmax0(scores))]], dtype=F32)
+
+    def calibration_step2(self, raw_input, raw_out, raw_grad=None):
+        """conv.py:253-277."""
+        x = np.ascontiguousarray(raw_input, dtype=F32)
+        out = np.ascontiguousarray(raw_out, dtype=F32)
+        grad = None if raw_grad is None else np.ascontiguousarray(raw_grad, dtype=F32)
+        self.initialize_intervals(x)
+        mult = candidate_multipliers(self.eq_alpha, self.eq_beta, self.eq_n)
+        w_cands = mult.reshape(-1, 1, 1, 1, 1) * self.w_interval[None]      # eq_n+1, n_V, 1, n_H, 1
+        a_cands = mult * self.a_interval[0]
+        for _ in range(self.search_round):
+            self.search_w(x, out, grad, w_cands)
+            self.search_a(x, out, grad, a_cands)
+        return {"w_interval": self.w_interval, "a_interval": self.a_interval}

@@ -246,3 +246,43 @@ def test_multi_copy_appends_every_block_in_one_launch(eng, index):
         assert torch.equal(d[index * n:(index + 1) * n], s)
         rest = torch.cat([d[:index * n], d[(index + 1) * n:]])
         assert bool((rest == -7.0).all())
+
+
+# ---- PTQSLQuantConv2d's own, non-batching search ---------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("ptqslconv_"))
+def test_ptqsl_conv_own_search_vs_reference(name):
+    """PTQSLQuantConv2d.calibration_step2(x) (reference conv.py:253-277) through the GPU Linear engine on the unfolded
+    patches: intervals against what the REFERENCE selected on the same tensors (bit-identical, or another entry of the same
+    candidate table at a near-tie), the returned quantised output against the reference's.  The reference's cosine runs over
+    all output channels whatever the block, so with n_V / n_H > 1 it is refused (the oracle covers that fixture on the CPU)."""
+    from tests.helpers import assert_on_candidate_grid, candidate_grid
+    from ptq4vit_amd.quant_layers.conv import PTQSLQuantConv2d
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    st = p.pop("stride")
+    oc, ic, k, _ = g["weight"].shape
+    m = PTQSLQuantConv2d(ic, oc, k, st, parallel_eq_n=10, **p).cuda()
+    m.weight.data = _t(g["weight"])
+    m.bias.data = _t(g["bias"])
+    x = _t(g["x"])
+    m.raw_input, m.raw_out = x, _t(g["out"])
+    m.raw_grad = _t(g["grad"]) if p["metric"] == "hessian" else None
+    if p["metric"] == "cosine" and (p["n_V"] > 1 or p["n_H"] > 1):
+        with pytest.raises(NotImplementedError):
+            m.calibration_step2(x)
+        return
+    with torch.no_grad():
+        out = m.calibration_step2(x)
+    torch.cuda.synchronize()
+    assert m.calibrated and not hasattr(m, "raw_out")
+    assert tuple(m.w_interval.shape) == (p["n_V"], 1, p["n_H"], 1) and m.a_interval.dim() == 0
+    mult = candidate_grid(p["eq_alpha"], p["eq_beta"], p["eq_n"])
+    moved = assert_on_candidate_grid(m.w_interval.cpu().numpy(), g["w_interval"], mult, name + " w_interval")
+    moved += assert_on_candidate_grid(m.a_interval.cpu().numpy(), g["a_interval"], mult, name + " a_interval")
+    print(f"[parity] {name}: {moved} intervals on another entry of the candidate table (near-ties), the rest bit-identical")
+    if moved == 0:
+        np.testing.assert_allclose(out.cpu().numpy(), g["quant_forward"], rtol=1e-4, atol=1e-5)
+        m.mode = "quant_forward"
+        with torch.no_grad():
+            np.testing.assert_allclose(m(x).cpu().numpy(), g["quant_forward"], rtol=1e-4, atol=1e-5)
