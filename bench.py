@@ -168,7 +168,7 @@ def _cpu_layer_types(imgs, dim=768, heads=12, tokens=197, mlp=4, patch=16, img=2
             ("patch-embed conv (channel-wise)", 1, conv), ("head", 1, lambda: linear(dim, 1000, 1, rows=1))]
 
 
-def cpu_baseline(calib=32, rounds=3, sample_images=2):
+def cpu_baseline(calib=32, rounds=3, sample_images=4):
     """CPU path beside the GPU number: the numpy oracle (a port of the reference algorithm, pinned to the
     reference by tests/golden) timed on this box's host cores, one search round of EVERY ViT-B/224 layer type at
     `sample_images` images, scaled to the headline workload: x (calib / sample_images) images (the work is linear in
@@ -389,7 +389,7 @@ def main():
         cpu = {"value": n_mod / est_s, "unit": "layers/s", "cores": threads, "kind": "port",
                "cpu_model": cpu_model, "logical_cpus": logical, "est_calibration_s": round(est_s, 1),
                "sample": f"numpy oracle (port of the reference's calibration_step2, pinned by tests/golden), ONE search round of each "
-                         f"ViT-B/224 layer type at 2 images ({spent:.1f} s of CPU work), scaled x{args.calib // 2} images x 3 rounds x layer "
+                         f"ViT-B/224 layer type at 4 images ({spent:.1f} s of CPU work), scaled x{args.calib / 4:g} images x 3 rounds x layer "
                          f"counts to the 74-module workload; search only (the reference's CPU path adds 74 x 8 capture passes)",
                "per_layer_type": per_type}
         if args.cpu_full:

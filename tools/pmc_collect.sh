@@ -15,7 +15,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "k_sweep" in k or "k_pack" in k or "k_prep_epi" in k:
+    if "k_sweep" in k or "k_pack" in k or "k_prep_epi" in k or "k_sos" in k:
         print(k.replace("\t", " ") + "\t" + r["Counter_Name"] + "\t" + r["Counter_Value"] + "\t" + r.get("Start_Timestamp", "0") + "\t" + r.get("End_Timestamp", "0"))
 PY
 done
