@@ -9,6 +9,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// LDS-DMA through a buffer resource (MUBUF `buffer_load_dwordx4 ... lds`): per-lane 32-bit offset + scalar base instead of a
+// 64-bit address per lane
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, int voff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
+}
 __device__ const char* g_src;
 
 template <int MODE>
@@ -30,6 +35,7 @@ __global__ __launch_bounds__(512, 2) void k(int iters, int* out, const char* src
     if (MODE & 256) cur = src + (size_t)(tlog / 50) * 128 * 76800 + wid * 1024 + lane * 16;   // dense 8 KB tiles: 1 KB contiguous per instruction
     constexpr int CSTEP = (MODE & 256) ? 8192 : 64;
     int stg = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 0x7fffffff, 0x00020000);
     v4i r0 = {0}, r1 = {0}, r2 = {0};
     if (MODE & 128) { r0 = *(const v4i*)cur; cur += CSTEP; r1 = *(const v4i*)cur; cur += CSTEP; r2 = *(const v4i*)cur; cur += CSTEP; }
     // MODE & 512: streaming fragments straight from global memory into VGPRs (no LDS), 3 k-tiles in flight;
@@ -54,7 +60,8 @@ __global__ __launch_bounds__(512, 2) void k(int iters, int* out, const char* src
                                                  (__attribute__((address_space(3))) void*)(smem + 16384 + 8192 + stg + wid * 1024 + q * 256), 4, 0, 0);
             cur += CSTEP; stg = (stg + 8192 == 6 * 8192) ? 0 : stg + 8192; if ((it & 1023) == 1023) cur -= 1024 * CSTEP;
         } else
-        if (MODE & 32) { glds16(cur, smem + 16384 + 8192 + stg + wid * 1024); cur += CSTEP; stg = (stg + 8192 == 6 * 8192) ? 0 : stg + 8192; if ((it & 1023) == 1023) cur -= 1024 * CSTEP; }
+        if ((MODE & 32) && (MODE & 32768)) { blds16(rsrc, (int)(cur - src), smem + 16384 + 8192 + stg + wid * 1024); cur += CSTEP; stg = (stg + 8192 == 6 * 8192) ? 0 : stg + 8192; if ((it & 1023) == 1023) cur -= 1024 * CSTEP; }
+        else if (MODE & 32) { glds16(cur, smem + 16384 + 8192 + stg + wid * 1024); cur += CSTEP; stg = (stg + 8192 == 6 * 8192) ? 0 : stg + 8192; if ((it & 1023) == 1023) cur -= 1024 * CSTEP; }
         if (MODE & 128) {   // register staging: global_load_dwordx4 -> VGPR -> ds_write_b128, 3 loads in flight
             *reinterpret_cast<v4i*>(smem + 16384 + 8192 + stg + wid * 1024 + lane * 16) = r0;
             r0 = r1; r1 = r2; r2 = *(const v4i*)cur;
@@ -160,6 +167,9 @@ int main() {
     run<16384 + 54>("NO mfma: 6 reads + barrier + LDS-DMA", 512, 100000);
     run<16384 + 54 + 4096>("NO mfma: 4 reads + barrier + LDS-DMA", 512, 100000);
     run<16384 + 22>("NO mfma: 6 reads + barrier", 512, 100000);
+    run<36 + 32768>("mfma + barrier + LDS-DMA via buffer_load lds", 512, 100000);
+    run<54 + 32768>("mfma + pipelined reads + barrier + buffer_load lds", 512, 100000);
+    run<16384 + 32 + 32768>("NO mfma: buffer_load lds only, no barrier", 512, 100000);
     run<4 + 128>("mfma + barrier + reg-staged stream", 512, 100000);
     run<22 + 128>("mfma + pipelined reads + barrier + reg-staged", 512, 100000);
     run<22 + 128 + 256>("mfma + pipelined reads + barrier + reg-staged dense", 512, 100000);
