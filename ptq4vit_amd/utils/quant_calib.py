@@ -312,7 +312,10 @@ class HessianQuantCalibrator(QuantCalibrator):
         """Record ONE sub-batch forward + KL backward with hooks on EVERY wrapped module (so that any group of modules, on
         any later calibration, can be served from it).  Returns the cache entry or None when graph capture is unavailable."""
         mods = self.wrapped_modules
-        saved = {n: (m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for n, m in mods.items()}
+        # (a module whose step 2 has run -- here, or on its owner rank before the interval exchange -- has had its cache
+        # attributes DELETED, reference linear.py:554; the hooks below expect them to exist)
+        missing = object()
+        saved = {n: tuple(m.__dict__.get(a, missing) for a in ("raw_input", "raw_out", "raw_grad")) for n, m in mods.items()}
 
         def reset():
             for m in mods.values():
@@ -335,6 +338,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             static_tgt = raw_pred_softmax[:bs].clone()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
+            reset()
             with torch.cuda.stream(side):            # warm-up outside the graph (allocator, autograd, library handles)
                 one_pass(static_in, static_tgt)
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -361,9 +365,11 @@ class HessianQuantCalibrator(QuantCalibrator):
             for h in hooks:
                 h.remove()
             for n, m in mods.items():
-                m.raw_input, m.raw_out = saved[n][0], saved[n][1]
-                if hasattr(m, "metric"):
-                    m.raw_grad = saved[n][2]
+                for a, v in zip(("raw_input", "raw_out", "raw_grad"), saved[n]):
+                    if v is missing:
+                        m.__dict__.pop(a, None)
+                    else:
+                        setattr(m, a, v)
         return entry
 
     def _capture_passes_graph(self, names, dev, bs, raw_pred_softmax):
