@@ -92,7 +92,7 @@ def exchange_intervals(wrapped_modules, owner):
     names = list(wrapped_modules)
     dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
     # slot shapes: 5 attrs x (1 + ndim, up to 8 dims) per module, encoded as ints (0 = absent)
-    shape_tab = torch.zeros(len(names), len(INTERVAL_ATTRS), 9, dtype=torch.int64, device=dev)
+    shape_tab = torch.zeros(len(names), len(INTERVAL_ATTRS), 9, dtype=torch.int64)      # filled on the host: one transfer
     packed = {}
     for i, n in enumerate(names):
         if owner[n] != rank:
@@ -104,6 +104,7 @@ def exchange_intervals(wrapped_modules, owner):
             shape_tab[i, j, 0] = 1 + len(shp)
             for k, s in enumerate(shp[:8]):
                 shape_tab[i, j, 1 + k] = s
+    shape_tab = shape_tab.to(dev)
     dist.all_reduce(shape_tab, op=dist.ReduceOp.MAX)
     shape_tab = shape_tab.cpu()
     offsets, total = {}, 0
@@ -119,13 +120,17 @@ def exchange_intervals(wrapped_modules, owner):
             offsets[(n, a)] = (total, numel, shp)
             total += numel
     vec = torch.zeros(total, dtype=torch.float32, device=dev)
+    mine, where = [], []                       # this rank's values and their positions: one cat + one index_copy_
     for n, vals in packed.items():
         k = 0
         for a in INTERVAL_ATTRS:
             if (n, a) in offsets and getattr(wrapped_modules[n], a, None) is not None:
                 off, numel, _ = offsets[(n, a)]
-                vec[off:off + numel] = vals[k].to(dev)
+                mine.append(vals[k].to(dev).reshape(-1)[:numel])
+                where.append(torch.arange(off, off + numel))
                 k += 1
+    if mine:
+        vec.index_copy_(0, torch.cat(where).to(dev), torch.cat(mine))
     parts = [torch.empty(total, dtype=torch.float32, device=dev) for _ in range(world)]
     dist.all_gather(parts, vec)        # one collective: a few KB per rank (RCCL over xGMI on the GPU box, gloo in tests)
     gathered = torch.stack(parts)
