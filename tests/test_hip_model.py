@@ -608,3 +608,50 @@ def test_capture_pass_size_does_not_change_the_captured_tensors():
             worst = max(worst, float((a - b).abs().max() / a.abs().max()))
     print(f"[capture] passes of 8 vs 4 images, fixed target: captured tensors within {worst:.1e} of the tensor maximum")
     assert worst <= 5e-5, worst
+
+
+def _rccl_worker(port, q):
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    from ptq4vit_amd.utils import shard
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        g, net, wrapped = _mini()
+        images = torch.from_numpy(g["images"]).cuda()
+
+        class Loader:
+            batch_size = images.shape[0]
+
+            def __iter__(self):
+                yield images, None
+
+        HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
+        before = _intervals(wrapped)
+        n = shard.exchange_intervals(wrapped, {name: 0 for name in wrapped})      # all_reduce + all_gather on device tensors
+        dist.barrier()
+        after = _intervals(wrapped)
+        same = all(torch.equal(a, b) for k in before for a, b in zip(before[k], after[k]))
+        q.put(("ok", int(n), same))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 - reported to the parent
+        q.put(("error", repr(e), False))
+
+
+def test_interval_exchange_runs_over_rccl():
+    """The only collective of the default multi-GPU path (shard.exchange_intervals: one all_reduce of the slot table, one
+    all_gather of the interval vector) on the `nccl` (= RCCL) backend with device tensors.  One GPU per box, so world_size is
+    1 -- what this pins is that the RCCL code path (device placement, dtypes, the calls themselves) runs and is the identity."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    status, n, same = q.get(timeout=300)
+    p.join(60)
+    assert status == "ok", n
+    assert n > 0 and same
