@@ -12,6 +12,7 @@ reference experiment uses.  Differences in HOW (not WHAT):
   calibrated intervals are exchanged with one all-gather at the end (ptq4vit_amd/utils/shard.py).
 """
 import os
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -397,6 +398,17 @@ class HessianQuantCalibrator(QuantCalibrator):
         use_graph = getattr(self, "use_graph", None)
         if use_graph is False:
             return False
+        import time
+        trace = os.environ.get("P4V_CAPTURE_TRACE") == "1"
+
+        def tick(label, t_prev):
+            if not trace:
+                return t_prev
+            torch.cuda.synchronize(dev)
+            now = time.time()
+            print(f"[capture] {label}: {now - t_prev:.3f} s", file=sys.stderr, flush=True)
+            return now
+        t_ = time.time()
         cache = self.net.__dict__.setdefault("_p4v_capture_graphs", {})
         key = self._graph_key(dev, bs, inp)
         lanes = cache.get(key)
@@ -419,6 +431,7 @@ class HessianQuantCalibrator(QuantCalibrator):
                 break
             lanes.append(entry)
         n_lanes = max(1, min(want, n_sub, len(lanes)))
+        t_ = tick(f"graphs ready ({len(lanes)} instance(s))", t_)
         from .. import engine
         flat_dsts, plans = [], []
         for li in range(n_lanes):
@@ -450,6 +463,7 @@ class HessianQuantCalibrator(QuantCalibrator):
                 table = torch.tensor(rows, dtype=torch.int64).to(dev)
                 max_bytes = max(r[2] for r in rows)
             plans.append((lanes[li], table, len(block), max_bytes, other))
+        t_ = tick(f"caches allocated ({sum(d.numel() * 4 for d in flat_dsts) / 2**30:.1f} GiB)", t_)
         main = torch.cuda.current_stream(dev)
         streams = [main] if n_lanes == 1 else engine.side_streams(dev, n_lanes)
         for s_ in streams:
@@ -469,6 +483,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         for s_ in streams:
             if s_ is not main:
                 main.wait_stream(s_)
+        tick(f"{n_sub} replays + appends on {n_lanes} stream(s)", t_)
         return True
 
     def _capture_passes(self, dev, bs, raw_pred_softmax, with_grad, stride=None):
