@@ -214,15 +214,25 @@ class HessianQuantCalibrator(QuantCalibrator):
 
     SEARCH_HEADROOM_BYTES = 44 << 30
 
-    def _resolve_budget(self):
+    def _resolve_budget(self, replay_is_cheap=False):
+        """Bytes of captured tensors resident at a time: what the GPU has free minus head room for the search workspaces.
+        `P4V_COLD_GROUP_GIB=<n>` additionally caps a group at n GiB while the memory would have to come fresh from the
+        driver and a capture pass is a cheap graph replay (`replay_is_cheap`).  Measured on MI355X (tools/alloc_probe.py,
+        P4V_CAPTURE_TRACE=1): the FIRST process that maps ~190 GiB on a freshly started box waits 3.5-5.5 s for it (Swin-B/384
+        x 128: 64 GiB groups bring that capture from 4.6-7.7 s to 2.6 s), every later process gets the same memory in
+        milliseconds and is better off with one resident group (1.0 s) -- hence off by default."""
         if self.cache_budget_bytes is not None:
             return int(self.cache_budget_bytes)
         dev = _dev_of(self.net)
         if dev.type != "cuda":
             return 96 << 30
         free, _total = torch.cuda.mem_get_info(dev)
-        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)    # cached by torch's allocator: reusable
-        return max(8 << 30, int(free) - self.SEARCH_HEADROOM_BYTES)
+        pooled = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)    # cached by torch's allocator: reusable
+        budget = max(8 << 30, int(free + pooled) - self.SEARCH_HEADROOM_BYTES)
+        cold = int(float(os.environ.get("P4V_COLD_GROUP_GIB", "0")) * 2**30)     # 0: no cap
+        if replay_is_cheap and cold > 0:
+            budget = min(budget, max(cold, int(pooled)))
+        return budget
 
     # ---- capture ------------------------------------------------------------------------------------
     def _ref_bs(self):
@@ -617,7 +627,12 @@ class HessianQuantCalibrator(QuantCalibrator):
         if want_shard is None:
             want_shard = os.environ.get("P4V_SHARD_CAPTURE", "0") == "1"
         shard_cap = False
-        budget = self._resolve_budget()
+        dev_ = _dev_of(self.net)
+        replay_is_cheap = (with_grad and dev_.type == "cuda" and not self.sequential and getattr(self, "use_graph", None) is not False
+                           and len(list(self.calib_loader)) == 1
+                           and (getattr(self, "use_graph", None) is True or n_sub >= 24 or self.net.__dict__.get("_p4v_calibrations", 0) > 0
+                                or bool(self.net.__dict__.get("_p4v_capture_graphs"))))
+        budget = self._resolve_budget(replay_is_cheap)
 
         def plan(todo, budget_):
             if self.sequential:
