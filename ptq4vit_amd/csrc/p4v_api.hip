@@ -102,7 +102,7 @@ std::atomic<int> g_variant_word{0};
 #define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[8];
-enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6 };   // P6: k_sweep6 prologue, 0.1 us
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7 };   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -596,8 +596,9 @@ struct Pass {
     EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
 };
 
-static const long PLANE_BUDGET = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
-static const long PLANE_CACHE_MAX = 3L << 30;   // largest candidate-expanded plane kept across the rounds of one call
+static const long PLANE_BUDGET_DEFAULT = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
+#define PLANE_BUDGET (tune(TUNE_PLANE_GIB) > 0 ? ((long)tune(TUNE_PLANE_GIB) << 30) : PLANE_BUDGET_DEFAULT)
+#define PLANE_CACHE_MAX (PLANE_BUDGET / 2)      // largest candidate-expanded plane kept across the rounds of one call
 
 // How many candidate groups (gridDim.z) to split a sweep into.  Splitting raises the workgroup count (fills the
 // 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary

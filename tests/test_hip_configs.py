@@ -54,6 +54,10 @@ def _run_config(model, bits, calib, oracle_matmul=None, logits_rel=0.35):
 
     torch.cuda.empty_cache()
     engine.release_workspace()
+    import os
+    if os.environ.get("P4V_TEST_PLANE_GIB"):          # tuning runs only (tools/): plane budget of the search workspaces
+        engine.debug_tuning(7, int(os.environ["P4V_TEST_PLANE_GIB"]))
+        HessianQuantCalibrator.SEARCH_HEADROOM_BYTES = int(os.environ.get("P4V_TEST_HEADROOM_GIB", "44")) << 30
     saved = _set_bits(PTQ4ViT, bits)
     try:
         net = models.get_net(model, seed=0, device="cuda")
