@@ -747,7 +747,6 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
     const int g = lane >> 5, l31 = lane & 31;
 
     // Tile order.  The ~32 workgroups that run concurrently on one XCD (consecutive t after xcd_remap) should touch as
@@ -768,6 +767,27 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
     if (c_lo >= c_hi) return;
+
+    // Which 64 x 32 part of the tile this wave computes.  Parts that hold only padding (attn.v: N = 64 of a 128-column tile;
+    // 197 tokens: the last 32-row / 32-column blocks) do no MFMA and no epilogue work -- their waves still move their share
+    // of the operand stream and keep the barriers.  Waves w and w + 4 share a SIMD, so the parts WITH work are dealt to
+    // wave ids 0, 1, 2, ... first: they spread over the four SIMDs instead of leaving whole SIMDs to the padding.
+    int pos = wid;
+    {
+        auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
+        int cnt = 0, found = -1;
+        for (int q = 0; q < 8; ++q)
+            if (useful(q)) { if (cnt == wid) found = q; ++cnt; }
+        if (found < 0) {
+            int k = wid - cnt;
+            for (int q = 0; q < 8; ++q)
+                if (!useful(q)) { if (k == 0) found = q; --k; }
+        }
+        pos = __builtin_amdgcn_readfirstlane(found);
+    }
+    const int wr = pos >> 2, wc = pos & 3;
+    const bool act = (n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M);
+    const bool act1 = act && (m0 + wr * 64 + 32 < p.M);              // second 32-row block of the part
 
     // ---- candidate-invariant epilogue operands (identical to k_sweep) -----------------------------
     float u[2][16], w[2][16];
@@ -813,8 +833,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     float* s1tab = res + per * 8;
     float* s2tab = s1tab + per * 8;
     for (int i = lane; i < c_hi - c_lo; i += 64) {
-        s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
-        if (TWIN) s2tab[i * 8 + wid] = p.S2 ? p.S2[(c_lo + i) * p.s_cs + sb] : 1.0f;
+        s1tab[i * 8 + pos] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+        if (TWIN) s2tab[i * 8 + pos] = p.S2 ? p.S2[(c_lo + i) * p.s_cs + sb] : 1.0f;
     }
 
     // ---- LDS-DMA addressing: wave `wid` fills rows [16*wid, 16*wid+16) of every plane ------------------
@@ -884,6 +904,14 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         if (it + 2 < total) wait_vmcnt<NPL>(); else wait_vmcnt<0>();   // pieces of tile it+2 may stay in flight
         __builtin_amdgcn_s_barrier();
         if (it + SW2_NS - 1 < total) issue((ST + SW2_NS - 1) % SW2_NS);
+        if (!act) {                                    // a part of pure padding: stream and barriers only
+            if (++kt == ktiles) {
+                if (!STORES && lane == 63) res[(c - c_lo) * 8 + pos] = 0.0f;
+                kt = 0;
+                ++c;
+            }
+            return;
+        }
         if (it + 1 < total) {
             read_fr(nxt, std::integral_constant<int, (ST + 1) % SW2_NS>{});
             __builtin_amdgcn_s_waitcnt(0xC07F | (NRD << 8));          // the reads just issued stay in flight
@@ -893,20 +921,20 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         asm volatile("" : "+v"(cur.b0), "+v"(cur.b1), "+v"(cur.a00), "+v"(cur.a10), "+v"(cur.a01), "+v"(cur.a11) :: "memory");
         if (TWIN) asm volatile("" : "+v"(cur.c00), "+v"(cur.c10), "+v"(cur.c01), "+v"(cur.c11));
         acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a00, cur.b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a10, cur.b0, acc[1], 0, 0, 0);
+        if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a10, cur.b0, acc[1], 0, 0, 0);
         if (TWIN) {
             acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c00, cur.b0, acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c10, cur.b0, acc2[1], 0, 0, 0);
+            if (act1) acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c10, cur.b0, acc2[1], 0, 0, 0);
         }
         acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a01, cur.b1, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a11, cur.b1, acc[1], 0, 0, 0);
+        if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a11, cur.b1, acc[1], 0, 0, 0);
         if (TWIN) {
             acc2[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c01, cur.b1, acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c11, cur.b1, acc2[1], 0, 0, 0);
+            if (act1) acc2[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.c11, cur.b1, acc2[1], 0, 0, 0);
         }
         if (++kt == ktiles) {
-            const float s1 = s1tab[(c - c_lo) * 8 + wid];
-            const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + wid] : 1.0f;
+            const float s1 = s1tab[(c - c_lo) * 8 + pos];
+            const float s2 = TWIN ? s2tab[(c - c_lo) * 8 + pos] : 1.0f;
             if constexpr (STORES) {
                 // quant_forward (EPI_FWD: scale * acc + bias) / folded twin target (EPI_STORE: raw_out - bias - scale * acc):
                 // same arithmetic as the generic k_sweep, 128-byte coalesced rows
@@ -929,7 +957,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
             // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !act1) break;              // (its accumulators were never touched: still zero)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const v2f a = {(float)acc[i][r], (float)acc[i][r + 1]};
@@ -944,8 +973,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                     acc[i][r] = 0; acc[i][r + 1] = 0;
                     if (TWIN) { acc2[i][r] = 0; acc2[i][r + 1] = 0; }
                 }
+            }
             const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
-            if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
+            if (lane == 63) res[(c - c_lo) * 8 + pos] = sum;
             kt = 0;
             ++c;
         }
@@ -988,7 +1018,6 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
     const int g = lane >> 5, l31 = lane & 31;
 
     const int nwg = p.mtiles * p.ntiles;
@@ -1000,6 +1029,25 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
+
+    // the 64 x 32 part of this wave; parts of pure padding do no MFMA / epilogue work and parts with work are dealt to wave
+    // ids 0, 1, ... first (they spread over the SIMDs) -- see k_sweep2
+    int pos = wid;
+    {
+        auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
+        int cnt = 0, found = -1;
+        for (int q = 0; q < 8; ++q)
+            if (useful(q)) { if (cnt == wid) found = q; ++cnt; }
+        if (found < 0) {
+            int k = wid - cnt;
+            for (int q = 0; q < 8; ++q)
+                if (!useful(q)) { if (k == 0) found = q; --k; }
+        }
+        pos = __builtin_amdgcn_readfirstlane(found);
+    }
+    const int wr = pos >> 2, wc = pos & 3;
+    const bool act = (n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M);
+    const bool act1 = act && (m0 + wr * 64 + 32 < p.M);              // second 32-row block of the part
 
     // ---- candidate-invariant epilogue operands (as k_sweep2) --------------------------------------------------------------
     float u[2][16], w[2][16];
@@ -1036,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     const int nw0 = n0 + wc * 32;
     const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
     float* s1tab = res + per * 8;
-    for (int i = lane; i < ncand; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * 8 + pos] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
     // ---- the fixed operand's fragments: registers for the whole sweep (ldk = 64: one k-tile) ----------------------------------
     v4i fx[2][2];                                        // [32-row block (row side only)][k-half]
@@ -1096,6 +1144,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         if (it + SW8_NS - 1 < ncand) wait_vmcnt<SW8_NS - 2>(); else wait_vmcnt<0>();   // (tail: no younger pieces are counted on)
         __builtin_amdgcn_s_barrier();
         if (it + SW8_NS - 1 < ncand) issue((ST + SW8_NS - 1) % SW8_NS);
+        if (!act) {                                    // a part of pure padding: stream and barriers only
+            if (lane == 63) res[(c - c_lo) * 8 + pos] = 0.0f;
+            ++c;
+            return;
+        }
         if (it + 1 < ncand) {
             read_fr(nxt, std::integral_constant<int, (ST + 1) % SW8_NS>{});
             __builtin_amdgcn_s_waitcnt(0xC07F | (NRD << 8));
@@ -1106,20 +1159,21 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         if (!ROWS_FIXED) asm volatile("" : "+v"(curf.t10), "+v"(curf.t11));
         if (ROWS_FIXED) {      // A (rows) in registers, B (columns) streamed
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][0], curf.t00, zero16, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][0], curf.t00, zero16, 0, 0, 0);
+            if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][0], curf.t00, zero16, 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][1], curf.t01, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][1], curf.t01, acc[1], 0, 0, 0);
+            if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][1], curf.t01, acc[1], 0, 0, 0);
         } else {               // A (rows) streamed, B (columns) in registers
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t00, fx[0][0], zero16, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t10, fx[0][0], zero16, 0, 0, 0);
+            if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t10, fx[0][0], zero16, 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t01, fx[0][1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t11, fx[0][1], acc[1], 0, 0, 0);
+            if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(curf.t11, fx[0][1], acc[1], 0, 0, 0);
         }
         // ---- fused similarity epilogue of candidate c: one float per wave -----------------------------------------------
-        const float s1 = s1tab[(c - c_lo) * 8 + wid];
+        const float s1 = s1tab[(c - c_lo) * 8 + pos];
         v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !act1) break;                  // a block of pure padding rows
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const v2f a = {(float)acc[i][r], (float)acc[i][r + 1]};
@@ -1131,8 +1185,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
                 else if (EPI == EPI_ABS) sum2 += v2f{fabsf(d.x), fabsf(d.y)};
                 else sum2 = (ww * d) * d + sum2;
             }
+        }
         const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
-        if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
+        if (lane == 63) res[(c - c_lo) * 8 + pos] = sum;
         ++c;
     };
     if (ncand >= SW8_NS) wait_vmcnt<SW8_NS - 2>(); else wait_vmcnt<0>();
