@@ -101,8 +101,8 @@ std::atomic<int> g_variant_word{0};
 #define g_variant (g_variant_word.load(std::memory_order_relaxed) & 0x3fffffff)
 #define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
-std::atomic<int> g_tune[8];
-enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7 };   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+std::atomic<int> g_tune[16];
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8 };   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -684,15 +684,18 @@ int run_pass(Ctx& c, Pass& ps) {
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
     // k_sweep6: epilogue operands in fragment order, one image per 256 x 64 tile (8 bytes per output element)
     const int s6_stiles = (a_search ? Np : Mp) / 256, s6_ttiles = (int)cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
-    const size_t epi6_bytes = regs6 ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
-    EpiCache* ec = (regs6 && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
+    // (only where the in-place gather is uncoalesced: the activation search, whose tile is transposed; in the weight search the
+    // lanes of a load already read consecutive features)
+    const bool epi6_on = regs6 && (a_search || tune(TUNE_EPI6W) == 1);
+    const size_t epi6_bytes = epi6_on ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
+    EpiCache* ec = (epi6_on && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
     if (ec && !ec->assigned) {
         ec->buf = c.ws.get_top(epi6_bytes);
         ec->assigned = true; ec->valid = false;
     }
-    float* epi6 = !regs6 ? nullptr : ec ? reinterpret_cast<float*>(ec->buf) : c.ws.get<float>(epi6_bytes / 4);
+    float* epi6 = !epi6_on ? nullptr : ec ? reinterpret_cast<float*>(ec->buf) : c.ws.get<float>(epi6_bytes / 4);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
-    if (regs6 && !c.dry && !(ec && ec->valid)) {
+    if (epi6_on && !c.dry && !(ec && ec->valid)) {
         PrepEpi6Params pe{};
         pe.O = ps.O; pe.Wt = ps.G ? ps.G : ps.O; pe.bias = ps.bias ? ps.bias : zero_bias;
         pe.o_ss = a_search ? ps.o_ns : ps.o_ms; pe.o_ts = a_search ? ps.o_ms : ps.o_ns;
@@ -1881,7 +1884,7 @@ int p4v_debug_set_variant(int variant, int force_generic) {
 }
 
 int p4v_debug_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) return fail(P4V_ERR_INVALID, "p4v_debug_set_tuning: unknown key %d", key);
+    if (key < 0 || key >= 16) return fail(P4V_ERR_INVALID, "p4v_debug_set_tuning: unknown key %d", key);
     g_tune[key].store(value, std::memory_order_relaxed);
     return 0;
 }

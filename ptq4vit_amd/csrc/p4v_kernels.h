@@ -773,7 +773,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     // of the operand stream and keep the barriers.  Waves w and w + 4 share a SIMD, so the parts WITH work are dealt to
     // wave ids 0, 1, 2, ... first: they spread over the four SIMDs instead of leaving whole SIMDs to the padding.
     int pos = wid;
-    {
+    constexpr bool SKIP = !(EPI == EPI_FWD || EPI == EPI_STORE);     // (the one-candidate store passes: not worth their registers)
+    if constexpr (SKIP) {
         auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
         int cnt = 0, found = -1;
         for (int q = 0; q < 8; ++q)
@@ -786,8 +787,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         pos = __builtin_amdgcn_readfirstlane(found);
     }
     const int wr = pos >> 2, wc = pos & 3;
-    const bool act = (n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M);
-    const bool act1 = act && (m0 + wr * 64 + 32 < p.M);              // second 32-row block of the part
+    const bool act = !SKIP || ((n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M));
+    const bool act1 = !SKIP || (act && (m0 + wr * 64 + 32 < p.M));   // second 32-row block of the part
 
     // ---- candidate-invariant epilogue operands (identical to k_sweep) -----------------------------
     float u[2][16], w[2][16];
@@ -1985,7 +1986,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming), in
     // fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in) ---------------------
     float u[RB][2][16], w[RB][2][16];
-    {
+    if (p.E) {
         const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -2002,6 +2003,42 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = u4[e]; w[i][cb][q * 4 + e] = w4[e]; }
                 }
+    } else {
+        // in place (weight search: the streaming rows are the output features, the contiguous dimension of raw_out, so the 32
+        // lanes of a half wave read 128 contiguous bytes per load): every load issued unconditionally at clamped addresses,
+        // then branch-free masking / weight selection
+        const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
+        const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
+        const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int tr = t0 + cb * 32 + l31;
+            const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
+            const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
+            const bool t_ok = tr < p.TR;
+            float bs[RB][16];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int src = min(s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1);
+                    const long idx = toff + (long)src * p.o_ss;
+                    u[i][cb][r] = p.O[idx];
+                    w[i][cb][r] = p.Wt[idx];
+                    bs[i][r] = p.bias[p.bias_on_t ? 0 : src];
+                }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = t_ok && (s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
+                    const float o = u[i][cb][r], gw = w[i][cb][r];
+                    const float b = p.bias_on_t ? bias_t : bs[i][r];
+                    const unsigned wbits = (__builtin_bit_cast(unsigned, gw) & m_g) | (__builtin_bit_cast(unsigned, o) & m_o) | m_1;
+                    u[i][cb][r] = ok ? o - b : 0.0f;
+                    w[i][cb][r] = ok ? __builtin_bit_cast(float, wbits) : 0.0f;
+                }
+        }
     }
     const int blk_row = p.sb_on_t ? t0 : s0;
     const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));

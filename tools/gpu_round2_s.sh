@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 2, call s: cost-model prologue constant of k_sweep6 after the fragment-order prologue
-cd /root/repo
-for P in 0 150 100 60 30; do
-  echo "P6=$P: $(python tools/bench_layer.py --layer qkv,proj,fc1 --rounds 3 --reps 3 --kernel-stats --tune 6=$P 2>&1 | grep 'sweep6:' | sed 's/launches, //; s/TOP.*//' | tr '\n' ' ')"
+# round 2: k_sweep6 weight-search prologue: in place (default) vs fragment-order image (tune 8=1)
+cd /root/repo; export TMPDIR=/tmp
+for T in 0 1 0 1; do
+  echo "EPI6W=$T: $(python tools/bench_layer.py --layer qkv,proj,fc1 --rounds 3 --reps 3 --kernel-stats --tune 8=$T 2>&1 | grep 'sweep6:\|per calibration' | sed 's/launches, //; s/TOP.*//; s/(3 round.*//' | tr '\n' ' ')"
 done
