@@ -1142,7 +1142,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     // MFMAs and the epilogue of candidate it.
     auto step = [&](int it, auto stage_c, Fr& curf, Fr& nxt) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_c)::value;
-        if (it + SW8_NS - 1 < ncand) wait_vmcnt<SW8_NS - 2>(); else wait_vmcnt<0>();   // (tail: no younger pieces are counted on)
+        // pieces of candidates .. it+6 have been issued; the fragments of candidate it+1 are read below, so at most the FIVE
+        // youngest (it+2 .. it+6) may still be in flight.  (The first version waited for vmcnt <= 6, i.e. only proved
+        // candidate `it`: harmless while every step took a microsecond, a race once workgroups of mostly-padding parts
+        // began to step faster than the DMA latency / 6.)
+        if (it + SW8_NS - 1 < ncand) wait_vmcnt<SW8_NS - 3>(); else wait_vmcnt<0>();   // (tail: no younger pieces are counted on)
         __builtin_amdgcn_s_barrier();
         if (it + SW8_NS - 1 < ncand) issue((ST + SW8_NS - 1) % SW8_NS);
         if (!act) {                                    // a part of pure padding: stream and barriers only

@@ -1,8 +1,4 @@
 #!/bin/bash
-# round 2, call q: k_sweep6 ablations on fc1 (timing only)
-cd /root/repo; LAYER=${LAYER:-fc1}
-mkdir -p gpurun_out
-for d in 0 16 32 48; do
-  if [ $d = 0 ]; then L=""; else L="P4V_LIB=/root/repo/ptq4vit_amd/csrc/dbg/libp4v_sw6dbg$d.so"; fi
-  echo "DBG $d: $(env $L python tools/bench_layer.py --layer $LAYER --rounds 1 --reps 3 --kernel-stats 2>&1 | grep 'sweep6:')"
-done | tee gpurun_out/q_ablate.log
+cd /root/repo
+for i in 1 2 3 4 5 6; do echo "run $i: $(python -m pytest tests/test_hip_parity.py -x -q -m gpu -k 'matmul_baseline_shapes or single_ktile or split_search or matmul_vs' 2>&1 | grep -a '^E  .*Error\|passed\|failed' | head -2 | tr '\n' ' ')"; done
+python tools/bench_layer.py --layer qk --rounds 3 --reps 3 --kernel-stats 2>&1 | grep 'sweep_i8\|per calibration'
