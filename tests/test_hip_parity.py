@@ -424,3 +424,40 @@ def test_split_search_kernel_matches_the_generic_fp32_sweep(eng, shape, metric):
     assert_scores_close(sn[0, 0, :20, 0], so[0, 0, :20, 0], rtol=2e-5, what="k_sos_split vs fp32 sweep (split table)")
     assert_scores_close(sn[0, 1], so[0, 1], rtol=1e-6, what="B search after the split search")
     assert torch.equal(new[1], old[1]) and torch.equal(new[4], old[4])
+
+
+@pytest.mark.parametrize("kind,b,H,S,D", [("qk", 64, 4, 144, 32), ("qk", 8, 12, 197, 64), ("sv", 64, 4, 144, 32), ("sv", 8, 12, 197, 64),
+                                           ("qk", 96, 3, 49, 32)],
+                         ids=["qk-swin-w12", "qk-vit-b", "sv-swin-w12", "sv-vit-b", "qk-swin-w7"])
+def test_attention_sweeps_are_run_to_run_deterministic(eng, kind, b, H, S, D):
+    """Six calibrations of the same attention matmul must agree bit for bit (score tables, selections, intervals).  Token counts
+    that leave most of a 128 x 128 tile as padding make some workgroups step through their candidates much faster than the
+    others: the first version of k_sweep8 proved the landing of the wrong ring stage and lost this test two runs out of three."""
+    A, B, out, grad = _mk_attention(41, b, H, S, D, kind)
+    hp = dict(A_bit=8, B_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, sos=(kind == "sv"))
+    Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1) if kind == "qk" else _t(B)
+    args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(grad), want_scores=True)
+    first = eng.matmul_calibrate(**args, **hp)
+    for run in range(5):
+        again = eng.matmul_calibrate(**args, **hp)
+        torch.cuda.synchronize()
+        for x, y in zip(first, again):
+            if x is not None:
+                assert torch.equal(x, y), f"run {run + 2} differs from run 1"
+
+
+@pytest.mark.parametrize("b,T,K,N,nV,gelu", [(1, 197, 768, 768, 1, False), (2, 50, 3072, 768, 1, True), (1, 10, 384, 1152, 3, False),
+                                             (3, 197, 1024, 1024, 1, False), (1, 5, 192, 192, 1, False)],
+                         ids=["proj-1img", "fc2-twin-100rows", "qkv-s-10rows", "vit-l-proj", "tiny"])
+def test_linear_sweeps_are_run_to_run_deterministic(eng, b, T, K, N, nV, gelu):
+    """The same for the Linear sweeps at row counts that leave most tiles empty (k_sweep6 / k_sweep7 / k_sweep2g rings)."""
+    w, bias, x, out, grad = _mk_linear(43, b, T, K, N, postgelu=gelu)
+    hp = dict(w_bit=8, a_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, n_V=nV, n_H=1, n_a=1)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), postgelu=gelu, want_scores=True)
+    first = eng.linear_calibrate(**args, **hp)
+    for run in range(4):
+        again = eng.linear_calibrate(**args, **hp)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(first, again):
+            if a_ is not None:
+                assert torch.equal(a_, b_), f"run {run + 2} differs from run 1"
