@@ -1031,10 +1031,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
-    // the 64 x 32 part of this wave; parts of pure padding do no MFMA / epilogue work and parts with work are dealt to wave
-    // ids 0, 1, ... first (they spread over the SIMDs) -- see k_sweep2
+    // the 64 x 32 part of this wave; the padding skip of k_sweep2 (parts of pure padding do no work, parts with work are dealt
+    // to wave ids 0, 1, ... first) is compiled out here:
     int pos = wid;
-    {
+    // (measured at 197 tokens, where only 4 of 32 parts are pure padding: 459 us per pass with the skip, 428 without -- the
+    // remap costs more registers and branches than the idle parts give back; attn.v in k_sweep2, half padding, gains 17 %)
+    constexpr bool SKIP = false;
+    if constexpr (SKIP) {
         auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
         int cnt = 0, found = -1;
         for (int q = 0; q < 8; ++q)
@@ -1047,8 +1050,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         pos = __builtin_amdgcn_readfirstlane(found);
     }
     const int wr = pos >> 2, wc = pos & 3;
-    const bool act = (n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M);
-    const bool act1 = act && (m0 + wr * 64 + 32 < p.M);              // second 32-row block of the part
+    const bool act = !SKIP || ((n0 + wc * 32 < p.N) && (m0 + wr * 64 < p.M));
+    const bool act1 = !SKIP || (act && (m0 + wr * 64 + 32 < p.M));   // second 32-row block of the part
 
     // ---- candidate-invariant epilogue operands (as k_sweep2) --------------------------------------------------------------
     float u[2][16], w[2][16];
