@@ -2372,9 +2372,12 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);          // logical 16-B chunk landing in physical slot lane & 3
     const unsigned voff0 = (unsigned)(ld_row * p.ldk + ld_chunk * 16);
     const unsigned voff1 = voff0 + 16u * (unsigned)p.ldk;
-    const char* curR = (const char*)p.R + (long)(r0 + wid * 32) * p.ldk + (long)c_lo * p.r_cs;
+    // (timing-only ablation 8: every workgroup streams the bytes of tile (0, 0), candidate group 0 -- what is left of the
+    // stream's cost when it always hits in the L2)
+    const int r0a = (P4V_SW7_DBG & 8) ? 0 : r0, m0a = (P4V_SW7_DBG & 8) ? 0 : m0, c_loa = (P4V_SW7_DBG & 8) ? p.c0 : c_lo;
+    const char* curR = (const char*)p.R + (long)(r0a + wid * 32) * p.ldk + (long)c_loa * p.r_cs;
     const char* cbase = (TWIN && wid >= 4) ? (const char*)p.C2 : (const char*)p.Cp;
-    const char* curC = cbase + (long)(m0 + (TWIN ? (wid & 3) * 32 : wid * 32)) * p.ldk + (TWIN ? 0L : (long)c_lo * p.c_cs);
+    const char* curC = cbase + (long)(m0a + (TWIN ? (wid & 3) * 32 : wid * 32)) * p.ldk + (TWIN ? 0L : (long)c_loa * p.c_cs);
     const int ktiles = p.ktiles;
     const long wrapR = p.r_cs - (long)ktiles * SW_BKB, wrapC = (TWIN ? 0L : p.c_cs) - (long)ktiles * SW_BKB;
     const int total = ncand * ktiles;
