@@ -274,3 +274,45 @@ def test_get_similarity_matches_the_oracle(metric):
     else:
         want_c = orc.elementwise_similarity(raw_c.numpy(), sim_c.numpy(), metric, grad_c.numpy())
     np.testing.assert_allclose(got, want_c, rtol=2e-6, atol=1e-9)
+
+
+def test_capture_cache_layout_helpers():
+    """quant_calib._cache_like / _same_dense_block (the capture's one-launch append): a cache keeps the hooked tensor's memory
+    layout exactly when a sub-batch piece is then ONE dense block of it; everything else falls back to a contiguous cache and
+    torch's copy."""
+    from ptq4vit_amd.utils.quant_calib import _cache_like, _same_dense_block
+    k = torch.randn(4, 3, 7, 5)
+    cases = {
+        "contiguous": (torch.randn(4, 7, 5), True),
+        "k.transpose(-2, -1) (batch-major dense permutation)": (k.transpose(-2, -1), True),
+        "gapped view": (torch.randn(4, 7, 10)[:, :, :5], False),
+        "batch not outermost in memory": (torch.randn(7, 4, 5).transpose(0, 1), False),
+        "1-D": (torch.randn(6), True),
+    }
+    for what, (t, dense) in cases.items():
+        c = _cache_like(t, 3)
+        assert tuple(c.shape) == (3 * t.shape[0],) + tuple(t.shape[1:]), what
+        assert _same_dense_block(c, t) == dense, what
+        if dense:      # a flat copy of t's storage block IS the copy of piece 1
+            n = t.numel()
+            c.as_strided((n,), (1,), storage_offset=n).copy_(t.as_strided((n,), (1,), storage_offset=t.storage_offset()))
+            assert torch.equal(c[t.shape[0]:2 * t.shape[0]], t), what
+    assert not _same_dense_block(_cache_like(k.half(), 2), k.half())          # the append kernel moves 4-byte elements
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r*_bench.json is a line bench.py printed on the MI355X: the fields the driver and the judge read."""
+    import glob
+    path = sorted(glob.glob("profiles/r*_bench.json"))[-1]
+    d = json.loads(open(path).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "layers/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 74 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert abs(r["achieved"] - r["ops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "layers/s" and c["sample"]
