@@ -533,6 +533,18 @@ class HessianQuantCalibrator(QuantCalibrator):
         # running: hold them until everything has been joined so that the allocator cannot hand the memory out again
         keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
         todo = list(names)
+        if os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt":
+            # longest first (by the size of what a search sweeps: rows x K x N), so that the last modules in flight are the
+            # small ones and the streams run dry together; the results do not depend on the order
+            def work(n):
+                m = self.wrapped_modules[n]
+                ri = m.raw_input
+                if isinstance(ri, (list, tuple)):                       # matmul: batch*heads x M x K x N
+                    a, b = ri
+                    return float(a.numel()) * b.shape[-1] * (0.2 if a.shape[-1] <= 64 else 1.0)
+                w = getattr(m, "weight", None)
+                return float(ri.numel()) / max(1, ri.shape[-1] if ri.dim() != 4 else 1) * (w.numel() if w is not None else 1) / (1 if ri.dim() != 4 else ri.shape[1])
+            todo.sort(key=work, reverse=True)
         lock = threading.Lock()
         errors = []
 
