@@ -576,8 +576,16 @@ class HessianQuantCalibrator(QuantCalibrator):
             raise errors[0]
 
     def _estimate_cache_bytes(self, names):
-        """One cheap probe forward of a single image to size the caches of `names`."""
+        """One cheap probe forward of a single image to size the caches of `names` (kept with the network: the sizes depend
+        on the architecture and the image geometry only; every rank of a sharded calibration needs them each time)."""
         dev = _dev_of(self.net)
+        geom = None
+        for inp, _ in self.calib_loader:
+            geom = (tuple(inp.shape[1:]), int(inp.shape[0]), tuple(self.wrapped_modules))
+            break
+        memo = self.net.__dict__.setdefault("_p4v_cache_sizes", {})
+        if geom in memo and all(n in memo[geom] for n in names):
+            return {n: memo[geom][n] for n in names}
         sizes = {}
         hooks = []
 
@@ -597,7 +605,9 @@ class HessianQuantCalibrator(QuantCalibrator):
                 break
         for h in hooks:
             h.remove()
-        return {n: s * total for n, s in sizes.items()}
+        out = {n: s * total for n, s in sizes.items()}
+        memo.setdefault(geom, {}).update(out)
+        return out
 
     # ---- entry points ------------------------------------------------------------------------------
     def quant_calib(self):
