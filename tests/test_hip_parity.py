@@ -461,3 +461,80 @@ def test_linear_sweeps_are_run_to_run_deterministic(eng, b, T, K, N, nV, gelu):
         for a_, b_ in zip(first, again):
             if a_ is not None:
                 assert torch.equal(a_, b_), f"run {run + 2} differs from run 1"
+
+
+def _random_linear_cases(n=18, seed=2024):
+    """Seeded random Linear geometries across every dispatch branch of the sweeps: K in the register-stationary set
+    (192 / 256 / 384 / 512 / 768), other K <= 768 (LDS-stationary), K >= 1024 (multiples of 256 and not), ragged rows / features,
+    1-3 row blocks, both bit widths, every difference metric, post-GELU twin or not, few candidates."""
+    rng = np.random.default_rng(seed)
+    ks = [192, 256, 384, 512, 768, 64, 100, 320, 640, 1024, 1280, 1536, 2048, 1100]
+    metrics = ["hessian", "L2_norm", "L1_norm", "linear_weighted_L2_norm", "square_weighted_L2_norm"]
+    cases = []
+    for i in range(n):
+        K = int(ks[i % len(ks)])
+        nV = int(rng.choice([1, 1, 2, 3]))
+        N = int(rng.integers(1, 9)) * 32 * nV if rng.random() < 0.6 else int(rng.integers(5, 200)) * nV
+        cases.append(dict(b=int(rng.integers(1, 4)), T=int(rng.integers(3, 140)), K=K, N=N, n_V=nV,
+                          bit=int(rng.choice([8, 8, 6, 4])), metric=str(rng.choice(metrics)), postgelu=bool(rng.random() < 0.35),
+                          eq_n=int(rng.choice([100, 100, 37, 7])), seed=100 + i))
+    return cases
+
+
+@pytest.mark.parametrize("cfg", _random_linear_cases(), ids=lambda c: f"K{c['K']}-N{c['N']}-nV{c['n_V']}-T{c['b']}x{c['T']}-w{c['bit']}-{c['metric'][:6]}-{'gelu' if c['postgelu'] else 'plain'}-c{c['eq_n']}")
+def test_random_linear_geometries_vs_oracle(eng, cfg):
+    from oracle.ptq4vit_oracle import LinearOracle
+    w, bias, x, out, grad = _mk_linear(cfg["seed"], cfg["b"], cfg["T"], cfg["K"], cfg["N"], cfg["postgelu"])
+    hp = dict(eq_alpha=0.01, eq_beta=1.2, eq_n=cfg["eq_n"], search_round=2, w_bit=cfg["bit"], a_bit=cfg["bit"], n_V=cfg["n_V"],
+              metric=cfg["metric"])
+    o = LinearOracle(w, bias, postgelu=cfg["postgelu"], **hp)
+    o.calibration_step2(x, out, grad)
+    w_iv, a_iv, scores, best = eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad),
+                                                    postgelu=cfg["postgelu"], n_H=1, n_a=1, want_scores=True, **hp)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    pairs = []
+    for r in range(2):
+        pairs.append((scores[r, 0], best[r, 0], o.trace[2 * r][1]))
+        pairs.append((scores[r, 1][:, :1], best[r, 1][:1], o.trace[2 * r + 1][1]))
+    flips = _cmp_tables(pairs, "random-linear")
+    if flips == 0:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), o.w_interval.reshape(-1))
+        np.testing.assert_array_equal(a_iv.cpu().numpy(), o.a_interval.reshape(-1))
+
+
+def _random_attention_cases(n=12, seed=77):
+    """Seeded random attention geometries: head dims 16-96 (single k-tile sweep or the streaming one), token counts from 5 to
+    300 (k_sos_split up to 200 keys, the generic fp32 split search above), 1-5 heads, both matmuls, 8 / 6 bit."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        cases.append(dict(kind="qk" if i % 2 == 0 else "sv", b=int(rng.integers(1, 4)), H=int(rng.integers(1, 6)),
+                          S=int(rng.choice([5, 17, 49, 50, 64, 129, 144, 197, 201, 257, 300])), D=int(rng.choice([16, 32, 64, 96])),
+                          bit=int(rng.choice([8, 8, 6])), metric=str(rng.choice(["hessian", "hessian", "L2_norm", "L1_norm"])), seed=300 + i))
+    return cases
+
+
+@pytest.mark.parametrize("cfg", _random_attention_cases(), ids=lambda c: f"{c['kind']}-b{c['b']}H{c['H']}S{c['S']}D{c['D']}-{c['bit']}bit-{c['metric'][:4]}")
+def test_random_attention_geometries_vs_oracle(eng, cfg):
+    from oracle.ptq4vit_oracle import MatMulOracle
+    sos = cfg["kind"] == "sv"
+    A, B, out, grad = _mk_attention(cfg["seed"], cfg["b"], cfg["H"], cfg["S"], cfg["D"], cfg["kind"])
+    hp = dict(A_bit=cfg["bit"], B_bit=cfg["bit"], metric=cfg["metric"], eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    o = MatMulOracle(sos=sos, **hp)
+    res = o.calibration_step2(A, B, out, grad)
+    Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1) if cfg["kind"] == "qk" else _t(B)
+    A_iv, B_iv, split, scores, best = eng.matmul_calibrate(A=_t(A), B=Bt, out=_t(out), grad=_t(grad), sos=sos, want_scores=True, **hp)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    pairs = []
+    for r in range(2):
+        ta, tb = o.trace[2 * r][1], o.trace[2 * r + 1][1]
+        pairs.append((scores[r, 0][:20, :1], best[r, 0][:1], ta) if sos else (scores[r, 0], best[r, 0], ta))
+        pairs.append((scores[r, 1], best[r, 1], tb))
+    flips = _cmp_tables(pairs, "random-attention")
+    if flips == 0:
+        np.testing.assert_array_equal(B_iv.cpu().numpy(), np.asarray(res["B_interval"]).reshape(-1))
+        np.testing.assert_array_equal(A_iv.cpu().numpy(), np.asarray(res["A_interval"]).reshape(-1))
+        if sos:
+            assert float(split.cpu()) == float(res["split"])
