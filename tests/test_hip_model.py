@@ -655,3 +655,35 @@ def test_interval_exchange_runs_over_rccl():
     p.join(60)
     assert status == "ok", n
     assert n > 0 and same
+
+
+def test_whole_calibration_is_run_to_run_deterministic():
+    """DeiT-tiny/224, 8 images, 74 modules on three search streams: four calibrations of one network (eager capture, graph
+    recording, graph replay twice) end with bit-identical intervals -- no result depends on how the streams interleave."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    net = models.get_net("deit_tiny_patch16_224", seed=9, device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(10)).cuda()
+
+    class Loader:
+        batch_size = 8
+
+        def __iter__(self):
+            yield images, None
+
+    runs = []
+    for _ in range(4):
+        for m in wrapped.values():
+            m.mode = "raw"
+        with contextlib.redirect_stdout(io.StringIO()):
+            HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
+        torch.cuda.synchronize()
+        runs.append(_intervals(wrapped))
+    for other in runs[1:]:
+        for n in runs[0]:
+            for a, b in zip(runs[0][n], other[n]):
+                assert torch.equal(a, b), n
