@@ -593,6 +593,8 @@ class HessianQuantCalibrator(QuantCalibrator):
             def hook(mod, inp, out):
                 numel = sum(t.numel() for t in inp if torch.is_tensor(t)) + 2 * out.numel()
                 sizes[n] = numel * 4
+                if out.dim() >= 2:
+                    mod._p4v_out_mn = (int(out.shape[-2]), int(out.shape[-1]))       # tile geometry for shard.module_cost_ms
             return hook
 
         for n in names:

@@ -34,23 +34,31 @@ def module_cost(module):
 
 def module_cost_ms(module, cache_bytes):
     """Predicted search time (ms, one MI355X, single stream) of one module from its captured size; constants fitted to
-    the per-layer measurements of ViT-B/224 x 32 (tools/bench_layer.py: qkv 2.7, proj 1.3, fc1 3.3, fc2 7.3, q.k 1.9,
-    attn.v 3.8 ms per search round; patch embedding 13 ms).  Only the RATIOS matter (LPT balance)."""
+    the per-module measurements of a ViT-B/224 x 32 calibration (tools/module_times.py, round 2 kernels: qkv 4.2, proj 1.9,
+    fc1 5.3, fc2 8.5, q.k 2.9, attn.v 2.4, patch embedding 7.6, head 0.6 ms for the three rounds with the pass memo).  Only
+    the RATIOS matter (LPT balance)."""
     w = getattr(module, "weight", None)
     cls = type(module).__name__
     if w is None:                                       # matmul: cache = A + B + 2 * out (fp32)
-        per_mac = 7.2e-9 if cls.startswith("SoS") else 2.3e-9
+        per_mac = 4.2e-9 if cls.startswith("SoS") else 3.9e-9
         # cache_bytes / 4 = Z (M K + K N + 2 M N); the sweeps cost ~ Z M N K; approximate with (cache / 4)^(3/2) / sqrt(Z)
         # being overkill, use the dominant square score matrix: out elements ~ cache / 16, K ~ 64
-        return 0.4 + per_mac * (cache_bytes / 16.0) * 64.0
+        t = 0.4 + per_mac * (cache_bytes / 16.0) * 64.0
+        mn = getattr(module, "_p4v_out_mn", None)
+        if mn is not None and not cls.startswith("SoS"):
+            # the q.k^T sweeps are epilogue-bound on 128 x 128 tiles: what they cost follows the PADDED score matrix
+            # (197 tokens: 1.69 x the valid area, the fit above; Swin windows of 144: 3.16 x -- measured 9.3 ms against 4.6)
+            pad = (-(-mn[0] // 128) * 128) * (-(-mn[1] // 128) * 128) / float(max(1, mn[0] * mn[1]))
+            t = 0.4 + (t - 0.4) * pad / 1.689
+        return t
     if w.dim() == 4:                                    # patch embedding: fp32-operand MFMA path
         k = w[0].numel()
         rows = cache_bytes / 4.0 / max(1.0, 2.0 * w.shape[0] + k)
-        return 0.5 + 3.5e-9 * rows * k * w.shape[0]
+        return 0.5 + 1.9e-9 * rows * k * w.shape[0]
     n_out, k = w.shape
     rows = cache_bytes / 4.0 / (k + 2.0 * n_out)        # cache = x + out + grad
-    t = 0.45 + 1.25e-6 * k * n_out * rows / 6304.0
-    return t * (2.2 if cls.startswith("PostGelu") else 1.0)
+    t = 0.78 + 1.93e-6 * k * n_out * rows / 6304.0
+    return t * (1.6 if cls.startswith("PostGelu") else 1.0)
 
 
 def assign_modules(wrapped_modules, world, costs=None):
