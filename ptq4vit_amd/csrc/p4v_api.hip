@@ -420,7 +420,7 @@ bool sweep8_ok(const SweepParams& p, bool twin, int epi) {
            !(g_variant & 65536);
 }
 
-template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool ROWS_FIXED, bool SKIP> int launch_sweep8_epi_s(Ctx& c, const SweepParams& p, int epi, int cgroups) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
     const size_t lds = (size_t)SW8_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2;
     dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
@@ -428,10 +428,10 @@ template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, i
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep8<ROWS_FIXED, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep8<ROWS_FIXED, E, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep8<ROWS_FIXED, E>), grid, block, lds, c.st, p);                              \
+        hipLaunchKernelGGL((k_sweep8<ROWS_FIXED, E, SKIP>), grid, block, lds, c.st, p);                        \
     } while (0)
     switch (epi) {
         case EPI_SQ_W: P4V_LAUNCH8(EPI_SQ_W); break;
@@ -442,6 +442,14 @@ template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, i
 #undef P4V_LAUNCH8
     HIPCHK(hipGetLastError());
     return 0;
+}
+// The padding skip of k_sweep2 (wave parts without a valid element do no MFMA / epilogue work) is available here only as an A/B
+// switch (variant 262144): measured slower at 197 tokens (4 of 32 parts padding: 459 vs 428 us) AND at the 144 tokens of a Swin
+// window (17 of 32 parts: 10.0 vs 9.3 ms per module) -- a single-k-tile candidate is paced by its ring step (DMA landing +
+// barrier), not by the MFMAs and the epilogue it would skip.
+template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+    const bool skip = (g_variant & 262144) != 0;
+    return skip ? launch_sweep8_epi_s<ROWS_FIXED, true>(c, p, epi, cgroups) : launch_sweep8_epi_s<ROWS_FIXED, false>(c, p, epi, cgroups);
 }
 
 // k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)

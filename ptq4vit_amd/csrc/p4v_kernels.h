@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 // Same tile (128 x 128, 8 waves x (64 x 32)), same epilogue, same partial-sum table as k_sweep2.
 static constexpr int SW8_NS = 8;
 
-template <bool ROWS_FIXED, int EPI>
+template <bool ROWS_FIXED, int EPI, bool SKIP>
 __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = reinterpret_cast<float*>(smem + SW8_NS * SW2_TILE);   // [per][8 waves]
@@ -1032,11 +1032,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     const int ncand = c_hi - c_lo;
 
     // the 64 x 32 part of this wave; the padding skip of k_sweep2 (parts of pure padding do no work, parts with work are dealt
-    // to wave ids 0, 1, ... first) is compiled out here:
+    // to wave ids 0, 1, ... first):
     int pos = wid;
-    // (measured at 197 tokens, where only 4 of 32 parts are pure padding: 459 us per pass with the skip, 428 without -- the
-    // remap costs more registers and branches than the idle parts give back; attn.v in k_sweep2, half padding, gains 17 %)
-    constexpr bool SKIP = false;
+    // SKIP: A/B switch only (launch_sweep8_epi) -- slower at 197 and at 144 tokens: the candidate step of this kernel is
+    // paced by the ring (DMA landing + barrier), not by the work the padding parts would skip
     if constexpr (SKIP) {
         auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
         int cnt = 0, found = -1;
