@@ -1012,6 +1012,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 // Same tile (128 x 128, 8 waves x (64 x 32)), same epilogue, same partial-sum table as k_sweep2.
 static constexpr int SW8_NS = 8;
 
+#ifndef P4V_SW8_DBG
+#define P4V_SW8_DBG 0      // timing-only ablations: 1 no operand stream in the loop, 2 no MFMAs, 4 no epilogue arithmetic
+#endif
 template <bool ROWS_FIXED, int EPI, bool SKIP>
 __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1150,7 +1153,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         // began to step faster than the DMA latency / 6.)
         if (it + SW8_NS - 1 < ncand) wait_vmcnt<SW8_NS - 3>(); else wait_vmcnt<0>();   // (tail: no younger pieces are counted on)
         __builtin_amdgcn_s_barrier();
-        if (it + SW8_NS - 1 < ncand) issue((ST + SW8_NS - 1) % SW8_NS);
+        if constexpr (!(P4V_SW8_DBG & 1)) if (it + SW8_NS - 1 < ncand) issue((ST + SW8_NS - 1) % SW8_NS);
         if (!act) {                                    // a part of pure padding: stream and barriers only
             if (lane == 63) res[(c - c_lo) * 8 + pos] = 0.0f;
             ++c;
@@ -1164,7 +1167,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         }
         asm volatile("" : "+v"(curf.t00), "+v"(curf.t01) :: "memory");
         if (!ROWS_FIXED) asm volatile("" : "+v"(curf.t10), "+v"(curf.t11));
-        if (ROWS_FIXED) {      // A (rows) in registers, B (columns) streamed
+        if constexpr ((P4V_SW8_DBG & 2) != 0) { acc[0] = zero16; acc[1] = zero16; acc[0][0] = curf.t00[0] + curf.t01[1]; }
+        else if (ROWS_FIXED) {      // A (rows) in registers, B (columns) streamed
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][0], curf.t00, zero16, 0, 0, 0);
             if (act1) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[1][0], curf.t00, zero16, 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fx[0][1], curf.t01, acc[0], 0, 0, 0);
@@ -1178,6 +1182,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         // ---- fused similarity epilogue of candidate c: one float per wave -----------------------------------------------
         const float s1 = s1tab[(c - c_lo) * 8 + pos];
         v2f sum2 = {0.0f, 0.0f};
+        if constexpr ((P4V_SW8_DBG & 4) != 0) sum2.x = (float)(acc[0][0] + acc[1][5]) * s1;
+        else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i == 1 && !act1) break;                  // a block of pure padding rows
