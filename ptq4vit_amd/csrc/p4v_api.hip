@@ -414,6 +414,44 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     return 0;
 }
 
+// k_sweep9: single-k-tile sweeps on 16 x 16 blocks (part layout [C][Z][halves * 8], set up by run_pass)
+int sweep9_halves(const SweepParams& p, bool twin, int epi) {
+    if (p.ktiles != 1 || twin || (p.a_cs == 0) == (p.b_cs == 0) || epi == EPI_STORE || epi == EPI_FWD || epi == EPI_COS) return 0;
+    if (p.sb_mode == 1 && p.s_cs > 1) return 0;
+    if (p.bias_axis != 0 || (g_variant & 524288)) return 0;
+    const long nb = (long)cdiv(p.M, 16) * cdiv(p.N, 16);
+    const int halves = (int)cdiv(nb, 8L * SW9_NB);
+    if (halves > 4) return 0;
+    // worth it where the 128 x 128 tiles of k_sweep8 are mostly padding: Swin windows (144 tokens: 3.2 x the 16-granular area,
+    // q.k^T search 9.2 -> 6.1 ms per module; 49 tokens: 4 x); at 197 tokens (1.5 x) the two kernels measure the same
+    // (436 us per pass) and k_sweep8 stays.  Variant 1048576 forces it for A/B runs.
+    const double waste = (double)rup(p.M, 128) * rup(p.N, 128) / ((double)rup(p.M, 16) * rup(p.N, 16));
+    return (waste >= 1.8 || (g_variant & 1048576)) ? halves : 0;
+}
+template <bool ROWS_FIXED> int launch_sweep9_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+    const int per = cdiv(p.c1 - p.c0, cgroups);
+    const size_t lds = (size_t)SW9_NS * SW9_STAGE + (size_t)per * 8 * sizeof(float) * 2;
+    dim3 grid(p.halves, p.Z, cgroups), block(512);
+#define P4V_LAUNCH9B(E)                                                                                        \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep9<ROWS_FIXED, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_sweep9<ROWS_FIXED, E>), grid, block, lds, c.st, p);                              \
+    } while (0)
+    switch (epi) {
+        case EPI_SQ_W: P4V_LAUNCH9B(EPI_SQ_W); break;
+        case EPI_SQ: P4V_LAUNCH9B(EPI_SQ); break;
+        case EPI_ABS: P4V_LAUNCH9B(EPI_ABS); break;
+        default: P4V_LAUNCH9B(EPI_W_SQ); break;
+    }
+#undef P4V_LAUNCH9B
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // k_sweep8: single k-tile (K <= 64) int8 sweep with the fixed operand's fragments in registers: q.k^T of every ViT / Swin
 bool sweep8_ok(const SweepParams& p, bool twin, int epi) {
     return p.ktiles == 1 && !twin && (p.a_cs == 0) != (p.b_cs == 0) && epi != EPI_STORE && epi != EPI_FWD && epi != EPI_COS &&
@@ -517,7 +555,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
-    if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
+    if (fast && p.halves > 0) r = p.a_cs == 0 ? launch_sweep9_epi<true>(c, p, epi, cgroups) : launch_sweep9_epi<false>(c, p, epi, cgroups);
+    else if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
     else if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
     else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
     else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups);
@@ -745,6 +784,7 @@ int run_pass(Ctx& c, Pass& ps) {
     if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));
     if (!ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, 0, 1));
 
+    int nine_halves = 0;
     for (int c0 = 0; c0 < ps.eq_n; c0 += chunk) {
         const int nc = std::min(chunk, ps.eq_n - c0);
         const bool packed = pc && pc->valid;   // (a cached plane is never chunked: one iteration)
@@ -840,6 +880,16 @@ int run_pass(Ctx& c, Pass& ps) {
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
                                         : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
+        if (fast && !ps.store_out && (ps.j_mode == 0 || ps.j_mode == 2)) {
+            const int h9 = sweep9_halves(sp, ps.twin, ps.epi);
+            if (h9 > 0 && (long)h9 * 8 <= p_zs) {       // the table allocated for the 128-tile layout holds this one
+                sp.halves = h9;
+                sp.rows_p_stream = sp.a_cs == 0 ? Np : Mp;
+                sp.p_zs = (long)h9 * 8; sp.p_cs = sp.p_zs * ps.Z;
+                nine_halves = h9;
+                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, 256, 12.0, 0.9);
+            }
+        }
         if (fast && !ps.store_out) {
             if (const int t_ = tune(sweep2g_ok(sp) ? TUNE_CG2G : TUNE_CG2); t_ > 0) cgroups = std::max(1, std::min(nc, t_));
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep2%s tiles %d x %d z %d ktiles %d cand %d twin %d -> cgroups %d\n", sweep2g_ok(sp) ? "g" : "", sp.mtiles, sp.ntiles, ps.Z, sp.ktiles, nc, (int)ps.twin, cgroups);
@@ -847,7 +897,11 @@ int run_pass(Ctx& c, Pass& ps) {
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
     if (ps.store_out) { c.ws.off = mark; return 0; }
-    if (!cosm) {
+    if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
+        const int slots = nine_halves * 8;
+        FinishParams fp{part, (long)slots * ps.Z, (long)slots, slots, 1, ps.Z, slots, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores};
+        CHK(launch_finish(c, fp));
+    } else if (!cosm) {
         const int gdiv = stat_ok ? s3_gw : 32;
         // k_sweep4 activation search (j_mode 0) sums the whole table; its columns are sample groups
         // (k_sweep6 skips streaming tiles that are pure padding: their table entries are never written)

@@ -457,6 +457,8 @@ struct SweepParams {
     int mtiles, ntiles;
     int dbg;                           // tuning experiments only (0 in production): 1 = no operand loads, 2 = no MFMA
     float* store;                      // EPI_STORE output [M][N]
+    int halves;                        // k_sweep9: workgroups per batch entry (part layout [C][Z][halves * 8]); 0 otherwise
+    int rows_p_stream;                 // k_sweep9: padded rows of the streamed operand plane
 };
 
 static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
@@ -1222,6 +1224,156 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep9: single-k-tile sweeps (q.k^T, K <= 64) on 16 x 16 blocks
+// ------------------------------------------------------------------------------------------
+// k_sweep8 is bound by its epilogue (profiles/r2_sweep8_ablation.txt: 60 % of the launch), and its 128 x 128 tiles compute 1.69 x
+// the valid outputs at 197 tokens, 3.16 x at the 144 tokens of a Swin window.  Here the score matrix of one batch entry is cut into
+// 16 x 16 blocks (mfma_i32_16x16x64_i8: one instruction per block and candidate; 197 -> 13 x 13 blocks = 1.11 x, 144 -> 9 x 9 = 1.0 x),
+// the blocks are dealt in row-major order to the 8 waves of `halves` workgroups (<= 12 blocks per wave), and every wave keeps per
+// block: the fixed operand's fragment, raw_out / metric weight (4 + 4 values per lane) and its accumulator.  The expanded operand
+// streams as in k_sweep8 (8-deep ring, one stage = the whole operand of one candidate: 256 rows x 64 B, two 1 KB pieces per wave).
+static constexpr int SW9_NS = 8, SW9_STAGE = 256 * 64, SW9_NB = 12;
+
+template <bool ROWS_FIXED, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = reinterpret_cast<float*>(smem + SW9_NS * SW9_STAGE);   // [per][8 waves]
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = blockIdx.x, z = blockIdx.y;
+    const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo;
+
+    // ---- this wave's blocks: a contiguous run of the row-major block list ---------------------------------------------------
+    const int CBk = (p.N + 15) / 16, nb = ((p.M + 15) / 16) * CBk;
+    const int nbh = (nb + p.halves - 1) / p.halves;
+    const int hb0 = half * nbh, hb1 = min(nb, hb0 + nbh);
+    const int nbw = (max(0, hb1 - hb0) + 7) / 8;
+    const int b0 = hb0 + wid * nbw;
+    const int nblk = __builtin_amdgcn_readfirstlane(max(0, min(hb1, b0 + nbw) - b0));
+
+    const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
+    float u[SW9_NB][4], w[SW9_NB][4];
+    v4i_ fxb[SW9_NB];
+    unsigned saddr[SW9_NB];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const int wm = p.wt_mode;
+#pragma unroll
+    for (int j = 0; j < SW9_NB; ++j) {
+        const int bj = min(b0 + j, nb - 1);
+        const int rb = bj / CBk, cb = bj - rb * CBk;
+        const int n = cb * 16 + l15;
+        const int nc = min(n, p.N - 1);
+        const long ncol_off = (long)z * p.o_zs + (long)(nc / p.o_ninner) * p.o_nbs + (long)(nc % p.o_ninner) * p.o_ns;
+        const float bias_n = (biasz && n < p.N) ? biasz[n] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = rb * 16 + 4 * l4 + e;
+            const int mc = min(m, p.M - 1);
+            const long idx = ncol_off + (long)(mc / p.o_inner) * p.o_bs + (long)(mc % p.o_inner) * p.o_ms;
+            const float o = p.O[idx], gw = p.Wt[idx];
+            const bool ok = j < nblk && n < p.N && m < p.M;
+            float wv;
+            if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+            u[j][e] = ok ? o - bias_n : 0.0f;
+            w[j][e] = ok ? wv : 0.0f;
+        }
+        // fragments: 16 rows x 64 B, lane (l4, l15) holds bytes [16 l4, 16 l4 + 16) of row l15 -- 1 KB contiguous per wave
+        const int fr = (ROWS_FIXED ? rb : cb) * 16 + l15, sr = (ROWS_FIXED ? cb : rb) * 16 + l15;
+        const char* gF = ROWS_FIXED ? (const char*)p.A + (long)z * p.a_zs : (const char*)p.B + (long)z * p.b_zs;
+        fxb[j] = *reinterpret_cast<const v4i_*>(gF + (long)fr * SW_BKB + l4 * 16);
+        saddr[j] = lds0 + sr * SW_BKB + l4 * 16;
+    }
+    const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 2 ? z % p.sb_div : 0);
+    float* s1tab = res + per * 8;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+
+    // ---- the expanded operand streams: one candidate per stage, wave `wid` moves rows [32 wid, 32 wid + 32) ---------------------
+    const long t_cs = ROWS_FIXED ? p.b_cs : p.a_cs;
+    const char* cur = ROWS_FIXED ? (const char*)p.B + (long)z * p.b_zs + (long)c_lo * p.b_cs
+                                 : (const char*)p.A + (long)z * p.a_zs + (long)c_lo * p.a_cs;
+    // (rows beyond the padded plane are clamped: they are never read as fragments)
+    const int r0 = min(wid * 32 + (lane >> 2), p.rows_p_stream - 1), r1 = min(wid * 32 + 16 + (lane >> 2), p.rows_p_stream - 1);
+    const unsigned voff0 = (unsigned)(r0 * SW_BKB + (lane & 3) * 16), voff1 = (unsigned)(r1 * SW_BKB + (lane & 3) * 16);
+    const int lds_wave = wid * 2048;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        glds16(cur + voff0, smem + stage * SW9_STAGE + lds_wave);
+        glds16(cur + voff1, smem + stage * SW9_STAGE + lds_wave + 1024);
+        cur += t_cs;
+    };
+    const int npre = min(SW9_NS - 1, ncand);
+    for (int i = 0; i < npre; ++i) issue(i);
+
+#define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    const v4i_ zero4 = {0, 0, 0, 0};
+    int c = c_lo;
+    // step `it` (compile-time stage): prove candidate `it` landed (own two pieces, then the barrier: candidates it+1 .. it+6 --
+    // twelve pieces -- may stay in flight), refill the stage of candidate it-1 with it+7, read the fragments, one MFMA per block,
+    // epilogue.
+    auto step = [&](int it, auto stage_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        if (it + SW9_NS - 1 <= ncand) wait_vmcnt<12>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (it + SW9_NS - 1 < ncand) issue((ST + SW9_NS - 1) % SW9_NS);
+        v4i_ sf[SW9_NB];
+        // (stages 4 .. 7 lie beyond the 16-bit offset field of ds_read: second base)
+        constexpr unsigned HI = (ST >> 2) * 65536u;
+        constexpr int SO = (ST & 3) * SW9_STAGE;
+#pragma unroll
+        for (int j = 0; j < SW9_NB; ++j) {
+            const unsigned a_ = saddr[j] + HI;
+            v4i_ t_;
+            P4V_DSR(t_, a_, SO);
+            sf[j] = t_;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
+#pragma unroll
+        for (int j = 0; j < SW9_NB; ++j) { v4i_ t_ = sf[j]; asm volatile("" : "+v"(t_)); sf[j] = t_; }
+        const float s1 = s1tab[(c - c_lo) * 8 + wid];
+        v2f sum2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < SW9_NB; ++j) {
+            if (j >= nblk) break;
+            const v4i_ acc = ROWS_FIXED ? __builtin_amdgcn_mfma_i32_16x16x64_i8(fxb[j], sf[j], zero4, 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_i32_16x16x64_i8(sf[j], fxb[j], zero4, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const v2f a = {(float)acc[e], (float)acc[e + 1]};
+                const v2f uu = {u[j][e], u[j][e + 1]};
+                const v2f ww = {w[j][e], w[j][e + 1]};
+                const v2f d = uu - a * s1;
+                if (EPI == EPI_SQ_W) { const v2f t2 = ww * d; sum2 = t2 * t2 + sum2; }
+                else if (EPI == EPI_SQ) sum2 = (ww * d) * d + sum2;
+                else if (EPI == EPI_ABS) sum2 += ww * v2f{fabsf(d.x), fabsf(d.y)};
+                else sum2 = (ww * d) * d + sum2;
+            }
+        }
+        const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
+        if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
+        ++c;
+    };
+    for (int it = 0; it < ncand; it += SW9_NS) {
+        step(it, std::integral_constant<int, 0>{});
+        if (it + 1 < ncand) step(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < ncand) step(it + 2, std::integral_constant<int, 2>{});
+        if (it + 3 < ncand) step(it + 3, std::integral_constant<int, 3>{});
+        if (it + 4 < ncand) step(it + 4, std::integral_constant<int, 4>{});
+        if (it + 5 < ncand) step(it + 5, std::integral_constant<int, 5>{});
+        if (it + 6 < ncand) step(it + 6, std::integral_constant<int, 6>{});
+        if (it + 7 < ncand) step(it + 7, std::integral_constant<int, 7>{});
+    }
+#undef P4V_DSR
+    __syncthreads();
+    for (int i = tid; i < ncand * 8; i += 512)
+        p.part[(long)(c_lo + i / 8) * p.p_cs + (long)z * p.p_zs + half * 8 + (i % 8)] = res[i];
 }
 
 // ------------------------------------------------------------------------------------------

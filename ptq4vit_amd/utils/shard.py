@@ -48,7 +48,11 @@ def module_cost_ms(module, cache_bytes):
         if mn is not None and not cls.startswith("SoS"):
             # the q.k^T sweeps are epilogue-bound on 128 x 128 tiles: what they cost follows the PADDED score matrix
             # (197 tokens: 1.69 x the valid area, the fit above; Swin windows of 144: 3.16 x -- measured 9.3 ms against 4.6)
-            pad = (-(-mn[0] // 128) * 128) * (-(-mn[1] // 128) * 128) / float(max(1, mn[0] * mn[1]))
+            area = float(max(1, mn[0] * mn[1]))
+            pad = (-(-mn[0] // 128) * 128) * (-(-mn[1] // 128) * 128) / area
+            pad16 = (-(-mn[0] // 16) * 16) * (-(-mn[1] // 16) * 16) / area
+            if pad / pad16 >= 1.8:                    # k_sweep9 (16 x 16 blocks): Swin windows, 6.1 ms measured at 144 tokens
+                pad = 2.3 * pad16
             t = 0.4 + (t - 0.4) * pad / 1.689
         return t
     if w.dim() == 4:                                    # patch embedding: fp32-operand MFMA path

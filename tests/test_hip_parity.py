@@ -538,3 +538,28 @@ def test_random_attention_geometries_vs_oracle(eng, cfg):
         np.testing.assert_array_equal(A_iv.cpu().numpy(), np.asarray(res["A_interval"]).reshape(-1))
         if sos:
             assert float(split.cpu()) == float(res["split"])
+
+
+@pytest.mark.parametrize("b,H,S,D", [(16, 4, 144, 32), (4, 12, 197, 64), (24, 3, 49, 32), (2, 2, 250, 64)],
+                         ids=["swin-w12", "vit-b", "swin-w7", "250-tokens"])
+def test_block16_sweep_matches_the_128_tile_sweep(eng, b, H, S, D):
+    """A/B of the single-k-tile sweeps: k_sweep9 (16 x 16 blocks, forced with variant 1048576) against k_sweep8 (128 x 128
+    tiles, variant 524288): same selections and intervals, score tables to summation-order noise, both searches."""
+    A, B, out, grad = _mk_attention(57, b, H, S, D, "qk")
+    hp = dict(A_bit=8, B_bit=8, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1)
+    args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(grad), want_scores=True)
+    try:
+        eng.debug_variant(1048576)
+        new = eng.matmul_calibrate(**args, **hp)
+        again = eng.matmul_calibrate(**args, **hp)
+        eng.debug_variant(524288)
+        old = eng.matmul_calibrate(**args, **hp)
+    finally:
+        eng.debug_variant(0)
+    torch.cuda.synchronize()
+    for x, y in zip(new, again):
+        if x is not None:
+            assert torch.equal(x, y), "k_sweep9 is not run-to-run deterministic"
+    assert_scores_close(new[3].cpu().numpy(), old[3].cpu().numpy(), rtol=2e-6, what="k_sweep9 vs k_sweep8")
+    assert torch.equal(new[4], old[4]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])

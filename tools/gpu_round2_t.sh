@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 2: matmul sweeps (k_sweep8 / k_sweep2 / k_sos_split): parity + layer bench
+# round 2: attention sweeps (k_sweep9 / k_sweep8 / k_sweep2 / k_sos_split): parity + layer bench
 cd /root/repo
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_planes.py tests/test_hip_granular.py -x -q -m gpu > gpurun_out/t_tests.log 2>&1
+timeout 1500 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "attention or matmul or single_ktile or split_search" > gpurun_out/t_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/t_tests.log
-grep -a "passed\|failed\|rc=\|^E " gpurun_out/t_tests.log | tail -8
-python tools/bench_layer.py --layer qk,sv --rounds 3 --reps 3 --kernel-stats 2>&1 | grep 'sweep_i8\|sweep_f32\|per calibration'
+grep -a "passed\|failed\|rc=\|^E " gpurun_out/t_tests.log | tail -6
+for V in 0 524288; do echo "variant $V: $(python tools/bench_layer.py --layer qk --rounds 3 --reps 3 --kernel-stats --variant $V 2>&1 | grep 'sweep_i8\|per calibration' | sed 's/TOP.*//; s/(3 round.*//' | tr '\n' ' ')"; done
