@@ -422,11 +422,11 @@ int sweep9_halves(const SweepParams& p, bool twin, int epi) {
     const long nb = (long)cdiv(p.M, 16) * cdiv(p.N, 16);
     const int halves = (int)cdiv(nb, 8L * SW9_NB);
     if (halves > 4) return 0;
-    // worth it where the 128 x 128 tiles of k_sweep8 are mostly padding: Swin windows (144 tokens: 3.2 x the 16-granular area,
-    // q.k^T search 9.2 -> 6.1 ms per module; 49 tokens: 4 x); at 197 tokens (1.5 x) the two kernels measure the same
-    // (436 us per pass) and k_sweep8 stays.  Variant 1048576 forces it for A/B runs.
+    // worth it where the 128 x 128 tiles of k_sweep8 carry padding: Swin windows (144 tokens: 3.2 x the 16-granular area, q.k^T
+    // search 9.2 -> 6.0 ms per module; 49 tokens: 4 x) and, by 5 %, the 197 tokens of ViT / DeiT (1.5 x: 433 -> 410 us per pass).
+    // Variant 1048576 forces it for A/B runs, 524288 disables it.
     const double waste = (double)rup(p.M, 128) * rup(p.N, 128) / ((double)rup(p.M, 16) * rup(p.N, 16));
-    return (waste >= 1.8 || (g_variant & 1048576)) ? halves : 0;
+    return (waste >= 1.4 || (g_variant & 1048576)) ? halves : 0;
 }
 template <bool ROWS_FIXED> int launch_sweep9_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
     const int per = cdiv(p.c1 - p.c0, cgroups);

@@ -1327,6 +1327,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
         // (stages 4 .. 7 lie beyond the 16-bit offset field of ds_read: second base)
         constexpr unsigned HI = (ST >> 2) * 65536u;
         constexpr int SO = (ST & 3) * SW9_STAGE;
+        float s1;
+        {   // the candidate's scale first: LDS returns in order, so it is covered by the first counted wait below
+            const unsigned sa = lds0 + SW9_NS * SW9_STAGE + (per * 8 + (c - c_lo) * 8 + wid) * 4;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(s1) : "v"(sa));
+        }
 #pragma unroll
         for (int j = 0; j < SW9_NB; ++j) {
             const unsigned a_ = saddr[j] + HI;
@@ -1334,14 +1339,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
             P4V_DSR(t_, a_, SO);
             sf[j] = t_;
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
-#pragma unroll
-        for (int j = 0; j < SW9_NB; ++j) { v4i_ t_ = sf[j]; asm volatile("" : "+v"(t_)); sf[j] = t_; }
-        const float s1 = s1tab[(c - c_lo) * 8 + wid];
         v2f sum2 = {0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < SW9_NB; ++j) {
-            if (j >= nblk) break;
+        auto block = [&](int j) __attribute__((always_inline)) {
             const v4i_ acc = ROWS_FIXED ? __builtin_amdgcn_mfma_i32_16x16x64_i8(fxb[j], sf[j], zero4, 0, 0, 0)
                                         : __builtin_amdgcn_mfma_i32_16x16x64_i8(sf[j], fxb[j], zero4, 0, 0, 0);
 #pragma unroll
@@ -1355,6 +1354,25 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
                 else if (EPI == EPI_ABS) sum2 += ww * v2f{fabsf(d.x), fabsf(d.y)};
                 else sum2 = (ww * d) * d + sum2;
             }
+        };
+        // two halves: the fragments of blocks 6 .. 11 are still in flight while blocks 0 .. 5 run their MFMAs and epilogue
+        constexpr int H1 = SW9_NB / 2;
+        __builtin_amdgcn_s_waitcnt(0xC07F | ((SW9_NB - H1) << 8));          // lgkmcnt(6): the scale and fragments 0 .. 5 have landed
+        asm volatile("" : "+v"(s1));
+#pragma unroll
+        for (int j = 0; j < H1; ++j) { v4i_ t_ = sf[j]; asm volatile("" : "+v"(t_)); sf[j] = t_; }
+#pragma unroll
+        for (int j = 0; j < H1; ++j) {
+            if (j >= nblk) break;
+            block(j);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0)
+#pragma unroll
+        for (int j = H1; j < SW9_NB; ++j) { v4i_ t_ = sf[j]; asm volatile("" : "+v"(t_)); sf[j] = t_; }
+#pragma unroll
+        for (int j = H1; j < SW9_NB; ++j) {
+            if (j >= nblk) break;
+            block(j);
         }
         const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
         if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
