@@ -10,7 +10,7 @@ import sys
 __version__ = "0.1.0"
 
 _SUBMODULES = ("quant_layers", "quant_layers.linear", "quant_layers.matmul", "quant_layers.conv", "utils",
-               "utils.net_wrap", "utils.quant_calib", "utils.models", "utils.shard", "configs", "configs.PTQ4ViT",
+               "utils.net_wrap", "utils.quant_calib", "utils.models", "utils.shard", "utils.integer", "configs", "configs.PTQ4ViT",
                "configs.BasePTQ")
 
 

@@ -419,6 +419,8 @@ int sweep9_halves(const SweepParams& p, bool twin, int epi) {
     if (p.ktiles != 1 || twin || (p.a_cs == 0) == (p.b_cs == 0) || epi == EPI_STORE || epi == EPI_FWD || epi == EPI_COS) return 0;
     if (p.sb_mode == 1 && p.s_cs > 1) return 0;
     if (p.bias_axis != 0 || (g_variant & 524288)) return 0;
+    // one ring stage holds the whole streamed operand of a candidate: 256 rows x 64 B (SW9_STAGE); beyond that k_sweep8
+    if ((p.a_cs == 0 ? p.N : p.M) > 256) return 0;
     const long nb = (long)cdiv(p.M, 16) * cdiv(p.N, 16);
     const int halves = (int)cdiv(nb, 8L * SW9_NB);
     if (halves > 4) return 0;
@@ -1272,6 +1274,9 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     CHK(run_pass(c, fp));
                     ps.twin = false; ps.row2 = Operand{};
                     ps.O = Ufold; ps.bias = nullptr;
+                    // Ufold depends on the CURRENT w_interval: it is rebuilt for every activation pass that runs, so the
+                    // fragment-order image of k_sweep6's epilogue operands (built from ps.O) must be rebuilt with it
+                    ps.ecache = nullptr;
                 }
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;

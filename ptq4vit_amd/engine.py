@@ -477,6 +477,9 @@ def export_quantize(src, *, mode, scale1, scale1_stride, scale1_div, lo1=0, hi1=
     dev = src.device
     src = src.detach()
     if src.dtype != torch.float32:
+        if src_stride is not None and not src.is_contiguous():
+            # the caller's strides describe `src` as it is; `.float()` of a non-dense view has other strides
+            raise TypeError("export_quantize: explicit src_stride needs a float32 source (convert before deriving the strides)")
         src = src.float()
     if dims is None:
         dims, src_stride = _pad4(src.shape, 1), _pad4(src.stride(), 0)

@@ -317,6 +317,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         module runs its RAW forward, so the same graph serves W8A8, W6A6, ... calibrations of one network -- the grid the
         reference's experiment driver walks (example/test_all.py:83-103)."""
         return (str(dev), int(bs), tuple(inp.shape[1:]), str(inp.dtype), tuple(self.wrapped_modules),
+                tuple(getattr(m, "mode", "raw") for m in self.wrapped_modules.values()),     # all "raw", see _capture_passes_graph
                 tuple(p.data_ptr() for p in self.net.parameters()))
 
     def _build_graph(self, dev, bs, inp, raw_pred_softmax):
@@ -407,6 +408,12 @@ class HessianQuantCalibrator(QuantCalibrator):
         n_sub = total // bs
         use_graph = getattr(self, "use_graph", None)
         if use_graph is False:
+            return False
+        # The recorded pass is the RAW forward of every wrapped module (`_graph_key`).  A network that is re-calibrated
+        # while modules are still in "quant_forward" (neither the reference nor `_calibrate` resets the modes) captures
+        # quantised forwards on the eager path; a graph would replay raw ones, or bake in kernels that read interval
+        # tensors which the next step 2 replaces.  Only the all-raw state is served from a graph.
+        if any(getattr(m, "mode", "raw") != "raw" for m in self.wrapped_modules.values()):
             return False
         import time
         trace = os.environ.get("P4V_CAPTURE_TRACE") == "1"

@@ -204,6 +204,36 @@ def test_linear_multitile_vs_oracle(eng, cfg):
         np.testing.assert_array_equal(a_iv.cpu().numpy(), o.a_interval.reshape(-1))
 
 
+@pytest.mark.parametrize("K,N,nV,bit,seed", [(384, 128, 2, 6, 2), (384, 128, 2, 6, 3), (768, 64, 2, 4, 3), (768, 96, 3, 8, 0)])
+def test_postgelu_activation_search_follows_the_weight_interval_between_rounds(eng, K, N, nV, bit, seed):
+    """Post-GELU twin on the register-stationary sweep (K = 384 / 768 B), three rounds, with inputs on which the weight
+    interval MOVES between rounds 1 and 2 (asserted on the oracle's trace): the folded target of the twin activation
+    search (raw_out - bias - s_neg s_w x_neg.W_q) depends on the current w_interval, so nothing derived from it may be kept
+    across rounds (round 2 kept k_sweep6's epilogue image of round 1's target).  Tables of all six passes, and the
+    memoised fused call without tables, against the oracle."""
+    from oracle.ptq4vit_oracle import LinearOracle
+    w, bias, x, out, grad = _mk_linear(seed, 2, 40, K, N, postgelu=True)
+    hp = dict(w_bit=bit, a_bit=bit, metric="hessian", n_V=nV, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3)
+    o = LinearOracle(w, bias, postgelu=True, **hp)
+    o.calibration_step2(x, out, grad)
+    w_sel = [np.argmax(o.trace[2 * r][1].reshape(100, -1), axis=0) for r in range(3)]
+    assert not np.array_equal(w_sel[0], w_sel[1]), "test input: the weight interval must move between the rounds"
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), postgelu=True, n_H=1, n_a=1)
+    w_iv, a_iv, scores, best = eng.linear_calibrate(want_scores=True, **args, **hp)
+    w2, a2 = eng.linear_calibrate(want_scores=False, **args, **hp)[:2]
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    pairs = []
+    for r in range(3):
+        pairs.append((scores[r, 0], best[r, 0], o.trace[2 * r][1]))
+        pairs.append((scores[r, 1][:, :1], best[r, 1][:1], o.trace[2 * r + 1][1]))
+    flips = _cmp_tables(pairs, "postgelu-rounds")
+    assert torch.equal(w_iv, w2) and torch.equal(a_iv, a2), "memoised call differs from the call with score tables"
+    if flips == 0:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), o.w_interval.reshape(-1))
+        np.testing.assert_array_equal(a_iv.cpu().numpy(), o.a_interval.reshape(-1))
+
+
 def test_quantize_i8_bit_exact(eng):
     """Integer planes are bit-exact: clamp(rint(x/s)) with IEEE division and round-half-even."""
     from oracle.ptq4vit_oracle import quant_int
@@ -280,6 +310,9 @@ def _mk_attention(seed, b, H, S, D, kind, gscale=1e-3):
     dict(kind="sv", b=64, H=4, S=144, D=32, bit=8, metric="hessian"),           # ... its split-of-softmax matmul
     dict(kind="qk", b=1, H=6, S=197, D=64, bit=8, metric="cosine"),             # BasePTQ metric, ViT-S heads
     dict(kind="sv", b=1, H=3, S=577, D=64, bit=8, metric="hessian"),            # 384-resolution token count (577 = 4.5 tiles)
+    dict(kind="qk", b=2, H=2, S=257, D=64, bit=8, metric="hessian"),            # 257..304 tokens: 17x17 blocks would fit k_sweep9's block budget but not its 256-row stage
+    dict(kind="qk", b=1, H=3, S=300, D=32, bit=8, metric="hessian"),
+    dict(kind="qk", b=1, H=2, S=577, D=64, bit=8, metric="hessian"),            # ViT-B/384 q.k^T
 ], ids=lambda c: f"{c['kind']}-{c['metric']}-{c['bit']}bit-b{c['b']}H{c['H']}S{c['S']}D{c['D']}")
 def test_matmul_baseline_shapes_vs_oracle(eng, cfg):
     """Same bar as the Linear size tests: every score table of every pass within SCORE_RTOL of the oracle's, selections
@@ -540,8 +573,8 @@ def test_random_attention_geometries_vs_oracle(eng, cfg):
             assert float(split.cpu()) == float(res["split"])
 
 
-@pytest.mark.parametrize("b,H,S,D", [(16, 4, 144, 32), (4, 12, 197, 64), (24, 3, 49, 32), (2, 2, 250, 64)],
-                         ids=["swin-w12", "vit-b", "swin-w7", "250-tokens"])
+@pytest.mark.parametrize("b,H,S,D", [(16, 4, 144, 32), (4, 12, 197, 64), (24, 3, 49, 32), (2, 2, 250, 64), (2, 2, 257, 64), (1, 3, 300, 32)],
+                         ids=["swin-w12", "vit-b", "swin-w7", "250-tokens", "257-tokens-falls-back", "300-tokens-falls-back"])
 def test_block16_sweep_matches_the_128_tile_sweep(eng, b, H, S, D):
     """A/B of the single-k-tile sweeps: k_sweep9 (16 x 16 blocks, forced with variant 1048576) against k_sweep8 (128 x 128
     tiles, variant 524288): same selections and intervals, score tables to summation-order noise, both searches."""

@@ -80,3 +80,24 @@ def test_twin_formats_dtypes_and_wraparound():
     hi = torch.clamp(torch.round(A.clamp(sv.split, 1) * 127), 0, 127)
     lo = torch.clamp(torch.round(A.clamp(0, sv.split) / sv.A_interval), 0, 127)
     assert torch.equal(qa.to(torch.int32), ((128 + hi + lo).to(torch.int32)) % 256)
+
+
+def test_half_precision_non_dense_views_are_read_through_their_own_strides():
+    """A sliced / expanded fp16 operand: the export must read the elements the VIEW addresses (its strides were taken
+    before the dtype conversion; `.float()` of such a view is dense and has other strides)."""
+    g, wrapped = _calibrated_mini()
+    fc1 = wrapped["blocks.0.mlp.fc1"]
+    x = torch.from_numpy(g["blocks__0__mlp__fc1::x"])
+    big = torch.zeros(x.shape[0], x.shape[1], 2 * x.shape[2], dtype=torch.float16)
+    big[..., ::2] = x.half()
+    view = big[..., ::2]                                   # stride 2 in the last dimension, fp16
+    assert not view.is_contiguous()
+    integer.quantize_int_activation(fc1, (view,))
+    got = fc1.int_input[0]
+    integer.quantize_int_activation(fc1, (x.half().float(),))
+    assert torch.equal(got, fc1.int_input[0])
+    row = x[:1, :1].half().expand(x.shape[0], x.shape[1], x.shape[2])      # stride-0 (expanded) fp16 view
+    integer.quantize_int_activation(fc1, (row,))
+    got = fc1.int_input[0]
+    integer.quantize_int_activation(fc1, (row.float().contiguous(),))
+    assert torch.equal(got, fc1.int_input[0])
