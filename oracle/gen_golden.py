@@ -319,6 +319,88 @@ def gen_mini_vit(name="minivit_ptq4vit"):
     print(f"wrote {name}.npz ({len(wrapped)} modules)")
 
 
+def _reference_harness(cfg_name):
+    """Import the reference's wrap / calibrator / config modules with timm stubbed."""
+    import types, importlib
+    _install_shims()
+    os.chdir(REF)
+    for sub in ("timm", "timm.models", "timm.models.vision_transformer", "timm.models.swin_transformer"):
+        sys.modules.setdefault(sub, types.ModuleType(sub))
+    sys.modules["timm.models.vision_transformer"].Attention = type("Attention", (torch.nn.Module,), {})
+    sys.modules["timm.models.swin_transformer"].WindowAttention = type("WindowAttention", (torch.nn.Module,), {})
+    ref_models = importlib.import_module("utils.models")
+    ref_wrap = importlib.import_module("utils.net_wrap")
+    ref_calib = importlib.import_module("utils.quant_calib")
+    cfg = importlib.import_module("configs." + cfg_name)
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    if repo not in sys.path:
+        sys.path.append(repo)
+    from ptq4vit_amd.utils import models as my_models
+    return ref_models, ref_wrap, ref_calib, cfg, my_models
+
+
+def _reference_net(my_models, ref_models, name, **kw):
+    net = my_models.get_net(name, seed=0, device="cpu", **kw)
+    for m in list(net.modules()):           # let the reference's isinstance(m, MatMul) recognise the matmul modules
+        for cname, child in list(m.named_children()):
+            if isinstance(child, my_models.MatMul):
+                setattr(m, cname, ref_models.MatMul())
+    return net
+
+
+class _Loader:
+    def __init__(self, images):
+        self.images, self.batch_size = images, images.shape[0]
+
+    def __iter__(self):
+        yield self.images, torch.zeros(self.images.shape[0], dtype=torch.long)
+
+
+def _interval_payload(wrapped):
+    payload = {"names": np.array(list(wrapped))}
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
+            v = getattr(m, a, None)
+            if v is None:
+                continue
+            if isinstance(v, (list, tuple)):      # non-batching post-GELU class: [positive (n_a, 1), negative scalar]
+                payload[f"{key}::{a}"] = np.asarray(v[0])
+                payload[f"{key}::a_neg_interval"] = np.asarray(v[1], dtype=np.float64)
+            else:
+                payload[f"{key}::{a}"] = np.asarray(v)
+    return payload
+
+
+def gen_deit_tiny(name="deit_tiny_224_baseptq_4img"):
+    """BASELINE.json config 0 run by the REFERENCE itself: DeiT-tiny/224 (the build's restatement of the architecture,
+    seeded random weights -- timm / checkpoints are not available offline), configs/BasePTQ.py as shipped (cosine metric,
+    one round; cosine does not read raw_grad), 4 seeded calibration images, reference utils/net_wrap.py:39-81 +
+    HessianQuantCalibrator.batching_quant_calib (utils/quant_calib.py:300-378) on the CPU.  Stored: every module's
+    calibrated intervals, the raw and the quantised logits of the calibration images.  Weights and images are
+    reproducible from the seeds (checksums stored), so the fixture is KBs."""
+    ref_models, ref_wrap, ref_calib, cfg, my_models = _reference_harness("BasePTQ")
+    net = _reference_net(my_models, ref_models, "deit_tiny_patch16_224")
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(4, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        raw_logits = net(images)
+    wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+    cal = ref_calib.HessianQuantCalibrator(net, wrapped, _Loader(images), sequential=False, batch_size=4)
+    cal.batching_quant_calib()
+    with torch.no_grad():
+        logits = net(images)
+    payload = _interval_payload(wrapped)
+    payload.update(raw_logits=raw_logits.numpy(), quant_logits=logits.numpy(),
+                   images_sum=np.array(images.double().sum().item()), images_abs_sum=np.array(images.double().abs().sum().item()),
+                   weights_abs_sum=np.array(sum(p.double().abs().sum().item() for p in net.parameters())),
+                   config=np.array(json.dumps(dict(model="deit_tiny_patch16_224", cfg="BasePTQ", images=4, image_seed=0, net_seed=0,
+                                                   batch_size=4, sequential=False))))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **payload)
+    print(f"wrote {name}.npz ({len(wrapped)} modules)")
+
+
 def gen_integer(name="minivit_integer"):
     """Reference utils/integer.py (quantize_int_weight, quantize_int_activation, get_model_int_weight) applied to
     the calibrated mini ViT of minivit_ptq4vit.npz: the reference modules get the stored intervals, the stored
@@ -408,6 +490,8 @@ def gen_swin_attention(name="swin_window_attention"):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         gen_swin_attention()
+    elif len(sys.argv) > 1 and sys.argv[1] == "deit":
+        gen_deit_tiny()
     elif len(sys.argv) > 1 and sys.argv[1] == "integer":
         gen_integer()
     else:
@@ -416,3 +500,4 @@ if __name__ == "__main__":
             gen_mini_vit()
             gen_integer()
             gen_swin_attention()
+            gen_deit_tiny()

@@ -85,3 +85,13 @@ def assert_on_candidate_grid(got, ref, mult, what=""):
         rel = np.abs(ratios - g / r).min() / (g / r)
         assert rel <= 4e-7, f"{what}: block {j}: interval {g!r} vs reference {r!r} is not on the candidate grid (off by {rel:.2e})"
     return differ
+
+
+def grid_steps_between(got, want, mult, tol=4e-7):
+    """Smallest |a - b| over candidate pairs with mult[a] / mult[b] == got / want (to fp32 rounding): how many steps of the
+    candidate table separate two intervals that were both taken from it.  None if no pair matches."""
+    m = np.asarray(mult, dtype=np.float64)[:-1]
+    r = float(got) / float(want)
+    ratios = m[:, None] / m[None, :]
+    hit = np.argwhere(np.abs(ratios - r) <= tol * r)
+    return None if hit.size == 0 else int(np.abs(hit[:, 0] - hit[:, 1]).min())

@@ -1,8 +1,8 @@
 """GPU: every configuration of BASELINE.json at FULL size on one MI355X (configs 1-4; config 0 is
-test_hip_model.py::test_deit_tiny_224_baseptq_4_images_runs):
+test_hip_model.py::test_deit_tiny_224_baseptq_4_images_vs_the_reference_itself, pinned to the reference's own run):
 
   1  ViT-S/224  PTQ4ViT W8A8, 32 calibration images
-  2  ViT-B/224  PTQ4ViT W6A6, 32 images (W8A8 is the bench.py headline and most of the other GPU tests)
+  2  ViT-B/224  PTQ4ViT W8A8 (the bench.py headline, as a whole network) and W6A6, 32 images
   3  Swin-B/384 PTQ4ViT W8A8, 128 images (149 modules, window attention, cache > HBM budget -> grouped capture)
   4  ViT-B/384  PTQ4ViT W6A6, 128 images
 
@@ -172,6 +172,11 @@ def _run_config(model, bits, calib, oracle_matmul=None, logits_rel=0.35):
 
 def test_config1_vit_small_224_w8a8_32_images():
     _run_config("vit_small_patch16_224", 8, 32, oracle_matmul="blocks.11.attn.matmul1")
+
+
+def test_config2_vit_base_224_w8a8_32_images():
+    """The headline configuration of bench.py / BASELINE.json's metric as a whole network (74 modules, 32 images)."""
+    _run_config("vit_base_patch16_224", 8, 32, oracle_matmul="blocks.0.attn.matmul2")
 
 
 def test_config2_vit_base_224_w6a6_32_images():

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_on_candidate_grid, assert_scores_close, candidate_grid
+from tests.helpers import assert_on_candidate_grid, assert_scores_close, candidate_grid, grid_steps_between
 
 pytestmark = pytest.mark.gpu
 
@@ -139,18 +139,33 @@ def test_baseptq_cosine_calibration_end_to_end_vs_oracle():
     _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.9, flat=("head",))   # head: 4 samples x 10 logits, cosine
 
 
-def test_deit_tiny_224_baseptq_4_images_runs():
-    """BASELINE.json config 0 at full size (DeiT-tiny/224, BasePTQ W8A8, 4 calibration images): 50 modules calibrate,
-    the quantised net produces finite logits, and a second calibration reproduces the intervals bit for bit."""
+def test_deit_tiny_224_baseptq_4_images_vs_the_reference_itself():
+    """BASELINE.json config 0 at full size against the REFERENCE's own run of it (tests/golden/deit_tiny_224_baseptq_4img.npz,
+    oracle/gen_golden.py::gen_deit_tiny: reference net_wrap + HessianQuantCalibrator.batching_quant_calib on the CPU, configs/
+    BasePTQ.py as shipped -- cosine, so nothing depends on the rounding-noise raw_grad; reference utils/quant_calib.py:300-378,
+    configs/BasePTQ.py:13-62).  Same seeded weights and images (checksums), then for all 74 modules: every calibrated interval
+    bit-identical to the reference's or -- the capture here is the GPU's fp32 GEMMs, the reference's was the CPU's -- another
+    entry of the same candidate table at most MAX_STEPS grid steps away (count printed); raw logits and quantised logits of
+    the calibration images within the stated tolerances; a second calibration reproduces the first bit for bit."""
     import contextlib, io
     from ptq4vit_amd.configs import BasePTQ
     from ptq4vit_amd.utils import models, net_wrap
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    RAW_TOL, QUANT_TOL, MAX_STEPS, MAX_MOVED = 2e-5, 5e-3, 3, 0.10     # logits: fractions of the raw logit range
+    g = np.load("tests/golden/deit_tiny_224_baseptq_4img.npz", allow_pickle=False)
     net = models.get_net("deit_tiny_patch16_224", seed=0, device="cuda")
+    images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    assert abs(images.double().sum().item() - float(g["images_sum"])) <= 1e-9 * float(g["images_abs_sum"])
+    w_sum = sum(p.double().abs().sum().item() for p in net.parameters())
+    assert abs(w_sum - float(g["weights_abs_sum"])) <= 1e-9 * float(g["weights_abs_sum"]), "not the weights the reference calibrated"
+    images = images.cuda()
+    rng = float(g["raw_logits"].max() - g["raw_logits"].min())
+    with torch.no_grad():
+        raw = net(images).cpu().numpy()
+    raw_err = np.abs(raw - g["raw_logits"]).max() / rng
     with contextlib.redirect_stdout(io.StringIO()):
         wrapped = net_wrap.wrap_modules_in_net(net, BasePTQ)
-    assert len(wrapped) == 74
-    images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    assert list(wrapped) == [str(n) for n in g["names"]]           # 74 modules, the reference's wrapping order
 
     class Loader:
         batch_size = 4
@@ -169,8 +184,38 @@ def test_deit_tiny_224_baseptq_4_images_runs():
     for n in runs[0]:
         for a, b in zip(runs[0][n], runs[1][n]):
             assert torch.equal(a, b), n
+    total = moved = 0
+    far, dist = [], []
+    for n, m in wrapped.items():
+        key = n.replace(".", "__")
+        for a in ("w_interval", "a_interval", "A_interval", "B_interval"):
+            if f"{key}::{a}" not in g.files:
+                continue
+            want = g[f"{key}::{a}"]
+            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
+            if a == "a_interval" and n == "patch_embed.proj":       # a_bit = 32: never searched, min-max of the input
+                np.testing.assert_array_equal(got, want.reshape(-1))
+                continue
+            k, mv = _interval_parity(m, n, a, got, want)
+            total += k
+            moved += mv
+            for x, y in zip(got, want.reshape(-1)):
+                if x != y:
+                    steps = grid_steps_between(x, y, candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n))
+                    dist.append(steps)
+                    if steps is None or steps > MAX_STEPS:
+                        far.append((n, a, float(x), float(y), steps))
     with torch.no_grad():
-        assert torch.isfinite(net(images)).all()
+        q = net(images).cpu().numpy()
+    q_err = np.abs(q - g["quant_logits"]).max() / rng
+    print(f"[parity] DeiT-tiny/224 BasePTQ x4 vs the reference's own run: {total - moved}/{total} intervals bit-identical, {moved} on "
+          f"another entry of the candidate table (grid steps away: {sorted(dist)}); raw logits {raw_err:.2e}, quantised logits {q_err:.2e} of the logit range "
+          f"(quantisation error itself: {np.abs(g['quant_logits'] - g['raw_logits']).max() / rng:.2e})")
+    assert raw_err <= RAW_TOL, raw_err
+    assert not far, far
+    assert moved <= MAX_MOVED * total, (moved, total)
+    assert q_err <= QUANT_TOL, q_err
+    assert (q.argmax(1) == g["quant_logits"].argmax(1)).all()
 
 
 def test_swin_calibration_end_to_end_vs_oracle():

@@ -1,0 +1,29 @@
+#!/bin/bash
+# One parametrised GPU-box job (replaces the per-call scripts of rounds 1-2).  Usage, from the repo root on the box:
+#   tools/gpu_job.sh <tag> <step> [<step> ...]        results under gpurun_out/<tag>/
+# steps: tests | tests:<pytest -k expr> | bench[:steps] | kstats1 | kstats3 | pmc:<layer> | layer:<bench_layer args> |
+#        forward | modules:<net> | sh:<command>
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp
+TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  echo "=== $step"
+  case $name in
+    tests)   if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -15 | tee $O/tests_k.log
+             else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/tests.log; fi ;;
+    bench)   timeout 900 python bench.py --steps ${arg:-10} --warmup 3 > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+             tail -1 $O/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], d.get('breakdown'), d.get('first_calibration_s')); print({k:(round(v['ms'],1), round(v['frac'],3)) for k,v in r.get('by_kernel',{}).items() if v}, r.get('all_int8_sweeps',{}).get('frac'), d['cpu_baseline'].get('value'))" ;;
+    kstats1|kstats3)
+             n=${name#kstats}
+             ( cd /tmp && P4V_SEARCH_STREAMS=$n timeout 600 rocprofv3 --kernel-trace -d $O/prof$n -o b -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
+             python tools/kstats_db.py "$O/prof$n/*.db" > $O/bench_${n}stream_kernel_stats.txt
+             [ $n = 3 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
+             head -24 $O/bench_${n}stream_kernel_stats.txt | cut -c1-180; rm -rf $O/prof$n ;;
+    pmc)     bash tools/pmc_collect.sh $arg $O/pmc_$arg.json > $O/pmc_$arg.log 2>&1; tail -6 $O/pmc_$arg.log | cut -c1-400 ;;
+    layer)   timeout 600 python tools/bench_layer.py $arg 2>&1 | tail -12 | tee -a $O/layer.log ;;
+    forward) timeout 600 python tools/bench_forward.py 2>&1 | tail -8 | tee $O/forward.log ;;
+    modules) timeout 900 python tools/module_times.py $arg 2>&1 | tail -30 | tee $O/modules_$arg.log ;;
+    sh)      bash -c "$arg" 2>&1 | tail -40 | tee -a $O/sh.log ;;
+    *)       echo "unknown step $step" ;;
+  esac
+done
