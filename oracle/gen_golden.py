@@ -401,6 +401,150 @@ def gen_deit_tiny(name="deit_tiny_224_baseptq_4img"):
     print(f"wrote {name}.npz ({len(wrapped)} modules)")
 
 
+# --------------------------------------------------------------------------- #
+# the non-batching classes and the other calibrator entry points
+# --------------------------------------------------------------------------- #
+def gen_ptqsl_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bias=True, **kw):
+    """PTQSLQuantLinear / PostGeluPTQSLQuantLinear.calibration_step2(x) (linear.py:94-347): raw_out / raw_grad cached,
+    the input handed over as the argument; scores are means over (batch, tokens) instead of the batching classes' sums."""
+    from quant_layers.linear import PTQSLQuantLinear, PostGeluPTQSLQuantLinear
+
+    g = torch.Generator().manual_seed(seed)
+    ic = shape_x[-1]
+    w = torch.randn(oc, ic, generator=g) * 0.05 * torch.linspace(0.5, 2.0, oc).view(-1, 1)
+    b = torch.randn(oc, generator=g) * 0.1 if bias else None
+    x = torch.randn(*shape_x, generator=g)
+    if postgelu:
+        x = F.gelu(1.5 * x)
+    out = F.linear(x, w, b)
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    m = (PostGeluPTQSLQuantLinear if postgelu else PTQSLQuantLinear)(ic, oc, bias=bias, **kw)
+    m.weight.data = w.clone()
+    if bias:
+        m.bias.data = b.clone()
+    m.raw_input, m.raw_out = x.clone(), out.clone()
+    m.raw_grad = grad.clone() if kw.get("metric") == "hessian" else None
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        qf = m.calibration_step2(x.clone())
+    a_iv = m.a_interval[0] if postgelu else m.a_interval
+    arrays = dict(weight=w.numpy(), x=x.numpy(), out=out.numpy(), grad=grad.numpy(), w_interval=m.w_interval.numpy(),
+                  a_interval=np.asarray(a_iv), quant_forward=qf.numpy())
+    if bias:
+        arrays["bias"] = b.numpy()
+    _save(name, dict(kind="ptqsl_linear", postgelu=postgelu, oc=oc, **kw), arrays, rec.tables)
+
+
+def gen_ptqsl_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, **kw):
+    """PTQSLQuantMatMul / SoSPTQSLQuantMatMul.calibration_step2(A, B) (matmul.py:62-388): n_G as configured (NOT forced to
+    the head count as in the batching classes), group scores = mean over the heads of a group."""
+    from quant_layers.matmul import PTQSLQuantMatMul, SoSPTQSLQuantMatMul
+
+    g = torch.Generator().manual_seed(seed)
+    if sos:
+        A = torch.softmax(torch.randn(b, H, d1, d2, generator=g) * 3.0, dim=-1)
+    else:
+        A = torch.randn(b, H, d1, d2, generator=g) * torch.linspace(0.5, 2.0, H).view(1, H, 1, 1)
+    Bm = (torch.randn(b, H, d3, d2, generator=g) * torch.linspace(2.0, 0.5, H).view(1, H, 1, 1)).transpose(-2, -1)
+    out = A @ Bm
+    grad = torch.randn(out.shape, generator=g) * grad_scale
+    m = (SoSPTQSLQuantMatMul if sos else PTQSLQuantMatMul)(**kw)
+    m.raw_input, m.raw_out = [A.clone(), Bm.clone()], out.clone()
+    m.raw_grad = grad.clone() if kw.get("metric") == "hessian" else None
+    with torch.no_grad(), ArgmaxRecorder() as rec:
+        qf = m.calibration_step2(A.clone(), Bm.clone())
+    arrays = dict(A=A.numpy(), B=Bm.contiguous().numpy(), out=out.numpy(), grad=grad.numpy(),
+                  A_interval=np.asarray(m.A_interval), B_interval=m.B_interval.numpy(), quant_forward=qf.numpy())
+    if sos:
+        arrays["split"] = np.asarray(m.split)
+    _save(name, dict(kind="ptqsl_matmul", sos=sos, **kw), arrays, rec.tables)
+
+
+def gen_quantile_conv(name="quantileconv_w8a8", *, b=3, ic=3, hw=24, oc=8, k=4, stride=4, seed=60, **kw):
+    """QuantileQuantConv2d.calibration_step2(x) (conv.py:91-124): intervals from the 0.9999 quantiles."""
+    from quant_layers.conv import QuantileQuantConv2d
+
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(oc, ic, k, k, generator=g) * 0.05
+    bias = torch.randn(oc, generator=g) * 0.1
+    x = torch.randn(b, ic, hw, hw, generator=g)
+    m = QuantileQuantConv2d(ic, oc, k, stride, **kw)
+    m.weight.data = w.clone()
+    m.bias.data = bias.clone()
+    with torch.no_grad():
+        qf = m.calibration_step2(x.clone())
+    _save(name, dict(kind="quantile_conv", stride=stride, **kw),
+          dict(weight=w.numpy(), bias=bias.numpy(), x=x.numpy(), w_interval=np.asarray(m.w_interval),
+               a_interval=np.asarray(m.a_interval), quant_forward=qf.numpy()), [])
+
+
+def gen_f4_layers():
+    hs = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    gen_ptqsl_linear("ptqsllinear_hessian_v3", shape_x=(4, 13, 48), oc=36, n_V=3, w_bit=8, a_bit=8, seed=50, **hs)
+    gen_ptqsl_linear("ptqsllinear_cosine_head2d", shape_x=(8, 40), oc=10, n_V=1, w_bit=8, a_bit=8, seed=51,
+                     metric="cosine", eq_alpha=0.5, eq_beta=1.2, eq_n=100, search_round=1)
+    gen_ptqsl_linear("ptqsllinear_l2_blocks_h2a2_w6", shape_x=(3, 7, 32), oc=16, n_V=2, n_H=2, n_a=2, w_bit=6, a_bit=6, seed=52,
+                     metric="L2_norm", eq_alpha=0.2, eq_beta=1.2, eq_n=40, search_round=2)
+    gen_ptqsl_linear("ptqslpostgelu_hessian_w8a8", shape_x=(4, 13, 64), oc=24, postgelu=True, n_V=1, w_bit=8, a_bit=8,
+                     seed=53, **hs)
+    gen_ptqsl_linear("ptqslpostgelu_l2_w6a6", shape_x=(4, 13, 64), oc=24, postgelu=True, n_V=2, w_bit=6, a_bit=6, seed=54,
+                     metric="L2_norm", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    gen_ptqsl_matmul("ptqslmatmul_qk_hessian_g3", b=4, H=3, d1=13, d2=8, d3=13, A_bit=8, B_bit=8, seed=55,
+                     n_G_A=3, n_G_B=3, **hs)
+    gen_ptqsl_matmul("ptqslmatmul_qk_l2_g1", b=4, H=3, d1=13, d2=8, d3=13, A_bit=8, B_bit=8, seed=56, n_G_A=1, n_G_B=1,
+                     metric="L2_norm", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    gen_ptqsl_matmul("ptqslmatmul_sv_hessian_g2of5_w6", b=3, H=5, d1=11, d2=11, d3=8, A_bit=6, B_bit=6, seed=57,
+                     n_G_A=2, n_G_B=2, **hs)                       # 5 heads in 2 groups: crb_groups 3, one padding head
+    gen_ptqsl_matmul("ptqslsos_hessian_g3", b=4, H=3, d1=13, d2=13, d3=8, sos=True, A_bit=8, B_bit=8, seed=58, n_G_B=3, **hs)
+    gen_ptqsl_matmul("ptqslsos_l2_g1_w6", b=4, H=3, d1=13, d2=13, d3=8, sos=True, A_bit=6, B_bit=6, seed=59, n_G_B=1,
+                     metric="L2_norm", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    gen_quantile_conv()
+
+
+def gen_f4_calibrators():
+    """The reference's other calibrator entry points on the 2-block mini ViT, every module a NON-batching class (what
+    these entry points call: calibration_step1(x) / calibration_step2(x)):
+      QuantCalibrator(sequential=True).quant_calib()   -> sequential_quant_calib   (quant_calib.py:28-55)
+      QuantCalibrator(sequential=False).quant_calib()  -> parallel_quant_calib     (quant_calib.py:57-93)
+      HessianQuantCalibrator(sequential=False, batch_size=4).quant_calib()          (quant_calib.py:216-298)
+    Stored per run: the images, every module's intervals, the quantised logits.  Weights come from the seed."""
+    ref_models, ref_wrap, ref_calib, _, my_models = _reference_harness("PTQ4ViT")
+    from quant_layers.conv import PTQSLQuantConv2d
+    from quant_layers.linear import PTQSLQuantLinear, PostGeluPTQSLQuantLinear
+    from quant_layers.matmul import PTQSLQuantMatMul, SoSPTQSLQuantMatMul
+    kw = dict(img_size=32, patch_size=8, embed_dim=48, depth=2, num_heads=3, num_classes=10)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(8, 3, 32, 32, generator=g)
+    for run, metric in (("sequential", "L2_norm"), ("parallel", "L2_norm"), ("hessian", "hessian")):
+        hp = dict(metric=metric, search_round=2, eq_alpha=0.01, eq_beta=1.2, eq_n=100)
+
+        class cfg:  # noqa: N801  (the factory protocol of configs/PTQ4ViT.py:51-80 over the non-batching classes)
+            @staticmethod
+            def get_module(kind, *a, **k):
+                if kind == "qconv":
+                    return PTQSLQuantConv2d(*a, **k, w_bit=8, a_bit=8, n_V=1, n_H=1, **hp)
+                if kind == "qlinear_MLP_2":
+                    return PostGeluPTQSLQuantLinear(*a, **k, w_bit=8, a_bit=8, **hp)
+                if kind.startswith("qlinear"):
+                    return PTQSLQuantLinear(*a, **k, w_bit=8, a_bit=8, n_V=3 if kind == "qlinear_qkv" else 1, **hp)
+                if kind == "qmatmul_scorev":
+                    return SoSPTQSLQuantMatMul(A_bit=8, B_bit=8, n_G_B=3, **hp)
+                return PTQSLQuantMatMul(A_bit=8, B_bit=8, n_G_A=3, n_G_B=3, **hp)
+
+        net = _reference_net(my_models, ref_models, "vit_tiny_patch16_224", **kw)
+        wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+        if run == "hessian":
+            ref_calib.HessianQuantCalibrator(net, wrapped, _Loader(images), sequential=False, batch_size=4).quant_calib()
+        else:
+            ref_calib.QuantCalibrator(net, wrapped, _Loader(images), sequential=(run == "sequential")).quant_calib()
+        with torch.no_grad():
+            logits = net(images)
+        payload = _interval_payload(wrapped)
+        payload.update(images=images.numpy(), quant_logits=logits.numpy(), model_kwargs=np.array(json.dumps(kw)),
+                       hp=np.array(json.dumps(hp)))
+        np.savez_compressed(os.path.join(OUT, f"minivit_calibrator_{run}.npz"), **payload)
+        print(f"wrote minivit_calibrator_{run}.npz ({len(wrapped)} modules)")
+
+
 def gen_integer(name="minivit_integer"):
     """Reference utils/integer.py (quantize_int_weight, quantize_int_activation, get_model_int_weight) applied to
     the calibrated mini ViT of minivit_ptq4vit.npz: the reference modules get the stored intervals, the stored
@@ -492,6 +636,11 @@ if __name__ == "__main__":
         gen_swin_attention()
     elif len(sys.argv) > 1 and sys.argv[1] == "deit":
         gen_deit_tiny()
+    elif len(sys.argv) > 1 and sys.argv[1] == "f4":
+        _install_shims()
+        os.chdir(REF)
+        gen_f4_layers()
+        gen_f4_calibrators()
     elif len(sys.argv) > 1 and sys.argv[1] == "integer":
         gen_integer()
     else:
@@ -501,3 +650,5 @@ if __name__ == "__main__":
             gen_integer()
             gen_swin_attention()
             gen_deit_tiny()
+            gen_f4_layers()
+            gen_f4_calibrators()

@@ -159,7 +159,10 @@ class LinearOracle:
 
     def __init__(self, weight, bias, *, w_bit=8, a_bit=8, metric="hessian", search_round=1,
                  eq_alpha=0.0, eq_beta=1.0, eq_n=100, n_V=1, n_H=1, n_a=1,
-                 init_layerwise=False, postgelu=False, chunk: int = 16):
+                 init_layerwise=False, postgelu=False, chunk: int = 16, batching: bool = True):
+        # batching=False: the non-batching classes PTQSLQuantLinear / PostGeluPTQSLQuantLinear (linear.py:94-347) -- the same
+        # search with the scores averaged over batch AND tokens in one mean (linear.py:201,227) instead of mean-then-sum
+        self.batching = batching
         self.weight = np.ascontiguousarray(weight, dtype=F32)
         self.bias = None if bias is None else np.ascontiguousarray(bias, dtype=F32)
         self.oc, self.ic = self.weight.shape
@@ -216,6 +219,8 @@ class LinearOracle:
 
         ``sim`` is (b, *mid, [trailing kept dims]); returns the trailing dims.
         """
+        if not self.batching:            # linear.py:201 / 227: one mean over every leading dim
+            return sim.mean(axis=tuple(range(sim.ndim - keep_last)), dtype=F32)
         mid = tuple(range(1, sim.ndim - keep_last))
         if mid:
             sim = sim.mean(axis=mid, dtype=F32)
@@ -308,7 +313,11 @@ class MatMulOracle:
 
     def __init__(self, *, A_bit=8, B_bit=8, metric="hessian", search_round=1, eq_alpha=0.1,
                  eq_beta=2.0, eq_n=100, n_V_A=1, n_H_A=1, n_V_B=1, n_H_B=1,
-                 init_layerwise=False, sos=False, chunk: int = 10):
+                 init_layerwise=False, sos=False, chunk: int = 10, n_G_A=None, n_G_B=None, batching: bool = True):
+        # batching=False: PTQSLQuantMatMul / SoSPTQSLQuantMatMul (matmul.py:62-388) -- the group counts n_G are the
+        # configured ones (the batching classes force n_G = heads, matmul.py:411-417) and the scores are means over the batch
+        self.batching = batching
+        self.cfg_n_G_A, self.cfg_n_G_B = (1 if sos else n_G_A), n_G_B      # matmul.py:298: the SoS class forces n_G_A = 1
         self.A_qmax, self.B_qmax = qmax_of(A_bit), qmax_of(B_bit)
         self.metric, self.search_round = metric, search_round
         self.eq_alpha, self.eq_beta, self.eq_n = eq_alpha, eq_beta, eq_n
@@ -323,6 +332,9 @@ class MatMulOracle:
     # ---- geometry: matmul.py:109-122 with n_G = #heads (:411-417) -----------------
     def _padding(self, A, B):
         self.n_G_A, self.n_G_B = A.shape[1], B.shape[1]
+        if not self.batching:
+            self.n_G_A = self.cfg_n_G_A if self.cfg_n_G_A is not None else 1
+            self.n_G_B = self.cfg_n_G_B if self.cfg_n_G_B is not None else 1
         cdiv = lambda a, n: (a + n - 1) // n
         self.crb = {
             "A": (cdiv(A.shape[1], self.n_G_A), cdiv(A.shape[2], self.n_V_A), cdiv(A.shape[3], self.n_H_A)),
@@ -407,7 +419,10 @@ class MatMulOracle:
                 Xs = self._unblock(fake_quant(Xb, cur, -qm, qm - 1), X.shape)
                 o = (Xs @ other) if which == "A" else (other @ Xs)  # p,b,H,d1,d3
                 sim = similarity_lastdim(raw, o, self.metric, g)  # p,b,H,d1
-                sim = sim.mean(axis=3, dtype=F32).sum(axis=1, dtype=F32)  # p,H
+                if self.batching:
+                    sim = sim.mean(axis=3, dtype=F32).sum(axis=1, dtype=F32)  # p,H
+                else:
+                    sim = sim.mean(axis=(1, 3), dtype=F32)                    # matmul.py:196 / 231
                 scores[p0:p1] = sim
             cg = self.crb[which][0]
             pg = self.pad[which][0]
@@ -422,7 +437,7 @@ class MatMulOracle:
         for i, s in enumerate(split_cands):
             o = self._sos_quant(A, s) @ B
             sim = similarity_lastdim(out, o, self.metric, grad)  # b,H,d1
-            scores[i] = sim.mean(axis=(1, 2), dtype=F32).sum(dtype=F32)
+            scores[i] = sim.mean(axis=(1, 2), dtype=F32).sum(dtype=F32) if self.batching else sim.mean(dtype=F32)  # matmul.py:335
         self.trace.append(("split", scores))
         self.split = F32(split_cands[int(_argmax0(scores))])
         self.A_interval = self.split / F32(self.A_qmax - 1)

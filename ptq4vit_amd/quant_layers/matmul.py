@@ -110,12 +110,15 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
             # intervals loaded from elsewhere (shard.exchange_intervals on a rank that did not search this module, or a
             # checkpoint): the block geometry is a function of the operand shapes only (matmul.py:109-122)
             self._get_padding_parameters(A, B)
-        headwise = (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) == (1, 1, 1, 1) and A.dim() == 4 and \
-            self.n_G_B == A.shape[1] and (self._sos or self.n_G_A == A.shape[1])
-        if (self.int8_forward and A.is_cuda and headwise and 2 <= self.A_bit <= 8 and 2 <= self.B_bit <= 8
+        # whole heads share a scale (row / column sub-blocks do not): group intervals are handed over head by head
+        by_head = (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) == (1, 1, 1, 1) and A.dim() == 4
+        if (self.int8_forward and A.is_cuda and by_head and 2 <= self.A_bit <= 8 and 2 <= self.B_bit <= 8
                 and not (torch.is_grad_enabled() and (A.requires_grad or B.requires_grad))):
             # inside the envelope of p4v_matmul_quant_forward the engine's errors propagate (no silent fallback)
-            return engine.matmul_quant_forward(A=A, B=B, A_interval=self.A_interval, B_interval=self.B_interval,
+            H = A.shape[1]
+            A_iv = self.A_interval if self._sos else self._per_head(self.A_interval, H, self.crb_groups_A)
+            return engine.matmul_quant_forward(A=A, B=B, A_interval=A_iv,
+                                               B_interval=self._per_head(self.B_interval, H, self.crb_groups_B),
                                                split=self.split if self._sos else None, A_bit=self.A_bit,
                                                B_bit=self.B_bit, sos=self._sos)
         return self.quant_input_A(A) @ self.quant_input_B(B)
@@ -142,8 +145,72 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
         else:
             self.A_interval = A_iv.view(1, H, 1, 1, 1, 1, 1)
 
+    @staticmethod
+    def _per_head(interval, H, crb_groups):
+        """(1, n_G, 1, 1, 1, 1, 1) group intervals -> one value per head (head h belongs to group h // crb_groups)."""
+        iv = torch.as_tensor(interval).reshape(-1)
+        if iv.numel() == H:
+            return iv
+        idx = torch.arange(H, device=iv.device) // int(crb_groups)
+        return iv[idx]
+
+    def _search_grouped(self, A, B, raw_out, raw_grad):
+        """Reference matmul.py:165-282 (SoS: :305-388) with the CONFIGURED group counts (the batching classes force
+        n_G = heads): one interval per group of crb_groups consecutive heads, the group's score the mean of its heads'
+        scores (matmul.py:199 / 234; zero padding heads only rescale the last group).  Every pass is one GPU sweep with
+        per-head candidate tables (p4v_matmul_search_A / _B / p4v_sos_search_split); the per-head score table is folded
+        to groups and the first-maximum / NaN-is-maximum selection taken on the device."""
+        if (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) != (1, 1, 1, 1):
+            raise NotImplementedError("ptq4vit_amd: MatMul row/column sub-blocks (n_V, n_H > 1) are not implemented on the GPU")
+        self._get_padding_parameters(A, B)
+        st = engine.MatMulStepper(A=A, B=B, out=raw_out, grad=raw_grad if self.metric == "hessian" else None,
+                                  A_bit=self.A_bit, B_bit=self.B_bit, metric=self.metric, eq_n=self.eq_n, sos=self._sos,
+                                  init_layerwise=self.init_layerwise)
+        H, dev = st.H, st.dev
+        mult = torch.tensor([self.eq_alpha + i * (self.eq_beta - self.eq_alpha) / self.eq_n for i in range(self.eq_n + 1)],
+                            dtype=torch.float32, device=dev)
+        A_h, B_h = st.init_intervals()                      # amax / (qmax - 0.5) per head (or layer-wise)
+        side = {}
+        for s, iv_h, nG, crb in (("A", A_h, self.n_G_A, self.crb_groups_A), ("B", B_h, self.n_G_B, self.crb_groups_B)):
+            if iv_h is None:
+                continue
+            idx = torch.arange(H, device=dev) // int(crb)
+            # the division by (qmax - 0.5) is monotone: the group's min-max interval is the largest of its heads'
+            iv_g = torch.zeros(nG, dtype=torch.float32, device=dev).index_reduce_(0, idx, iv_h, "amax", include_self=False)
+            side[s] = dict(idx=idx, iv=iv_g, cands=mult[:, None] * iv_g[None, :], nG=nG)
+
+        def pick(s, scores):
+            d = side[s]
+            grp = torch.zeros(self.eq_n, d["nG"], dtype=torch.float32, device=dev).index_add_(1, d["idx"], scores[: self.eq_n])
+            best = torch.argmax(grp, dim=0)
+            d["iv"] = torch.gather(d["cands"], 0, best[None, :]).reshape(-1)
+
+        split = None
+        for _ in range(self.search_round):
+            B_cur = side["B"]["iv"][side["B"]["idx"]]
+            if self._sos:
+                split, A_cur, _, _ = st.search_split()
+            else:
+                d = side["A"]
+                _, scores, _ = st.search_A(d["cands"][:, d["idx"]], d["iv"][d["idx"]], B_cur, want_scores=True)
+                pick("A", scores)
+                A_cur = d["iv"][d["idx"]]
+            d = side["B"]
+            _, scores, _ = st.search_B(d["cands"][:, d["idx"]], A_cur, B_cur, split=split, want_scores=True)
+            pick("B", scores)
+        self.B_interval = side["B"]["iv"].view(1, self.n_G_B, 1, 1, 1, 1, 1)
+        if self._sos:
+            self.split = split.reshape(())
+            self.A_interval = A_cur.reshape(())
+        else:
+            self.A_interval = side["A"]["iv"].view(1, self.n_G_A, 1, 1, 1, 1, 1)
+
     def calibration_step2(self, A, B):
-        self._search_on_gpu(A, B, self.raw_out, self.raw_grad)
+        H = A.shape[1]
+        if self.n_G_B == H and (self._sos or self.n_G_A == H):
+            self._search_on_gpu(A, B, self.raw_out, self.raw_grad)       # head-wise: the fused call
+        else:
+            self._search_grouped(A, B, self.raw_out, self.raw_grad)
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
         dev = self.B_interval.device

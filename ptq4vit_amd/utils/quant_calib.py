@@ -150,25 +150,41 @@ class QuantCalibrator:
                 self.net(inp.to(dev))
 
     def sequential_quant_calib(self):
-        """One module at a time; already-calibrated predecessors run quantised (reference :28-55)."""
-        for name, module in tqdm(self.wrapped_modules.items(), desc="Calibration"):
-            for step in ("calibration_step1", "calibration_step2"):
-                module.mode = step
-                self._run_loader()
-            module.mode = "quant_forward"
+        """Reference quant_calib.py:28-55: TWO passes over the calibration set.  Pass 1: every module in "calibration_step1"
+        (raw forward; caches raw_input / raw_out of the RAW network).  Pass 2: every module in "calibration_step2": module k
+        calibrates on the input it receives in this pass -- the output of its predecessors' calibration_step2, i.e. their
+        quantised forward -- against the raw_out cached in pass 1.  Modules that already carry `calibrated` are left alone
+        in pass 1 and run raw in pass 2 (the reference compares `step == 2` inside `range(2)`: a dead branch, kept)."""
+        for step in range(2):
+            print(f"Start calibration step={step + 1}")
+            for module in self.wrapped_modules.values():
+                if hasattr(module, "calibrated"):
+                    if step == 1:
+                        module.mode = "raw"
+                else:
+                    module.mode = f"calibration_step{step + 1}"
+            self._run_loader()
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
         print("sequential calibration finished")
 
     def parallel_quant_calib(self):
-        """All modules collect raw data first, then calibrate one by one (reference :57-93)."""
+        """Reference quant_calib.py:57-93: one raw pass caches every module's raw_input / raw_out, then each module runs
+        calibration_step2 on ITS OWN cached raw input (the module is called directly, not through the network)."""
+        print("Start calibration step=1")
         for module in self.wrapped_modules.values():
-            module.mode = "calibration_step1"
+            module.mode = "raw" if hasattr(module, "calibrated") else "calibration_step1"
         self._run_loader()
+        dev = _dev_of(self.net)
         for name, module in tqdm(self.wrapped_modules.items(), desc="Calibration"):
+            if hasattr(module, "calibrated"):
+                continue
             module.mode = "calibration_step2"
-            self._run_loader()
-            module.mode = "raw"
+            with torch.no_grad():
+                if isinstance(module, MinMaxQuantMatMul):
+                    module.forward(module.raw_input[0].to(dev), module.raw_input[1].to(dev))
+                else:
+                    module.forward(module.raw_input.to(dev))
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
         print("calibration finished")
