@@ -251,8 +251,11 @@ int p4v_quantize_i8(const float* d_x, int64_t rows, int64_t cols, int64_t cols_p
  *                     d_scales is NULL: the fixed 0.16997.../q of linear.py:574)
  *   P4V_PLANE_SOS_HI  clamp(rint(clamp(x, split, 1) * (q-1)), 0, q-1)               matmul.py:596, split = d_scales[0]
  *   P4V_PLANE_SOS_LO  clamp(rint(clamp(x, 0, split) / (split / (q-1))), 0, q-1)     matmul.py:597
+ *   P4V_PLANE_TWIN    clamp(rint(x / s), 0, hi) + clamp(rint(x / const_scale), lo, 0): both ranges of the post-GELU twin
+ *                     (linear.py:605-606) in one plane -- their supports are disjoint -- as the large-K weight search streams
+ *                     them (k_sweep7 splits the bytes by sign again); s = d_scales[0], lo < 0 < hi
  * q = qmax = 2^(bit-1).  Output layout as p4v_quantize_i8. */
-enum p4v_plane_mode { P4V_PLANE_SYM = 1, P4V_PLANE_SOS_HI = 2, P4V_PLANE_SOS_LO = 3 };
+enum p4v_plane_mode { P4V_PLANE_SYM = 1, P4V_PLANE_SOS_HI = 2, P4V_PLANE_SOS_LO = 3, P4V_PLANE_TWIN = 4 };
 typedef struct p4v_plane_desc {
     int64_t rows, cols, cols_padded;
     int64_t rows_per_scale;   /* P4V_PLANE_SYM with d_scales: scale index = row / rows_per_scale */

@@ -63,7 +63,7 @@ class ExportDesc(C.Structure):
                 ("qmax", C.c_int32), ("reserved", C.c_int32)]
 
 
-PLANE_SYM, PLANE_SOS_HI, PLANE_SOS_LO = 1, 2, 3
+PLANE_SYM, PLANE_SOS_HI, PLANE_SOS_LO, PLANE_TWIN = 1, 2, 3, 4
 EXPORT_SYM_I8, EXPORT_SYM_F32, EXPORT_GELU_U8, EXPORT_SOS_U8 = 0, 1, 2, 3
 
 

@@ -493,7 +493,7 @@ template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, i
 }
 
 // k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)
-template <bool TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds) {
+template <int TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds) {
 #define P4V_LAUNCH7(E)                                                                                         \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
@@ -514,7 +514,7 @@ template <bool TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int ep
     return 0;
 }
 
-int launch_sweep7(Ctx& c, const Sweep7Params& p, bool twin, int epi, int cgroups) {
+int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups) {   // twin: 0 plain, 1 two planes, 2 merged plane
     if (c.dry) return 0;
     const int nc = p.c1 - p.c0;
     // the per-candidate tables live behind the ring: at most 160 candidates per workgroup
@@ -535,7 +535,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, bool twin, int epi, int cgroups
         rec.alg = g_alg_macs_cand * nc;
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
-    CHK(twin ? launch_sweep7_epi<true>(c, q, epi, grid, lds) : launch_sweep7_epi<false>(c, q, epi, grid, lds));
+    CHK(twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds) : launch_sweep7_epi<0>(c, q, epi, grid, lds));
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
         g_stat_recs.push_back(rec);
@@ -641,6 +641,7 @@ struct Pass {
     float* scores_out; int scores_out_ld;
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
+    bool twin_disjoint;       // twin whose two ranges never overlap (post-GELU): k_sweep7 may stream them as one merged plane
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
     EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
 };
@@ -686,6 +687,9 @@ int run_pass(Ctx& c, Pass& ps) {
                       ps.row.expanded != ps.col.expanded && !(ps.twin && (ps.row.expanded || ps.row2.expanded)) &&
                       ps.o_bs == 0 && ps.o_nbs == 0 && ps.o_ns == 1 && ps.Ncols % 32 == 0 && ps.o_ms % 4 == 0 &&
                       (c.dry || ((((unsigned long long)ps.O) | ((unsigned long long)(ps.G ? ps.G : ps.O))) & 15) == 0) && ps.bias_axis == 0;
+    // post-GELU twin on k_sweep7: ONE merged int8 plane k_pos + k_neg (disjoint supports), split in registers (variant
+    // 2097152 keeps the two-plane kernel for A/B runs)
+    const bool merged7 = big7 && ps.twin && ps.twin_disjoint && !(g_variant & 2097152);
     // k_sweep6 tiles the stationary operand (the one that is NOT candidate-expanded) in 256-row slabs
     const int Mp = (int)rup(ps.Mrows, big7 ? (ps.twin ? 128 : 256) : (regs6 && !ps.row.expanded) ? 256 : PADR);
     const int Np = (int)rup(ps.Ncols, big7 ? 256 : (regs6 && !ps.col.expanded) ? 256 : PADR);
@@ -782,8 +786,15 @@ int run_pass(Ctx& c, Pass& ps) {
         return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
     };
     // fixed planes once
-    if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
-    if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));
+    if (merged7) {
+        Operand both = ps.row;              // positive range: scale + upper clamp; negative range: fixed scale + lower clamp
+        both.pk.mode = PACK_TWIN_I8;
+        both.pk.lo = ps.row2.pk.lo; both.pk.neg_scale = ps.row2.pk.neg_scale;
+        CHK(pack(both, rowbuf, Mp, ps.row_zs_shared, 0, 1));
+    } else {
+        if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
+        if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));
+    }
     if (!ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, 0, 1));
 
     int nine_halves = 0;
@@ -829,7 +840,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.R = colbuf - (long)c0 * q.r_cs;
             q.c_cs = ps.row.expanded ? row_plane1 : 0;
             q.Cp = rowbuf - (long)c0 * q.c_cs;
-            q.C2 = ps.twin ? row2buf : nullptr;
+            q.C2 = (ps.twin && !merged7) ? row2buf : nullptr;
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.S2 = S2; q.s_cs = ps.s_cs; q.sb_div = ps.s_cs > 1 ? std::max(1, ps.sb_div) : (1 << 30);
             q.E = epi7;
@@ -842,7 +853,7 @@ int run_pass(Ctx& c, Pass& ps) {
             if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
             q.order = tune(TUNE_ORDER7) > 0 ? tune(TUNE_ORDER7) - 1 : 1;
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);
-            CHK(launch_sweep7(c, q, ps.twin, ps.epi, cg7));
+            CHK(launch_sweep7(c, q, merged7 ? 2 : ps.twin ? 1 : 0, ps.epi, cg7));
             continue;
         }
         SweepParams sp{};
@@ -1197,7 +1208,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             if (!cosm) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
                 ps.row = x_operand(false, a_iv, 0);
-                if (twin) ps.row2 = xneg_operand();
+                if (twin) { ps.row2 = xneg_operand(); ps.twin_disjoint = true; }    // linear.py:605-606: clamp(.,0,q-1) / clamp(.,-q,0)
                 ps.col = w_operand(true, wc, wc_cs, false);
                 ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 1; ps.sb_div = crb_rows;
                 ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
@@ -1959,8 +1970,10 @@ int p4v_debug_set_tuning(int key, int value) {
 int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_scales, int8_t* d_q, void* stream) {
     if (!d || !d_x || !d_q || d->rows <= 0 || d->cols <= 0 || d->cols_padded % 64 || d->cols_padded < d->cols)
         return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: bad argument");
-    if (d->mode != P4V_PLANE_SYM && d->mode != P4V_PLANE_SOS_HI && d->mode != P4V_PLANE_SOS_LO)
+    if (d->mode != P4V_PLANE_SYM && d->mode != P4V_PLANE_SOS_HI && d->mode != P4V_PLANE_SOS_LO && d->mode != P4V_PLANE_TWIN)
         return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: unknown mode %d", d->mode);
+    if (d->mode == P4V_PLANE_TWIN && (d->lo > 0 || d->hi < 0 || !(d->const_scale > 0.0f)))
+        return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: the merged twin plane needs lo <= 0 <= hi and const_scale > 0");
     if (d->mode != P4V_PLANE_SYM && !d_scales) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: split-of-softmax planes need d_scales = &split");
     if (d->mode == P4V_PLANE_SYM && d_scales && d->rows_per_scale <= 0) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: rows_per_scale");
     if (d->lo < -128 || d->hi > 127 || d->qmax < 2 || d->qmax > 128) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: grid wider than int8");
@@ -1972,6 +1985,8 @@ int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_
     if (d->mode == P4V_PLANE_SYM) {
         p.mode = PACK_SYM;
         if (d_scales) { p.blk_mode = 1; p.blk_div = (int)d->rows_per_scale; p.nblk_r = cdiv(d->rows, d->rows_per_scale); p.nblk_k = 1; }
+    } else if (d->mode == P4V_PLANE_TWIN) {
+        p.mode = PACK_TWIN_I8;
     } else {
         p.mode = d->mode == P4V_PLANE_SOS_HI ? PACK_SOS_HI : PACK_SOS_LO;
     }

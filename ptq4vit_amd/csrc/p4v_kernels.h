@@ -123,7 +123,10 @@ enum PackMode {
     PACK_SOS_HI = 2,  // clamp(rint(clamp(x,split,1)*(q-1)), 0, q-1)   matmul.py:596
     PACK_SOS_LO = 3,  // clamp(rint(clamp(x,0,split)/(split/(q-1))), 0, q-1)   matmul.py:597
     PACK_SOS_SIM = 4, // fp32 only: hi/(q-1) + lo*(split/(q-1))        matmul.py:613-615
-    PACK_TWIN_SIM = 5 // fp32 only: pos*s + neg*s_neg                  linear.py:605-607
+    PACK_TWIN_SIM = 5, // fp32 only: pos*s + neg*s_neg                  linear.py:605-607
+    PACK_TWIN_I8 = 6   // int8 only: clamp(rint(x/s),0,hi) + clamp(rint(x/neg_scale),lo,0) -- the two grid indices of the post-GELU
+                       // twin (linear.py:605-606) in ONE plane: their supports are disjoint (x > 0 clamps the negative range to 0,
+                       // x < 0 the positive one), so the sum is the one that is not zero and fits the int8 range
 };
 
 struct PackParams {
@@ -158,6 +161,8 @@ __device__ __forceinline__ float pack_value(const PackParams& p, float x, float 
             const float a_int = s / p.qm1;
             return fminf(fmaxf(rintf(fminf(fmaxf(x, 0.0f), s) / a_int), 0.0f), p.qm1);
         }
+        case PACK_TWIN_I8:
+            return fminf(fmaxf(rintf(x / s), 0.0f), (float)p.hi) + fminf(fmaxf(rintf(x / p.neg_scale), (float)p.lo), 0.0f);
         default: return x;
     }
 }
@@ -2497,8 +2502,15 @@ __global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) {
     }
 }
 
-template <bool TWIN, int EPI>
+// TW = 0: one sample-side plane.  TW = 1: twin, two planes streamed side by side (128 samples x 2 planes per tile).
+// TW = 2: twin whose two ranges have DISJOINT supports (post-GELU, linear.py:605-606), streamed as ONE merged int8 plane
+// k_pos + k_neg (PACK_TWIN_I8) and split into its two MFMA fragments in registers -- per byte max(v, 0) / min(v, 0), six
+// VALU operations per dword in the wave's load phase: a quarter less LDS-DMA (three 1 KB pieces per wave and k-tile instead
+// of four) and 10 instead of 12 fragment reads per k-tile; the MFMAs, accumulators and epilogue are those of TW = 1.
+template <int TW, int EPI>
 __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
+    constexpr bool TWIN = TW != 0, MERGED = TW == 2;
+    constexpr int PPT = MERGED ? 3 : 4;                  // LDS-DMA pieces per wave and k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = reinterpret_cast<float*>(smem + SW7_NS * SW7_STAGE);   // [per][8 waves][4 feature blocks]
 
@@ -2551,8 +2563,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     // stream's cost when it always hits in the L2)
     const int r0a = (P4V_SW7_DBG & 8) ? 0 : r0, m0a = (P4V_SW7_DBG & 8) ? 0 : m0, c_loa = (P4V_SW7_DBG & 8) ? p.c0 : c_lo;
     const char* curR = (const char*)p.R + (long)(r0a + wid * 32) * p.ldk + (long)c_loa * p.r_cs;
-    const char* cbase = (TWIN && wid >= 4) ? (const char*)p.C2 : (const char*)p.Cp;
-    const char* curC = cbase + (long)(m0a + (TWIN ? (wid & 3) * 32 : wid * 32)) * p.ldk + (TWIN ? 0L : (long)c_loa * p.c_cs);
+    const char* cbase = (TW == 1 && wid >= 4) ? (const char*)p.C2 : (const char*)p.Cp;
+    // (merged twin: the 128 sample rows of the tile are one plane; wave w fills rows [16 w, 16 w + 16) with ONE piece)
+    const char* curC = cbase + (long)(m0a + (MERGED ? wid * 16 : TWIN ? (wid & 3) * 32 : wid * 32)) * p.ldk + (TWIN ? 0L : (long)c_loa * p.c_cs);
     const int ktiles = p.ktiles;
     const long wrapR = p.r_cs - (long)ktiles * SW_BKB, wrapC = (TWIN ? 0L : p.c_cs) - (long)ktiles * SW_BKB;
     const int total = ncand * ktiles;
@@ -2561,9 +2574,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     // the four pieces of a tile: k = 0, 1 feature side, k = 2, 3 sample side (the cursors advance behind the last one)
     auto piece = [&](auto stage_c, auto k_c) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_c)::value, k = decltype(k_c)::value;
-        char* s = smem + ST * SW7_STAGE + lds_w + (k >> 1) * SW7_REGION + (k & 1) * 1024;
+        if constexpr (MERGED && k == 3) return;          // three pieces per tile
+        char* s = smem + ST * SW7_STAGE + ((MERGED && k == 2) ? wid * 1024 : lds_w) + (k >> 1) * SW7_REGION + (k & 1) * 1024;
         if constexpr (!(P4V_SW7_DBG & 1)) glds16((k >> 1 ? curC : curR) + ((k & 1) ? voff1 : voff0), s);
-        if constexpr (k == 3) {
+        if constexpr (k == PPT - 1) {
             curR += SW_BKB; curC += SW_BKB;
             if (++ikt == ktiles) { ikt = 0; curR += wrapR; curC += wrapC; }
         }
@@ -2589,7 +2603,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     const unsigned crow = (TWIN ? wc * 32 : wc * 64) + l31;
     const unsigned aC0 = lds0 + SW7_REGION + crow * 64 + ((g ^ sw) << 4), aC1 = lds0 + SW7_REGION + crow * 64 + (((2 + g) ^ sw) << 4);
     const unsigned aR0h = aR0 + 2 * SW7_STAGE, aR1h = aR1 + 2 * SW7_STAGE, aC0h = aC0 + 2 * SW7_STAGE, aC1h = aC1 + 2 * SW7_STAGE;
-    constexpr int QOFF = TWIN ? 128 * 64 : 32 * 64;      // second sample block: the other plane / the next 32 samples
+    constexpr int QOFF = TW == 1 ? 128 * 64 : 32 * 64;   // second sample block: the other plane / the next 32 samples
 
 #define P4V_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct Fr { v4i r[2][4], c[2][2]; };                 // [k-half][block]: the 12 fragments of one k-tile
@@ -2600,15 +2614,37 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         const unsigned bR0 = (ST >> 1) ? aR0h : aR0, bR1 = (ST >> 1) ? aR1h : aR1;
         const unsigned bC0 = (ST >> 1) ? aC0h : aC0, bC1 = (ST >> 1) ? aC1h : aC1;
         P4V_DSR(f.c[0][0], bC0, SO); P4V_DSR(f.r[0][0], bR0, SO); P4V_DSR(f.r[0][1], bR0, SO + 2048);
-        P4V_DSR(f.c[0][1], bC0, SO + QOFF); P4V_DSR(f.r[0][2], bR0, SO + 4096); P4V_DSR(f.r[0][3], bR0, SO + 6144);
+        if constexpr (!MERGED) P4V_DSR(f.c[0][1], bC0, SO + QOFF);
+        P4V_DSR(f.r[0][2], bR0, SO + 4096); P4V_DSR(f.r[0][3], bR0, SO + 6144);
         P4V_DSR(f.c[1][0], bC1, SO); P4V_DSR(f.r[1][0], bR1, SO); P4V_DSR(f.r[1][1], bR1, SO + 2048);
-        P4V_DSR(f.c[1][1], bC1, SO + QOFF); P4V_DSR(f.r[1][2], bR1, SO + 4096); P4V_DSR(f.r[1][3], bR1, SO + 6144);
+        if constexpr (!MERGED) P4V_DSR(f.c[1][1], bC1, SO + QOFF);
+        P4V_DSR(f.r[1][2], bR1, SO + 4096); P4V_DSR(f.r[1][3], bR1, SO + 6144);
     };
     auto read_tile = [&](auto stage_c) __attribute__((always_inline)) { read_tile_(f, stage_c); };
     // all 12 fragments have landed, and no MFMA below is scheduled above this point
     auto frags_ready = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.c[0][0]), "+v"(f.c[0][1]),
-                                               "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]), "+v"(f.c[1][0]), "+v"(f.c[1][1]) :: "memory");
+        if constexpr (MERGED) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.c[0][0]),
+                                                   "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]), "+v"(f.c[1][0]) :: "memory");
+            // split the merged plane: byte-wise negative part n = v & mask (mask = 0xFF where the sign bit is set), positive
+            // part v ^ n; plane 0 = positive range, plane 1 = negative range (the order of S1 / S2 and of acc[.][0 / 1])
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned v = (unsigned)f.c[h][0][e];
+                    const unsigned sg = v & 0x80808080u;
+                    const unsigned mask = (sg - (sg >> 7)) | sg;
+                    const unsigned ng = v & mask;
+                    f.c[h][1][e] = (int)ng;
+                    f.c[h][0][e] = (int)(v ^ ng);
+                }
+            // (keep the split in this load phase: nothing else orders it against the barrier in front of the MFMAs)
+            asm volatile("" : "+v"(f.c[0][0]), "+v"(f.c[0][1]), "+v"(f.c[1][0]), "+v"(f.c[1][1]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[0][2]), "+v"(f.r[0][3]), "+v"(f.c[0][0]), "+v"(f.c[0][1]),
+                                                   "+v"(f.r[1][0]), "+v"(f.r[1][1]), "+v"(f.r[1][2]), "+v"(f.r[1][3]), "+v"(f.c[1][0]), "+v"(f.c[1][1]) :: "memory");
+        }
     };
     // The 16 MFMAs of a k-tile.  `fill` (compile-time stage, or none): pieces k0, k0 + 1 of the tile being streamed in are
     // issued between them -- an LDS-DMA issue costs a wave ~60 clk next to bare MFMAs but 100-185 clk in a phase that also
@@ -2727,14 +2763,14 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     if (npre > 0) issue(std::integral_constant<int, 0>{});
     if (npre > 1) issue(std::integral_constant<int, 1>{});
     if (npre > 2) issue(std::integral_constant<int, 2>{});
-    if (total > 2) wait_vmcnt<8>(); else if (total > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (total > 2) wait_vmcnt<2 * PPT>(); else if (total > 1) wait_vmcnt<PPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // Tile it+3 is streamed in during k-tile `it`, two pieces under each group's MFMAs and two in its load phase (A: feature
     // side while computing, then sample side; B: feature side in its load phase, sample side while computing).  At the
     // landed-wait before B1(it) the younger pieces of a wave are therefore tile it+2 (4) and the first two of tile it+3.
     int it = 0;
     auto wait_landed = [&](int it_) __attribute__((always_inline)) {      // own pieces of tile it_+1
-        if (it_ + 3 < total) wait_vmcnt<6>(); else if (it_ + 2 < total) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        if (it_ + 3 < total) wait_vmcnt<PPT + 2>(); else if (it_ + 2 < total) wait_vmcnt<PPT>(); else wait_vmcnt<0>();
     };
     if (wr == 0) {
         read_tile(std::integral_constant<int, 0>{});

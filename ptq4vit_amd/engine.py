@@ -430,7 +430,8 @@ def quantize_i8(x2d, scales, rows_per_scale, lo, hi):
 def pack_plane_i8(x2d, *, mode="sym", scales=None, rows_per_scale=1, lo=-128, hi=127, qmax=128, const_scale=0.0):
     """ONE int8 operand plane exactly as the candidate sweeps consume it (p4v_pack_plane_i8): mode "sym"
     (clamp(rint(x/s), lo, hi); `scales=None` uses `const_scale`, the post-GELU negative range), "sos_hi" / "sos_lo"
-    (split-of-softmax ranges, `scales` = the split).  Returns the [rows][cols] int8 plane (padding stripped)."""
+    (split-of-softmax ranges, `scales` = the split), "twin" (both post-GELU ranges in one plane: `scales` = the positive
+    interval, `const_scale` the negative one, lo < 0 < hi).  Returns the [rows][cols] int8 plane (padding stripped)."""
     lib = _lib.load()
     _require_cuda(x2d, "x")
     x2d = x2d.contiguous().float()
@@ -438,7 +439,7 @@ def pack_plane_i8(x2d, *, mode="sym", scales=None, rows_per_scale=1, lo=-128, hi
     colsp = (cols + 63) // 64 * 64
     q = torch.empty(rows, colsp, dtype=torch.int8, device=x2d.device)
     d = _lib.PlaneDesc(rows, cols, colsp, int(rows_per_scale),
-                       {"sym": _lib.PLANE_SYM, "sos_hi": _lib.PLANE_SOS_HI, "sos_lo": _lib.PLANE_SOS_LO}[mode],
+                       {"sym": _lib.PLANE_SYM, "sos_hi": _lib.PLANE_SOS_HI, "sos_lo": _lib.PLANE_SOS_LO, "twin": _lib.PLANE_TWIN}[mode],
                        int(lo), int(hi), int(qmax), float(const_scale), 0)
     sc = scales.to(x2d.device, torch.float32).reshape(-1).contiguous() if scales is not None else None
     with torch.cuda.device(x2d.device):

@@ -407,6 +407,29 @@ def test_large_k_sweep_matches_the_128_tile_sweeps(eng):
     assert torch.equal(new[3], old[3]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
 
 
+@pytest.mark.parametrize("b,T,K,N,bit", [(8, 197, 3072, 768, 8), (3, 131, 1024, 288, 6), (2, 150, 1536, 384, 8), (1, 100, 4096, 64, 4)],
+                         ids=["vit-b-fc2", "ragged-w6", "vit-s-fc2", "one-sample-tile-w4"])
+def test_merged_plane_twin_is_bit_identical_to_the_two_plane_twin(eng, b, T, K, N, bit):
+    """A/B of the post-GELU weight search on k_sweep7: ONE merged int8 plane k_pos + k_neg split into its two fragments in
+    registers (default) against the two streamed planes (variant 2097152).  The int32 accumulators are the same integers and
+    the epilogue is the same code in the same order: score tables, selections and intervals must be BIT-identical."""
+    w, bias, x, out, grad = _mk_linear(23, b, T, K, N, postgelu=True, gscale=1e-3)
+    hp = dict(w_bit=bit, a_bit=bit, metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2, n_V=1, n_H=1, n_a=1)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), want_scores=True, postgelu=True)
+    new = eng.linear_calibrate(**args, **hp)
+    again = eng.linear_calibrate(**args, **hp)
+    eng.debug_variant(2097152)
+    try:
+        old = eng.linear_calibrate(**args, **hp)
+    finally:
+        eng.debug_variant(0)
+    torch.cuda.synchronize()
+    for a, c in zip(new, again):
+        assert torch.equal(a, c), "merged-plane twin is not run-to-run deterministic"
+    for a, c, what in zip(new, old, ("w_interval", "a_interval", "score tables", "selections")):
+        assert torch.equal(a, c), f"merged-plane twin differs from the two-plane twin: {what}"
+
+
 def test_single_ktile_sweep_matches_the_streaming_sweep(eng):
     """A/B at ViT-B q.k^T geometry (4 images x 12 heads, 197 x 64 x 197): k_sweep8 (fixed operand in registers, 8-deep ring)
     against k_sweep2 (variant 65536), both searches -- identical selections, tables equal to summation-order noise (the

@@ -52,6 +52,11 @@ def test_twin_postgelu_planes_bit_exact(eng, bit, cols):
     neg, padded = eng.pack_plane_i8(_t(x), mode="sym", scales=None, const_scale=float(s_neg), lo=-q, hi=0, qmax=q)
     np.testing.assert_array_equal(pos.cpu().numpy(), ref_pos)
     np.testing.assert_array_equal(neg.cpu().numpy(), ref_neg)
+    # the merged plane of the large-K weight search (k_sweep7 splits it by sign): k_pos + k_neg, byte for byte
+    both, _ = eng.pack_plane_i8(_t(x), mode="twin", scales=torch.tensor([s_pos]), const_scale=float(s_neg), lo=-q, hi=q - 1, qmax=q)
+    np.testing.assert_array_equal(both.cpu().numpy(), ref_pos + ref_neg)
+    np.testing.assert_array_equal(np.maximum(both.cpu().numpy(), 0), ref_pos)
+    np.testing.assert_array_equal(np.minimum(both.cpu().numpy(), 0), ref_neg)
     assert (ref_pos != 0).any() and (ref_neg != 0).any()
     assert not np.logical_and(ref_pos != 0, ref_neg != 0).any()            # disjoint supports
     assert int(padded[:, cols:].abs().max().item() if padded.shape[1] > cols else 0) == 0   # K padding is zero
