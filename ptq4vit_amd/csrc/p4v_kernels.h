@@ -2458,6 +2458,10 @@ struct Sweep7Params {
 #ifndef P4V_SW7_DBG
 #define P4V_SW7_DBG 0
 #endif
+// P4V_SW7_FILL: LDS-DMA pieces of a k-tile that a wave issues between its own MFMAs (the rest in its load phase)
+#ifndef P4V_SW7_FILL
+#define P4V_SW7_FILL 4
+#endif
 static constexpr int SW7_NS = 4;
 static constexpr int SW7_REGION = 256 * 64;       // one operand side of a k-tile: 256 rows x 64 B
 static constexpr int SW7_STAGE = 2 * SW7_REGION;
@@ -2659,7 +2663,18 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     acc[j][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.r[h][j], f.c[h][q], acc[j][q], 0, 0, 0);
-                    if (j == 1 && q == 1) {              // behind the 4th / 12th MFMA
+                    if constexpr (P4V_SW7_FILL == 4) {
+                        if (j % 2 == 0 && q == 1) {      // behind the 2nd / 6th / 10th / 14th MFMA: all four pieces ride here
+                            __builtin_amdgcn_sched_barrier(0x6);
+                            if (fill) {
+                                if (h == 0 && j == 0) piece(stage_c, std::integral_constant<int, 0>{});
+                                else if (h == 0) piece(stage_c, std::integral_constant<int, 1>{});
+                                else if (j == 0) piece(stage_c, std::integral_constant<int, 2>{});
+                                else piece(stage_c, std::integral_constant<int, 3>{});
+                            }
+                            __builtin_amdgcn_sched_barrier(0x6);
+                        }
+                    } else if (j == 1 && q == 1) {       // behind the 4th / 12th MFMA
                         __builtin_amdgcn_sched_barrier(0x6);
                         if (fill) { if (h == 0) piece(stage_c, std::integral_constant<int, k0>{}); else piece(stage_c, std::integral_constant<int, k0 + 1>{}); }
                         __builtin_amdgcn_sched_barrier(0x6);
@@ -2770,7 +2785,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     // landed-wait before B1(it) the younger pieces of a wave are therefore tile it+2 (4) and the first two of tile it+3.
     int it = 0;
     auto wait_landed = [&](int it_) __attribute__((always_inline)) {      // own pieces of tile it_+1
-        if (it_ + 3 < total) wait_vmcnt<PPT + 2>(); else if (it_ + 2 < total) wait_vmcnt<PPT>(); else wait_vmcnt<0>();
+        if constexpr (P4V_SW7_FILL == 4) {
+            // group A has issued all of tile it+3 (under the MFMAs of this k-tile), group B none of it yet
+            if (wr == 0) { if (it_ + 3 < total) wait_vmcnt<2 * PPT>(); else if (it_ + 2 < total) wait_vmcnt<PPT>(); else wait_vmcnt<0>(); }
+            else { if (it_ + 2 < total) wait_vmcnt<PPT>(); else wait_vmcnt<0>(); }
+        } else {
+            if (it_ + 3 < total) wait_vmcnt<PPT + 2>(); else if (it_ + 2 < total) wait_vmcnt<PPT>(); else wait_vmcnt<0>();
+        }
     };
     if (wr == 0) {
         read_tile(std::integral_constant<int, 0>{});
@@ -2788,7 +2809,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
             if constexpr (!(P4V_SW7_DBG & 4)) if (epi_ci >= 0) epilogue(epi_ci);
             // fragment reads FIRST: their LDS latency passes under the DMA issues behind them
             if (it_ + 1 < total) read_tile(std::integral_constant<int, (ST + 1) % SW7_NS>{});
-            if (it_ + 3 < total) {
+            if (P4V_SW7_FILL != 4 && it_ + 3 < total) {
                 piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 2>{});
                 piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 3>{});
             }
@@ -2811,7 +2832,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         auto first = [&](int it_, auto stage_c) __attribute__((always_inline)) {
             constexpr int ST = decltype(stage_c)::value;
             read_tile(stage_c);
-            if (it_ + 3 < total) {
+            if (P4V_SW7_FILL != 4 && it_ + 3 < total) {
                 piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 0>{});
                 piece(std::integral_constant<int, (ST + 3) % SW7_NS>{}, std::integral_constant<int, 1>{});
             }

@@ -661,18 +661,26 @@ class HessianQuantCalibrator(QuantCalibrator):
         self.owner = owner
         raw_pred_softmax = self._raw_pred_softmax() if with_grad else None
 
-        # Capture plan.  Default (the design BASELINE.json's north_star names): every rank runs the same deterministic
+        # Capture plan.  Replicated (the design BASELINE.json's north_star names): every rank runs the same deterministic
         # capture passes with hooks on its OWN modules only -- no data-path collective -- and the only exchange is the
-        # interval all-gather at the end.  Opt-in (`shard_capture = True` / P4V_SHARD_CAPTURE=1): sub-batch sharded
-        # capture, every rank runs 1/world of the passes hooking ALL modules and the pieces are gathered onto the owners
-        # (shard.exchange_captures).  Whether that collective is entered must be the SAME decision on every rank, so it
+        # interval all-gather at the end.  Sharded: every rank runs 1/world of the sub-batch passes hooking ALL modules and
+        # the pieces travel to the module owners in one all_to_all (shard.exchange_captures); chosen by the cost model where
+        # the replicated passes would cap the speed-up.  Whether that collective is entered must be the SAME decision on every rank, so it
         # is derived from rank-invariant quantities only (all_sizes covers every module on every rank; a rank that owns
         # nothing, or whose own cache would need several groups, decides exactly like the others).
         bs_ = self._capture_bs()
         n_sub = sum(-(-inp.shape[0] // bs_) for inp, _ in self.calib_loader)
+        # `shard_capture` / P4V_SHARD_CAPTURE: True / "1" = sharded, False / "0" = replicated, None / "auto" (default) = the
+        # cost model of shard.choose_capture_mode (rank-invariant inputs only) where all_to_all_single works on every rank
         want_shard = getattr(self, "shard_capture", None)
         if want_shard is None:
-            want_shard = os.environ.get("P4V_SHARD_CAPTURE", "0") == "1"
+            env = os.environ.get("P4V_SHARD_CAPTURE", "auto")
+            want_shard = True if env == "1" else False if env == "0" else None
+        if want_shard is None:
+            want_shard = (world > 1 and not self.sequential and with_grad and all_sizes is not None
+                          and shard.choose_capture_mode(self.wrapped_modules, all_sizes, world, n_sub) == "sharded"
+                          and shard.all_to_all_available())
+        self.capture_mode = "replicated"
         shard_cap = False
         dev_ = _dev_of(self.net)
         replay_is_cheap = (with_grad and dev_.type == "cuda" and not self.sequential and getattr(self, "use_graph", None) is not False
@@ -731,8 +739,10 @@ class HessianQuantCalibrator(QuantCalibrator):
             per_rank = [sum(all_sizes.get(n, 0) for n in names if owner[n] == r) for r in range(world)]
             during = sum(all_sizes.values()) / world          # every rank holds all modules x its share of sub-batches
             shard_budget = self.cache_budget_bytes if self.cache_budget_bytes is not None else (200 << 30)   # NOT the locally
-            shard_cap = (n_sub >= world and max(per_rank) + during <= shard_budget                            # measured one
+            # (pieces of all modules + the send buffer, then the receive buffer + the reassembled tensors of the own modules)
+            shard_cap = (n_sub >= world and 2 * max(per_rank) + 2 * during <= shard_budget                    # measured one
                          and all(inp.shape[0] % bs_ == 0 for inp, _ in self.calib_loader))
+            self.capture_mode = "sharded" if shard_cap else "replicated"
         groups = plan(mine, budget)
         t_cap = t_cal = 0.0
         done = set()
@@ -763,12 +773,15 @@ class HessianQuantCalibrator(QuantCalibrator):
             done.update(grp)
             t_cap += dc
             t_cal += ds
+        t_ex = 0.0
         if world > 1 and not self.sequential:
+            t1 = time.time()
             shard.exchange_intervals(self.wrapped_modules, owner)
+            t_ex = time.time() - t1          # includes waiting for the slowest rank's search (the collective is the barrier)
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
         self.net.__dict__["_p4v_calibrations"] = self.net.__dict__.get("_p4v_calibrations", 0) + 1
-        self.timings = {"capture_s": t_cap, "search_s": t_cal, "total_s": time.time() - t0,
+        self.timings = {"capture_s": t_cap, "search_s": t_cal, "exchange_s": t_ex, "total_s": time.time() - t0,
                         "modules": len(names), "owned": len(mine)}
         self.calibrated = True
         print("hessian calibration finished")

@@ -192,13 +192,14 @@ def _module_pieces(module, with_grad):
 
 def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
     """Every rank ran the capture passes of the sub-batches i with i % world == rank, hooking ALL modules; afterwards
-    each module's pieces travel to its owner: one `gather` per owner rank (RCCL over xGMI; gloo in the tests), payload =
-    that owner's modules x the sender's sub-batches, padded to a common slot count so that all senders agree on the
-    layout.  The owner reassembles the full tensors in sub-batch order -- bit-identical to a capture of all sub-batches
-    on one GPU (each sub-batch pass is the same computation wherever it runs).  Non-owners drop their pieces.
+    each module's pieces travel to its owner in ONE `all_to_all_single` (RCCL over xGMI: every GPU sends to its seven
+    peers over their own links at the same time; gloo in the tests).  Send buffer of a rank = for each destination, that
+    owner's modules x this rank's sub-batches, padded to a common slot count so that every sender uses the same layout.  The
+    owner reassembles the full tensors in sub-batch order -- bit-identical to a capture of all sub-batches on one GPU (each
+    sub-batch pass is the same computation wherever it runs).  Non-owners drop their pieces.
 
-    Traffic per GPU: (its modules' cache) x (world - 1) / world -- for ViT-B/224 x 32 images on 8 GPUs about 1 GB in,
-    against 7/8 of the forward/backward passes saved.
+    Traffic per GPU: (its modules' cache) x (world - 1) / world in and about as much out -- for ViT-B/224 x 32 images on
+    8 GPUs about 1 GB each way, against 7/8 of the forward/backward passes saved.
     """
     rank, world = rank_world()
     names = list(wrapped_modules)
@@ -211,11 +212,12 @@ def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
             break
     # RCCL moves device buffers; gloo (CPU tests, or several ranks sharing one GPU) needs host buffers
     backend_dev = data_dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    layouts, sizes, chunks = [], [], []              # per destination: [(name, list index, piece shape)], elements
     for dst in range(world):
-        mine = [n for n in names if owner[n] == dst]
-        layout = []                                   # (name, list index, piece shape)
-        chunks = []
-        for n in mine:
+        layout, numel = [], 0
+        for n in names:
+            if owner[n] != dst:
+                continue
             for li, lst in enumerate(_module_pieces(wrapped_modules[n], n in grad_names)):
                 shp = tuple(lst[0].shape)
                 layout.append((n, li, shp))
@@ -224,39 +226,108 @@ def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
                         chunks.append(lst[k].reshape(-1).to(device=backend_dev, dtype=torch.float32))
                     else:
                         chunks.append(torch.zeros(lst[0].numel(), dtype=torch.float32, device=backend_dev))
-        send = torch.cat(chunks) if chunks else torch.zeros(1, dtype=torch.float32, device=backend_dev)
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, recv, dst=dst)
-        if rank == dst:
-            full = {}
-            off = 0
-            for (n, li, shp) in layout:
-                per = 1
-                for d in shp:
-                    per *= d
-                t = torch.empty((n_sub * shp[0],) + shp[1:], dtype=torch.float32, device=data_dev)
-                for k in range(slots):
-                    for src in range(world):
-                        i = src + k * world                   # global sub-batch index of (sender, slot)
-                        if i < n_sub:
-                            t[i * shp[0]:(i + 1) * shp[0]].copy_(recv[src][off + k * per: off + (k + 1) * per].reshape(shp))
-                off += slots * per
-                full[(n, li)] = t
-            for n in mine:
-                m = wrapped_modules[n]
-                with_g = n in grad_names
-                nl = len(_module_pieces(m, with_g))
-                ts = [full[(n, li)] for li in range(nl)]
-                n_in = nl - 1 - (1 if with_g else 0)
-                m.raw_input = ts[0] if n_in == 1 else ts[:n_in]
-                m.raw_out = ts[n_in]
-                if with_g:
-                    m.raw_grad = ts[n_in + 1]
-            del recv
-        del send, chunks
-    for n in names:                                   # pieces of modules this rank does not own are no longer needed
+                numel += slots * lst[0].numel()
+        layouts.append(layout)
+        sizes.append(numel)
+    send = torch.cat(chunks) if chunks else torch.zeros(0, dtype=torch.float32, device=backend_dev)
+    del chunks
+    for n in names:                                   # the pieces are in `send` now; what this rank owns comes back below
+        m = wrapped_modules[n]
+        m.raw_input = m.raw_out = None
+        if n in grad_names:
+            m.raw_grad = None
+    per_src = sizes[rank]                             # every sender's block for this rank has this rank's layout
+    recv = torch.empty(per_src * world, dtype=torch.float32, device=backend_dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=[per_src] * world, input_split_sizes=sizes)
+    del send
+    full, off = {}, 0
+    for (n, li, shp) in layouts[rank]:
+        per = 1
+        for d in shp:
+            per *= d
+        t = torch.empty((n_sub * shp[0],) + shp[1:], dtype=torch.float32, device=data_dev)
+        for src in range(world):
+            base = src * per_src + off
+            for k in range(slots):
+                i = src + k * world                   # global sub-batch index of (sender, slot)
+                if i < n_sub:
+                    t[i * shp[0]:(i + 1) * shp[0]].copy_(recv[base + k * per: base + (k + 1) * per].reshape(shp))
+        off += slots * per
+        full[(n, li)] = t
+    del recv
+    for n in names:
         if owner[n] != rank:
-            m = wrapped_modules[n]
-            m.raw_input = m.raw_out = None
-            if n in grad_names:
-                m.raw_grad = None
+            continue
+        m = wrapped_modules[n]
+        with_g = n in grad_names
+        nl = sum(1 for (nn, _, _) in layouts[rank] if nn == n)
+        ts = [full[(n, li)] for li in range(nl)]
+        n_in = nl - 1 - (1 if with_g else 0)
+        m.raw_input = ts[0] if n_in == 1 else ts[:n_in]
+        m.raw_out = ts[n_in]
+        if with_g:
+            m.raw_grad = ts[n_in + 1]
+
+
+# ---- replicated or sharded capture: a rank-invariant cost model --------------------------------------------------
+def capture_cost_ms(wrapped_modules, sizes):
+    """Predicted time (ms, one MI355X) of ALL capture passes of a calibration, from rank-invariant quantities only: the
+    MACs of the wrapped GEMMs (forward + the activation-gradient half of the backward; weight gradients are skipped) at the
+    fp32 rate the sub-batch passes reach (21.5 TMAC/s: ViT-B/224 x 32 images = 2 x 560 GMAC in 52 ms, profiles/r2_bench.json).
+    `sizes[name]` = bytes of the module's captured tensors (x + out + grad; matmuls A + B + out + grad)."""
+    macs = 0.0
+    for n, m in wrapped_modules.items():
+        w = getattr(m, "weight", None)
+        c = float(sizes.get(n, 0))
+        if w is None:
+            macs += (c / 16.0) * 64.0                 # out elements ~ cache / 16, K ~ head dim
+        elif w.dim() == 4:
+            k = w[0].numel()
+            macs += c / 4.0 / max(1.0, 2.0 * w.shape[0] + k) * k * w.shape[0]
+        else:
+            macs += c / 4.0 / (w.shape[1] + 2.0 * w.shape[0]) * w.shape[0] * w.shape[1]
+    return 2.0 * macs / 21.5e9
+
+
+def choose_capture_mode(wrapped_modules, sizes, world, n_sub, gb_per_s_per_peer=40.0):
+    """"sharded" when running 1/world of the capture passes per rank and moving the pieces to the module owners is predicted
+    to beat every rank running all passes, else "replicated".  Every input is the same on every rank (module list, captured
+    sizes from the shape probe, world size), so all ranks take the same branch -- required: the sharded path is a collective.
+    xGMI is point to point: a GPU receives from its world - 1 peers over as many links at once (conservative 40 GB/s
+    each), and pays two extra passes over its share in HBM for packing and reassembly."""
+    if world < 2 or n_sub < 2:
+        return "replicated"
+    t_cap = capture_cost_ms(wrapped_modules, sizes)
+    share = sum(float(v) for v in sizes.values()) / world              # bytes a rank ends up owning (LPT: about equal)
+    moved = share * (world - 1) / world
+    t_xfer = moved / (gb_per_s_per_peer * 1e6 * (world - 1)) + 3.0 * share / 2.0e9 + 2.0      # ms
+    passes_saved = 1.0 - float(-(-n_sub // world)) / n_sub
+    return "sharded" if t_cap * passes_saved > 1.5 * t_xfer + 5.0 else "replicated"
+
+
+_A2A_OK = None
+
+
+def all_to_all_available():
+    """One-time check that the process group's all_to_all_single works here, AGREED between the ranks (a tiny all_reduce(MIN)
+    of the local outcomes -- the collective the interval exchange needs anyway): the sharded capture is only entered when
+    every rank can run it; otherwise all of them stay with the replicated capture."""
+    global _A2A_OK
+    if _A2A_OK is not None:
+        return _A2A_OK
+    rank, world = rank_world()
+    dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
+    ok = 1
+    try:
+        send = torch.full((world * 4,), float(rank), dtype=torch.float32, device=dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, output_split_sizes=[4] * world, input_split_sizes=[4] * world)
+        want = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(4)
+        ok = int(bool(torch.equal(recv, want)))
+    except Exception as e:  # pragma: no cover - depends on the backend build
+        print(f"[ptq4vit_amd] all_to_all_single unavailable on rank {rank} ({type(e).__name__}: {e}); replicated capture")
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _A2A_OK = bool(int(flag.item()))
+    return _A2A_OK

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from tests.helpers import (assert_argmax_tie_aware, assert_on_candidate_grid, assert_scores_close, candidate_grid,
-                           golden_names, load_golden)
+                           golden_names, grid_steps_between, load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -242,7 +242,7 @@ def test_calibrator_entry_points_vs_reference(run):
             QuantCalibrator(net, wrapped, Loader(), sequential=(run == "sequential")).quant_calib()
     assert all(m.mode == "quant_forward" and m.calibrated for m in wrapped.values())
     mult = candidate_grid(hp["eq_alpha"], hp["eq_beta"], hp["eq_n"])
-    total = moved = 0
+    total = moved = rounded = 0
     for n, m in wrapped.items():
         key = n.replace(".", "__")
         for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split"):
@@ -258,16 +258,24 @@ def test_calibrator_entry_points_vs_reference(run):
                 assert float(got) in [2.0 ** -i for i in range(20)] or a == "A_interval"
                 continue
             total += want.size
-            moved += assert_on_candidate_grid(got, want, mult, f"{n}.{a}")
+            assert_on_candidate_grid(got, want, mult, f"{n}.{a}")
+            for x, y in zip(got.reshape(-1), want.reshape(-1)):
+                if x != y:
+                    # 0 steps: the SAME candidate of a table whose initial interval differs in the last bits
+                    if grid_steps_between(x, y, mult) == 0:
+                        rounded += 1
+                    else:
+                        moved += 1
         if f"{key}::a_neg_interval" in g.files:
             assert float(m.a_interval[1]) == float(g[f"{key}::a_neg_interval"])
     with torch.no_grad():
         q = net(images).cpu().numpy()
     rng = float(g["quant_logits"].max() - g["quant_logits"].min())
     err = np.abs(q - g["quant_logits"]).max() / rng
-    print(f"[parity] {run}_quant_calib on the mini ViT vs the reference's run: {total - moved}/{total} intervals bit-identical, "
-          f"{moved} on another entry of the candidate table; quantised logits {err:.2e} of the logit range")
-    # sequential: a module's input is its predecessors' QUANTISED output (int8 GEMMs here, fp32 fake-quant GEMMs in the
-    # reference), so near-ties can resolve differently downstream; parallel / hessian capture raw tensors only
-    assert moved <= (0.2 if run == "sequential" else 0.1) * total, (moved, total)
+    print(f"[parity] {run}_quant_calib on the mini ViT vs the reference's run: {total - moved - rounded}/{total} intervals "
+          f"bit-identical, {rounded} the same candidate within 4e-7 (input rounding), {moved} on another entry of the candidate "
+          f"table; quantised logits {err:.2e} of the logit range")
+    # (`rounded`: the captured tensors come from this GPU's fp32 GEMMs, the reference's from the CPU's -- a min-max that sits
+    # on an element whose last bits differ moves the whole candidate table by those bits; the selected INDEX is what is compared)
+    assert moved <= 0.1 * total, (moved, total)
     assert err <= (1e-5 if moved == 0 else 2e-2), err

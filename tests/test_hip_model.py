@@ -184,7 +184,7 @@ def test_deit_tiny_224_baseptq_4_images_vs_the_reference_itself():
     for n in runs[0]:
         for a, b in zip(runs[0][n], runs[1][n]):
             assert torch.equal(a, b), n
-    total = moved = 0
+    total = moved = rounded = 0
     far, dist = [], []
     for n, m in wrapped.items():
         key = n.replace(".", "__")
@@ -193,23 +193,27 @@ def test_deit_tiny_224_baseptq_4_images_vs_the_reference_itself():
                 continue
             want = g[f"{key}::{a}"]
             got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy().reshape(-1)
-            if a == "a_interval" and n == "patch_embed.proj":       # a_bit = 32: never searched, min-max of the input
+            if a == "a_interval" and n == "patch_embed.proj":       # a_bit = 32: never searched, min-max of the (identical) images
                 np.testing.assert_array_equal(got, want.reshape(-1))
                 continue
-            k, mv = _interval_parity(m, n, a, got, want)
+            k, _ = _interval_parity(m, n, a, got, want)          # bit-identical or on the candidate grid (asserts)
             total += k
-            moved += mv
             for x, y in zip(got, want.reshape(-1)):
                 if x != y:
                     steps = grid_steps_between(x, y, candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n))
+                    if steps == 0:        # the SAME candidate of a table whose initial (min-max) interval differs in the last bits:
+                        rounded += 1      # the capture here is the GPU's fp32 GEMMs, the reference's was the CPU's
+                        continue
+                    moved += 1
                     dist.append(steps)
                     if steps is None or steps > MAX_STEPS:
                         far.append((n, a, float(x), float(y), steps))
     with torch.no_grad():
         q = net(images).cpu().numpy()
     q_err = np.abs(q - g["quant_logits"]).max() / rng
-    print(f"[parity] DeiT-tiny/224 BasePTQ x4 vs the reference's own run: {total - moved}/{total} intervals bit-identical, {moved} on "
-          f"another entry of the candidate table (grid steps away: {sorted(dist)}); raw logits {raw_err:.2e}, quantised logits {q_err:.2e} of the logit range "
+    print(f"[parity] DeiT-tiny/224 BasePTQ x4 vs the reference's own run: {total - moved - rounded}/{total} intervals bit-identical, "
+          f"{rounded} the same candidate within 4e-7 (rounding of the captured input), {moved} on "
+          f"another entry of the candidate table (grid steps away: {sorted(dist, key=lambda v: (v is None, v))}); raw logits {raw_err:.2e}, quantised logits {q_err:.2e} of the logit range "
           f"(quantisation error itself: {np.abs(g['quant_logits'] - g['raw_logits']).max() / rng:.2e})")
     assert raw_err <= RAW_TOL, raw_err
     assert not far, far

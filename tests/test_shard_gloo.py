@@ -324,3 +324,109 @@ def test_lpt_balance_on_swin_base():
         owner = shard.assign_modules(wrapped, world, costs)
         load = [sum(costs[n] for n in wrapped if owner[n] == r) for r in range(world)]
         assert max(load) <= 1.12 * (sum(load) / world), (world, load)
+
+
+# ---- world 8 on the real module lists: ViT-B/224 (74 modules) and Swin-B/384 (149) --------------------------------------
+def _interval_specs(wrapped):
+    """(name, {attr: shape}) of what each module's step 2 leaves behind, without running it."""
+    from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
+    from ptq4vit_amd.quant_layers.linear import MinMaxQuantLinear
+    specs = []
+    for n, m in wrapped.items():
+        if isinstance(m, MinMaxQuantLinear):
+            specs.append((n, {"w_interval": (m.n_V, 1, m.n_H, 1), "a_interval": (m.n_a, 1)}))
+        elif isinstance(m, MinMaxQuantConv2d):
+            specs.append((n, {"w_interval": (m.out_channels, 1, 1, 1), "a_interval": (1,)}))
+        else:
+            heads = m._p4v_heads
+            spec = {"B_interval": (1, heads, 1, 1, 1, 1, 1)}
+            spec.update({"split": (), "A_interval": ()} if m._sos else {"A_interval": (1, heads, 1, 1, 1, 1, 1)})
+            specs.append((n, spec))
+    return specs
+
+
+class _Slot(torch.nn.Module):
+    pass
+
+
+def _fill(name, spec, m):
+    g = torch.Generator().manual_seed(sum(ord(ch) for ch in name))
+    for a, shp in spec.items():
+        setattr(m, a, torch.rand(*shp, generator=g) if shp else torch.rand((), generator=g))
+
+
+def _world8_worker(rank, world, port, q, specs, owner):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mods = {}
+    for n, spec in specs:
+        m = _Slot()
+        for a in shard.INTERVAL_ATTRS:
+            setattr(m, a, None)
+        if owner[n] == rank:
+            _fill(n, spec, m)
+        mods[n] = m
+    shard.exchange_intervals(mods, owner)
+    ok = True
+    for n, spec in specs:
+        ref = _Slot()
+        _fill(n, spec, ref)
+        for a, shp in spec.items():
+            got = getattr(mods[n], a)
+            ok &= got is not None and tuple(got.shape) == tuple(shp) and torch.equal(got.float().cpu(), getattr(ref, a).float())
+    q.put((rank, ok, sum(1 for n, _ in specs if owner[n] == rank)))
+    dist.destroy_process_group()
+
+
+def test_world8_lpt_balance_and_interval_exchange_on_vit_base_and_swin_base():
+    """Eight ranks (the node BASELINE.json names) on the real module lists: the LPT assignment by predicted search time is
+    within 10 % of the mean load, every rank owns work, and after ONE interval exchange (all_reduce of the slot shapes +
+    all_gather of the interval vector, gloo here, RCCL on the GPUs) every rank holds every module's intervals bit for bit."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap, quant_calib
+    for model, img, calib, n_mod in (("vit_base_patch16_224", 224, 32, 74), ("swin_base_patch4_window12_384", 384, 128, 149)):
+        net = models.get_net(model, seed=0, device="cpu")
+        with contextlib.redirect_stdout(io.StringIO()):
+            wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+        assert len(wrapped) == n_mod
+        image = torch.zeros(1, 3, img, img)
+
+        class Loader:
+            batch_size = 1
+
+            def __iter__(self):
+                yield image, None
+
+        cal = quant_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=1)
+        sizes = {n: calib * b for n, b in cal._estimate_cache_bytes(list(wrapped)).items()}
+        costs = {n: shard.module_cost_ms(wrapped[n], sizes[n]) for n in wrapped}
+        owner = shard.assign_modules(wrapped, 8, costs)
+        load = [sum(costs[n] for n in wrapped if owner[n] == r) for r in range(8)]
+        assert min(load) > 0 and max(load) <= 1.10 * (sum(load) / 8), (model, load)
+        assert shard.choose_capture_mode(wrapped, sizes, 8, calib // 4) == "sharded"        # 7/8 of the passes saved > the transfer
+        assert shard.choose_capture_mode(wrapped, sizes, 1, calib // 4) == "replicated"
+        # heads of the matmul modules (the interval shapes): from a probe forward
+        hooks = [m.register_forward_hook(lambda mod, inp, out: setattr(mod, "_p4v_heads", inp[0].shape[1]))
+                 for m in wrapped.values() if not hasattr(m, "weight")]
+        with torch.no_grad():
+            net(image)
+        for h in hooks:
+            h.remove()
+        specs = _interval_specs(wrapped)
+        del net, cal
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q, specs, owner)) for r in range(8)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(60)
+        assert all(ok for _, ok, _ in res), (model, res)
+        assert sum(k for _, _, k in res) == n_mod and all(k > 0 for _, _, k in res)
