@@ -386,11 +386,24 @@ def gen_deit_tiny(name="deit_tiny_224_baseptq_4img"):
     with torch.no_grad():
         raw_logits = net(images)
     wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+    tables = {}
+    for n, m in wrapped.items():            # every score table the reference feeds to argmax, per module, in call order
+        orig = m.calibration_step2
+
+        def rec(_orig=orig, _n=n):
+            with ArgmaxRecorder() as r:
+                out = _orig()
+            tables[_n] = r.tables
+            return out
+        m.calibration_step2 = rec
     cal = ref_calib.HessianQuantCalibrator(net, wrapped, _Loader(images), sequential=False, batch_size=4)
     cal.batching_quant_calib()
     with torch.no_grad():
         logits = net(images)
     payload = _interval_payload(wrapped)
+    for n, tabs in tables.items():
+        for i, t in enumerate(tabs):
+            payload[f"{n.replace('.', '__')}::scores_{i}"] = t
     payload.update(raw_logits=raw_logits.numpy(), quant_logits=logits.numpy(),
                    images_sum=np.array(images.double().sum().item()), images_abs_sum=np.array(images.double().abs().sum().item()),
                    weights_abs_sum=np.array(sum(p.double().abs().sum().item() for p in net.parameters())),

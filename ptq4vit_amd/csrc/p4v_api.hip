@@ -422,8 +422,8 @@ int sweep9_halves(const SweepParams& p, bool twin, int epi) {
     // one ring stage holds the whole streamed operand of a candidate: 256 rows x 64 B (SW9_STAGE); beyond that k_sweep8
     if ((p.a_cs == 0 ? p.N : p.M) > 256) return 0;
     const long nb = (long)cdiv(p.M, 16) * cdiv(p.N, 16);
-    const int halves = (int)cdiv(nb, 8L * SW9_NB);
-    if (halves > 4) return 0;
+    const int halves = (int)cdiv(nb, (long)SW9_NW * SW9_NB);
+    if (halves > 32 / SW9_NW) return 0;
     // worth it where the 128 x 128 tiles of k_sweep8 carry padding: Swin windows (144 tokens: 3.2 x the 16-granular area, q.k^T
     // search 9.2 -> 6.0 ms per module; 49 tokens: 4 x) and, by 5 %, the 197 tokens of ViT / DeiT (1.5 x: 433 -> 410 us per pass).
     // Variant 1048576 forces it for A/B runs, 524288 disables it.
@@ -432,8 +432,8 @@ int sweep9_halves(const SweepParams& p, bool twin, int epi) {
 }
 template <bool ROWS_FIXED> int launch_sweep9_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    const size_t lds = (size_t)SW9_NS * SW9_STAGE + (size_t)per * 8 * sizeof(float) * 2;
-    dim3 grid(p.halves, p.Z, cgroups), block(512);
+    const size_t lds = (size_t)SW9_NS * SW9_STAGE + (size_t)per * SW9_NW * sizeof(float) * 2;
+    dim3 grid(p.halves, p.Z, cgroups), block(SW9_NW * 64);
 #define P4V_LAUNCH9B(E)                                                                                        \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
@@ -895,12 +895,12 @@ int run_pass(Ctx& c, Pass& ps) {
         }
         if (fast && !ps.store_out && (ps.j_mode == 0 || ps.j_mode == 2)) {
             const int h9 = sweep9_halves(sp, ps.twin, ps.epi);
-            if (h9 > 0 && (long)h9 * 8 <= p_zs) {       // the table allocated for the 128-tile layout holds this one
+            if (h9 > 0 && (long)h9 * SW9_NW <= p_zs) {       // the table allocated for the 128-tile layout holds this one
                 sp.halves = h9;
                 sp.rows_p_stream = sp.a_cs == 0 ? Np : Mp;
-                sp.p_zs = (long)h9 * 8; sp.p_cs = sp.p_zs * ps.Z;
+                sp.p_zs = (long)h9 * SW9_NW; sp.p_cs = sp.p_zs * ps.Z;
                 nine_halves = h9;
-                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, 256, 12.0, 0.9);
+                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, SW9_NW == 4 ? 512 : 256, 12.0, 0.9);
             }
         }
         if (fast && !ps.store_out) {
@@ -911,7 +911,7 @@ int run_pass(Ctx& c, Pass& ps) {
     }
     if (ps.store_out) { c.ws.off = mark; return 0; }
     if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
-        const int slots = nine_halves * 8;
+        const int slots = nine_halves * SW9_NW;
         FinishParams fp{part, (long)slots * ps.Z, (long)slots, slots, 1, ps.Z, slots, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish(c, fp));
     } else if (!cosm) {

@@ -308,6 +308,33 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                         const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
                         w[q] = (int)(lo16 | (hi16 << 16));   // (an OR of two perms with selector 0x04000c0c is mis-folded by the backend)
                     }
+                } else if (p.mode == PACK_TWIN_I8 && live && kc * 16 + 16 <= p.K) {
+                    // merged post-GELU twin: both ranges through the reciprocal path, same exactness check; the supports are
+                    // disjoint (one of the two indices is 0), so the merged byte is the sum of the two low bytes
+                    const float rcp = 1.0f / s, rcn = 1.0f / p.neg_scale, flo = (float)p.lo, fhi = (float)p.hi;
+                    unsigned qb[16];
+                    float maxdev = 0.0f;
+                    float magic = PACK_MAGIC;
+                    asm volatile("" : "+v"(magic));
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        qb[e] = quant_fast1(x[e], rcp, -0.49f, fhi + 0.49f, magic, maxdev) + quant_fast1(x[e], rcn, flo - 0.49f, 0.49f, magic, maxdev);
+                    const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || !(rcn < 3.0e38f) || !(fmaxf(-flo, fhi) < 129.0f);
+                    if (__any(bad)) {
+                        float sd = s;
+                        asm volatile("" : "+v"(sd));
+                        if (bad) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), 0.0f), fhi) + fminf(fmaxf(rintf(x[e] / p.neg_scale), flo), 0.0f) + PACK_MAGIC);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
+                        const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
+                        w[q] = (int)(lo16 | (hi16 << 16));
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1240,12 +1267,20 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
 // the blocks are dealt in row-major order to the 8 waves of `halves` workgroups (<= 12 blocks per wave), and every wave keeps per
 // block: the fixed operand's fragment, raw_out / metric weight (4 + 4 values per lane) and its accumulator.  The expanded operand
 // streams as in k_sweep8 (8-deep ring, one stage = the whole operand of one candidate: 256 rows x 64 B, two 1 KB pieces per wave).
-static constexpr int SW9_NS = 8, SW9_STAGE = 256 * 64, SW9_NB = 12;
+// P4V_SW9_NW waves per workgroup: 8 = one workgroup per CU behind an 8-deep ring; 4 = TWO workgroups per CU (4-deep rings of
+// 64 KB each): the candidate step is a latency chain (barrier, fragment reads, MFMAs, epilogue) and the two waves of a SIMD now
+// belong to different workgroups -- different barriers -- so one's VALU phase runs under the other's waits instead of both
+// waiting and both computing in lock step.
+#ifndef P4V_SW9_NW
+#define P4V_SW9_NW 4
+#endif
+static constexpr int SW9_NW = P4V_SW9_NW, SW9_NS = (SW9_NW == 4 ? 4 : 8), SW9_STAGE = 256 * 64, SW9_NB = 12;
+static constexpr int SW9_PIECES = 16 / SW9_NW;            // 1 KB LDS-DMA pieces (16 rows) per wave and candidate
 
 template <bool ROWS_FIXED, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
+__global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = reinterpret_cast<float*>(smem + SW9_NS * SW9_STAGE);   // [per][8 waves]
+    float* res = reinterpret_cast<float*>(smem + SW9_NS * SW9_STAGE);   // [per][SW9_NW waves]
     typedef int v4i_ __attribute__((ext_vector_type(4)));
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1261,7 +1296,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
     const int CBk = (p.N + 15) / 16, nb = ((p.M + 15) / 16) * CBk;
     const int nbh = (nb + p.halves - 1) / p.halves;
     const int hb0 = half * nbh, hb1 = min(nb, hb0 + nbh);
-    const int nbw = (max(0, hb1 - hb0) + 7) / 8;
+    const int nbw = (max(0, hb1 - hb0) + SW9_NW - 1) / SW9_NW;
     const int b0 = hb0 + wid * nbw;
     const int nblk = __builtin_amdgcn_readfirstlane(max(0, min(hb1, b0 + nbw) - b0));
 
@@ -1298,20 +1333,22 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
         saddr[j] = lds0 + sr * SW_BKB + l4 * 16;
     }
     const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 2 ? z % p.sb_div : 0);
-    float* s1tab = res + per * 8;
-    for (int i = lane; i < ncand; i += 64) s1tab[i * 8 + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
+    float* s1tab = res + per * SW9_NW;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * SW9_NW + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
-    // ---- the expanded operand streams: one candidate per stage, wave `wid` moves rows [32 wid, 32 wid + 32) ---------------------
+    // ---- the expanded operand streams: one candidate per stage, wave `wid` moves rows [256 / SW9_NW * wid, + 256 / SW9_NW) ---------------------
     const long t_cs = ROWS_FIXED ? p.b_cs : p.a_cs;
     const char* cur = ROWS_FIXED ? (const char*)p.B + (long)z * p.b_zs + (long)c_lo * p.b_cs
                                  : (const char*)p.A + (long)z * p.a_zs + (long)c_lo * p.a_cs;
     // (rows beyond the padded plane are clamped: they are never read as fragments)
-    const int r0 = min(wid * 32 + (lane >> 2), p.rows_p_stream - 1), r1 = min(wid * 32 + 16 + (lane >> 2), p.rows_p_stream - 1);
-    const unsigned voff0 = (unsigned)(r0 * SW_BKB + (lane & 3) * 16), voff1 = (unsigned)(r1 * SW_BKB + (lane & 3) * 16);
-    const int lds_wave = wid * 2048;
+    unsigned voff[SW9_PIECES];
+#pragma unroll
+    for (int k = 0; k < SW9_PIECES; ++k)
+        voff[k] = (unsigned)(min(wid * (16 * SW9_PIECES) + 16 * k + (lane >> 2), p.rows_p_stream - 1) * SW_BKB + (lane & 3) * 16);
+    const int lds_wave = wid * (1024 * SW9_PIECES);
     auto issue = [&](int stage) __attribute__((always_inline)) {
-        glds16(cur + voff0, smem + stage * SW9_STAGE + lds_wave);
-        glds16(cur + voff1, smem + stage * SW9_STAGE + lds_wave + 1024);
+#pragma unroll
+        for (int k = 0; k < SW9_PIECES; ++k) glds16(cur + voff[k], smem + stage * SW9_STAGE + lds_wave + k * 1024);
         cur += t_cs;
     };
     const int npre = min(SW9_NS - 1, ncand);
@@ -1325,7 +1362,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
     // epilogue.
     auto step = [&](int it, auto stage_c) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_c)::value;
-        if (it + SW9_NS - 1 <= ncand) wait_vmcnt<12>(); else wait_vmcnt<0>();
+        if (it + SW9_NS - 1 <= ncand) wait_vmcnt<(SW9_NS - 2) * SW9_PIECES>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (it + SW9_NS - 1 < ncand) issue((ST + SW9_NS - 1) % SW9_NS);
         v4i_ sf[SW9_NB];
@@ -1334,7 +1371,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
         constexpr int SO = (ST & 3) * SW9_STAGE;
         float s1;
         {   // the candidate's scale first: LDS returns in order, so it is covered by the first counted wait below
-            const unsigned sa = lds0 + SW9_NS * SW9_STAGE + (per * 8 + (c - c_lo) * 8 + wid) * 4;
+            const unsigned sa = lds0 + SW9_NS * SW9_STAGE + (per * SW9_NW + (c - c_lo) * SW9_NW + wid) * 4;
             asm volatile("ds_read_b32 %0, %1" : "=v"(s1) : "v"(sa));
         }
 #pragma unroll
@@ -1380,7 +1417,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
             block(j);
         }
         const float sum = wave_sum_dpp(sum2.x + sum2.y);           // fixed order: deterministic
-        if (lane == 63) res[(c - c_lo) * 8 + wid] = sum;
+        if (lane == 63) res[(c - c_lo) * SW9_NW + wid] = sum;
         ++c;
     };
     for (int it = 0; it < ncand; it += SW9_NS) {
@@ -1388,15 +1425,17 @@ __global__ __launch_bounds__(512, 2) void k_sweep9(SweepParams p) {
         if (it + 1 < ncand) step(it + 1, std::integral_constant<int, 1>{});
         if (it + 2 < ncand) step(it + 2, std::integral_constant<int, 2>{});
         if (it + 3 < ncand) step(it + 3, std::integral_constant<int, 3>{});
-        if (it + 4 < ncand) step(it + 4, std::integral_constant<int, 4>{});
-        if (it + 5 < ncand) step(it + 5, std::integral_constant<int, 5>{});
-        if (it + 6 < ncand) step(it + 6, std::integral_constant<int, 6>{});
-        if (it + 7 < ncand) step(it + 7, std::integral_constant<int, 7>{});
+        if constexpr (SW9_NS == 8) {
+            if (it + 4 < ncand) step(it + 4, std::integral_constant<int, 4>{});
+            if (it + 5 < ncand) step(it + 5, std::integral_constant<int, 5>{});
+            if (it + 6 < ncand) step(it + 6, std::integral_constant<int, 6>{});
+            if (it + 7 < ncand) step(it + 7, std::integral_constant<int, 7>{});
+        }
     }
 #undef P4V_DSR
     __syncthreads();
-    for (int i = tid; i < ncand * 8; i += 512)
-        p.part[(long)(c_lo + i / 8) * p.p_cs + (long)z * p.p_zs + half * 8 + (i % 8)] = res[i];
+    for (int i = tid; i < ncand * SW9_NW; i += SW9_NW * 64)
+        p.part[(long)(c_lo + i / SW9_NW) * p.p_cs + (long)z * p.p_zs + half * SW9_NW + (i % SW9_NW)] = res[i];
 }
 
 // ------------------------------------------------------------------------------------------
