@@ -162,6 +162,13 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
     if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack (%ld 16-element runs)", total);
     const int blocks = (int)std::min<long>(cdiv(total, 256), 256L * 64);
+    if (p.mode == PACK_TWIN_I8) {
+        if (sizeof(T) != 1 || p.C != 1 || p.c_inner != 0 || !p.scales || p.conv || p.zdiv > 0)
+            return fail(P4V_ERR_UNSUPPORTED, "merged twin plane: one fixed row-major int8 plane only");
+        hipLaunchKernelGGL(k_pack_twin, dim3(blocks), dim3(256), 0, c.st, p);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_pack<T>, dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;

@@ -161,8 +161,6 @@ __device__ __forceinline__ float pack_value(const PackParams& p, float x, float 
             const float a_int = s / p.qm1;
             return fminf(fmaxf(rintf(fminf(fmaxf(x, 0.0f), s) / a_int), 0.0f), p.qm1);
         }
-        case PACK_TWIN_I8:
-            return fminf(fmaxf(rintf(x / s), 0.0f), (float)p.hi) + fminf(fmaxf(rintf(x / p.neg_scale), (float)p.lo), 0.0f);
         default: return x;
     }
 }
@@ -308,33 +306,6 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                         const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
                         w[q] = (int)(lo16 | (hi16 << 16));   // (an OR of two perms with selector 0x04000c0c is mis-folded by the backend)
                     }
-                } else if (p.mode == PACK_TWIN_I8 && live && kc * 16 + 16 <= p.K) {
-                    // merged post-GELU twin: both ranges through the reciprocal path, same exactness check; the supports are
-                    // disjoint (one of the two indices is 0), so the merged byte is the sum of the two low bytes
-                    const float rcp = 1.0f / s, rcn = 1.0f / p.neg_scale, flo = (float)p.lo, fhi = (float)p.hi;
-                    unsigned qb[16];
-                    float maxdev = 0.0f;
-                    float magic = PACK_MAGIC;
-                    asm volatile("" : "+v"(magic));
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        qb[e] = quant_fast1(x[e], rcp, -0.49f, fhi + 0.49f, magic, maxdev) + quant_fast1(x[e], rcn, flo - 0.49f, 0.49f, magic, maxdev);
-                    const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || !(rcn < 3.0e38f) || !(fmaxf(-flo, fhi) < 129.0f);
-                    if (__any(bad)) {
-                        float sd = s;
-                        asm volatile("" : "+v"(sd));
-                        if (bad) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e)
-                                qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), 0.0f), fhi) + fminf(fmaxf(rintf(x[e] / p.neg_scale), flo), 0.0f) + PACK_MAGIC);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
-                        const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
-                        w[q] = (int)(lo16 | (hi16 << 16));
-                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -365,6 +336,38 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                 }
             }
         }
+    }
+}
+
+// PACK_TWIN_I8: both grid indices of the post-GELU twin (linear.py:605-606) in ONE int8 plane, row-major [Z][Rp][Kp], zero
+// padded.  A kernel of its own: the plane is small and fixed (one per weight-search pass) and k_pack's hot path is register
+// sensitive (the extra branch there cost it an occupancy step: 112 -> 155 VGPRs).  IEEE divisions, as the reference divides;
+// the supports are disjoint (x > 0 clamps the negative range to 0, x < 0 the positive one), so the sum is the index that is
+// not zero and fits the int8 range.
+__global__ __launch_bounds__(256) void k_pack_twin(PackParams p) {
+    const unsigned kchunks = p.Kp / 16;
+    const unsigned total = (unsigned)p.Z * p.Rp * kchunks;
+    const float s = p.scales[0], sn = p.neg_scale, flo = (float)p.lo, fhi = (float)p.hi;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = i / kchunks;
+        const int kc = (int)(i - row * kchunks);
+        const int z = (int)(row / (unsigned)p.Rp);
+        const int r = (int)(row - (unsigned)z * p.Rp);
+        const float* zbase = p.src + (long)z * p.s_z;
+        int w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int acc = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kc * 16 + q * 4 + e;
+                const float x = pack_load(p, zbase, r, k);           // 0 outside the valid rows / columns
+                const float v = fminf(fmaxf(rintf(x / s), 0.0f), fhi) + fminf(fmaxf(rintf(x / sn), flo), 0.0f);
+                acc |= ((int)v & 0xff) << (8 * e);
+            }
+            w[q] = acc;
+        }
+        *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + (((long)z * p.Rp + r) * p.Kp + (long)kc * 16)) = v4i{w[0], w[1], w[2], w[3]};
     }
 }
 

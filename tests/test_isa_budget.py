@@ -46,3 +46,11 @@ def test_streaming_sweeps_keep_two_waves_per_simd(resources):
     for k, v in resources.items():
         if "k_sweep2<" in k or "k_sweep2g<" in k or "k_sweep<" in k or "k_sweep7<" in k:
             assert v["NumVgprs"] + v["NumAgprs"] <= 256 and v["Occupancy"] >= 2, (k, v)
+
+
+def test_pack_kernel_keeps_four_waves_per_simd(resources):
+    """k_pack<int8> writes 85 GB of candidate-expanded planes per ViT-B calibration, half VALU- half write-bound: it lives on
+    its occupancy.  (Round 3: one more mode branch inside it took it from 112 to 155 VGPRs -- 4 -> 3 waves per SIMD -- and the
+    whole calibration from 333 to 345 ms; the merged twin plane has its own kernel since.)"""
+    k = [v for n, v in resources.items() if "k_pack<signed char>" in n]
+    assert len(k) == 1 and k[0]["NumVgprs"] <= 128 and k[0]["Occupancy"] >= 4, k
