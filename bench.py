@@ -183,7 +183,7 @@ def _cpu_layer_types_torch(imgs, dim=768, heads=12, tokens=197, mlp=4, patch=16,
             x = torch.nn.functional.gelu(x)
         out = torch.nn.functional.linear(x, w, b)
         grad = rn(*out.shape) * 1e-3
-        o = TorchLinear(w, b, w_bit=8, a_bit=8, n_V=n_V, postgelu=gelu, chunk=16, **hp)
+        o = TorchLinear(w, b, w_bit=8, a_bit=8, n_V=n_V, postgelu=gelu, chunk=10 if N >= 2048 else 4, **hp)
         return (lambda: o.calibration_step2(x, out, grad)), 2.0 * 100 * x.numel() * N
 
     def matmul(sos):
@@ -194,7 +194,7 @@ def _cpu_layer_types_torch(imgs, dim=768, heads=12, tokens=197, mlp=4, patch=16,
             A, B = rn(imgs, heads, tokens, D) * D ** -0.5, rn(imgs, heads, D, tokens)
         out = A @ B
         grad = rn(*out.shape) * 1e-3
-        o = TorchMatMul(A_bit=8, B_bit=8, sos=sos, chunk=4, **hp)
+        o = TorchMatMul(A_bit=8, B_bit=8, sos=sos, chunk=2, **hp)
         per = imgs * heads * A.shape[2] * A.shape[3] * B.shape[3]
         return (lambda: o.calibration_step2(A, B, out, grad)), ((20 + 100) if sos else 200) * per
 
@@ -483,7 +483,10 @@ def main():
         cpu_model, threads, logical = _cpu_info()
         backend = "numpy" if args.cpu_numpy else "torch"
         if backend == "torch":
-            threads = torch.get_num_threads()
+            # thread count from tools/cpu_port_threads.py on the GPU box (2 x EPYC 9575F, 256 logical CPUs): at the sample's
+            # sizes (788 rows) 16-32 threads are the optimum; torch's default of 128 is 3-10 x slower (thread start-up per op)
+            threads = min(32, os.cpu_count() or 1)
+            torch.set_num_threads(threads)
         est_s, per_type, spent = cpu_baseline(calib=args.calib, backend=backend)
         what = ("oracle/torch_port.py (torch-CPU restatement of the reference's calibration_step2 on all host threads, validated "
                 "against the reference's golden files)" if backend == "torch" else
