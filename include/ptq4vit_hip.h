@@ -14,6 +14,10 @@
  *     read the interval selected by each search pass back to the host (pass memoisation: a pass whose input
  *     interval was already evaluated is skipped) and therefore synchronise `stream` after every pass; setting
  *     desc.reserved bit 1 (or requesting score tables) disables that and makes the call fully asynchronous.
+ *     Exact candidate pruning (difference metrics; on by default, off when score tables are requested or with
+ *     desc.reserved bit 3): candidates that provably cannot be the argmax -- their score on a slice of the samples is
+ *     already below the complete score of another candidate -- are not swept over the remaining samples; the selected
+ *     intervals are bit-identical with and without it.
  *     *_quant_forward, p4v_quantize_i8 and p4v_fake_quant never synchronise;
  *   - return value 0 = ok, <0 = error; p4v_last_error() returns a per-thread message;
  *   - safe to call concurrently on different devices / streams: the only state outside the call is per calling
@@ -76,7 +80,8 @@ typedef struct p4v_linear_desc {
     int32_t init_layerwise;
     int32_t has_bias;
     int32_t reserved;     /* bit 0: force the generic fp32-operand path; bit 1: disable pass memoisation;
-                             bit 2: p4v_linear_workspace_bytes sizes the workspace for p4v_linear_quant_forward only */
+                             bit 2: p4v_linear_workspace_bytes sizes the workspace for p4v_linear_quant_forward only;
+                             bit 3: disable exact candidate pruning (every candidate is swept over every sample) */
 } p4v_linear_desc;
 
 size_t p4v_linear_workspace_bytes(const p4v_linear_desc* desc);
@@ -110,7 +115,8 @@ typedef struct p4v_matmul_desc {
     int32_t search_round;
     int32_t sos;
     int32_t init_layerwise;
-    int32_t reserved;           /* bit 1: disable pass memoisation; bit 2: workspace query for quant_forward only */
+    int32_t reserved;           /* bit 1: disable pass memoisation; bit 2: workspace query for quant_forward only;
+                                   bit 3: disable exact candidate pruning */
 } p4v_matmul_desc;
 
 size_t p4v_matmul_workspace_bytes(const p4v_matmul_desc* desc);

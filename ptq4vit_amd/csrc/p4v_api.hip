@@ -80,6 +80,7 @@ struct Arena {
 // on other threads / streams / devices are unaffected.
 struct StatRec { hipEvent_t a, b; int kind; double macs, alg; };
 thread_local double g_alg_macs_cand = 0;   // unpadded single-plane MACs of one candidate of the pass being launched
+thread_local double g_exec_frac = 1.0;     // share of a launch's candidates that a pruned pass executes (stats mode only)
 thread_local bool g_stat_on = false;
 thread_local std::vector<StatRec> g_stat_recs;
 thread_local p4v_kernel_stats g_stats = {};
@@ -161,7 +162,8 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
     if (c.dry) return 0;
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
     if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack (%ld 16-element runs)", total);
-    const int blocks = (int)std::min<long>(cdiv(total, 256), 256L * 64);
+    // (a pruned launch lets most candidate groups exit at once: fewer, longer-running workgroups)
+    const int blocks = (int)std::min<long>(cdiv(total, 256), p.crange ? 256L * 12 : 256L * 64);
     if (p.mode == PACK_TWIN_I8) {
         if (sizeof(T) != 1 || p.C != 1 || p.c_inner != 0 || !p.scales || p.conv || p.zdiv > 0)
             return fail(P4V_ERR_UNSUPPORTED, "merged twin plane: one fixed row-major int8 plane only");
@@ -313,7 +315,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -416,7 +418,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -545,7 +547,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     CHK(twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds) : launch_sweep7_epi<0>(c, q, epi, grid, lds));
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -572,7 +574,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
     }
     return r;
 }
@@ -611,6 +613,7 @@ int launch_select(Ctx& c, const SelectParams& p) {
 struct PlaneCache {
     char* buf = nullptr;
     bool assigned = false, valid = false;
+    unsigned char* done = nullptr;    // pruned passes: device flags, one per pack group of PACK_CG candidates already in `buf`
 };
 // The same for the epilogue operands of k_sweep6 in fragment order (k_prep_epi6): raw_out, raw_grad and the bias are fixed
 // for the whole call, so the tile image of one search orientation is built by its first pass and read by the later rounds.
@@ -649,6 +652,11 @@ struct Pass {
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
     bool twin_disjoint;       // twin whose two ranges never overlap (post-GELU): k_sweep7 may stream them as one merged plane
+    // exact candidate pruning (run_pass_pruned): device-side candidate range, scores kept for the next stage, no selection
+    const int* crange;
+    float* scores_keep;
+    bool no_select;
+    bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
     EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
 };
@@ -715,9 +723,12 @@ int run_pass(Ctx& c, Pass& ps) {
     PlaneCache* pc = (ps.cache && chunk >= ps.eq_n && !ps.store_out && ps.row.expanded != ps.col.expanded &&
                       !(ps.twin && ps.row2.expanded) && exp_plane * (long)ps.eq_n <= PLANE_CACHE_MAX &&
                       !(g_variant & 1024)) ? ps.cache : nullptr;
+    const int pack_groups = cdiv(ps.eq_n, PACK_CG);
     if (pc && !pc->assigned) {
         pc->buf = c.ws.get_top((size_t)exp_plane * chunk_al + slack);
+        pc->done = reinterpret_cast<unsigned char*>(c.ws.get_top((size_t)rup(pack_groups, 256)));
         pc->assigned = true; pc->valid = false;
+        if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 0, (size_t)pack_groups, c.st));
     }
     char* rowbuf = (pc && ps.row.expanded) ? pc->buf : c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
@@ -739,7 +750,7 @@ int run_pass(Ctx& c, Pass& ps) {
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
     float* S2 = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
-    float* scores = c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
+    float* scores = ps.scores_keep ? ps.scores_keep : c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
     float* zero_bias = (stat_ok && !ps.bias) ? c.ws.get<float>((size_t)std::max(Mp, Np)) : nullptr;
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
     // k_sweep6: epilogue operands in fragment order, one image per 256 x 64 tile (8 bytes per output element)
@@ -790,7 +801,16 @@ int run_pass(Ctx& c, Pass& ps) {
         pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
         if (regs6 && !op.expanded) pk.c_inner = 3;                     // k_sweep6: stationary operand in MFMA-fragment order
         if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
-        return ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk);
+        if (op.expanded && ps.crange) {       // pruned pass: only the candidate groups in range, and not the ones already kept
+            pk.crange = ps.crange; pk.c_base = c0;
+            pk.done = (pc && pc->done) ? pc->done : nullptr;
+        }
+        CHK(ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk));
+        if (op.expanded && ps.crange && pc && pc->done && !c.dry) {
+            hipLaunchKernelGGL(k_mark_done, dim3(cdiv(pack_groups, 64)), dim3(64), 0, c.st, pc->done, pack_groups, ps.crange, c0);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
     };
     // fixed planes once
     if (merged7) {
@@ -811,7 +831,17 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.row.expanded && !packed) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
-        if (pc) pc->valid = true;
+        if (pc && !ps.crange) {          // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
+            pc->valid = true;
+            if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)pack_groups, c.st));
+        }
+        if (g_stat_on && ps.crange && !c.dry) {     // roofline step only: how many of this launch's candidates run
+            int h[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h, ps.crange, sizeof h, hipMemcpyDeviceToHost, c.st));
+            HIPCHK(hipStreamSynchronize(c.st));
+            const int lo = std::max(h[0], c0), hi = std::min(h[1], c0 + nc);
+            g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
+        } else g_exec_frac = 1.0;
         if (stat_ok) {
             Sweep3Params q{};
             q.S = a_search ? colbuf : rowbuf; q.s_zs = 0;
@@ -823,7 +853,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.O = ps.O; q.Wt = ps.G ? ps.G : ps.O; q.wt_mode = ps.wt_mode;
             q.o_ss = a_search ? ps.o_ns : ps.o_ms; q.o_ts = a_search ? ps.o_ms : ps.o_ns;
             q.SR = a_search ? ps.Ncols : ps.Mrows; q.TR = a_search ? ps.Mrows : ps.Ncols;
-            q.c0 = c0; q.c1 = c0 + nc;
+            q.c0 = c0; q.c1 = c0 + nc; q.crange = ps.crange;
             q.part = part; q.p_cs = p_cs; q.NG = s3_groups;
             q.stiles = (a_search ? Np : Mp) / 128; q.ttiles = (a_search ? Mp : Np) / 128;
             q.dbg = g_variant & 3;
@@ -851,7 +881,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.ldk = Kp; q.ktiles = Kp / SW_BKB;
             q.S1 = S1; q.S2 = S2; q.s_cs = ps.s_cs; q.sb_div = ps.s_cs > 1 ? std::max(1, ps.sb_div) : (1 << 30);
             q.E = epi7;
-            q.c0 = c0; q.c1 = c0 + nc;
+            q.c0 = c0; q.c1 = c0 + nc; q.crange = ps.crange;
             q.part = part; q.p_cs = p_cs; q.NG = NpP;
             q.rtiles = Np / 256; q.ctiles = Mp / (ps.twin ? 128 : 256);
             // one workgroup per CU; per k-tile ~0.62 us (16 MFMAs per wave, two waves per SIMD), ~3 k-tiles' worth of
@@ -883,7 +913,7 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.o_zs = ps.o_zs; sp.o_bs = ps.o_bs; sp.o_ms = ps.o_ms; sp.o_nbs = ps.o_nbs; sp.o_ns = ps.o_ns;
         sp.o_inner = ps.o_inner > 0 ? ps.o_inner : INT_MAX;
         sp.o_ninner = ps.o_ninner > 0 ? ps.o_ninner : INT_MAX;
-        sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc;
+        sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc; sp.crange = ps.crange;
         sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = NpP;
         sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
         sp.dbg = g_variant & 3;
@@ -916,10 +946,11 @@ int run_pass(Ctx& c, Pass& ps) {
         }
         CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
     }
+    g_exec_frac = 1.0;
     if (ps.store_out) { c.ws.off = mark; return 0; }
     if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
         const int slots = nine_halves * SW9_NW;
-        FinishParams fp{part, (long)slots * ps.Z, (long)slots, slots, 1, ps.Z, slots, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores};
+        FinishParams fp{part, (long)slots * ps.Z, (long)slots, slots, 1, ps.Z, slots, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores, ps.crange};
         CHK(launch_finish(c, fp));
     } else if (!cosm) {
         const int gdiv = stat_ok ? s3_gw : 32;
@@ -928,7 +959,7 @@ int run_pass(Ctx& c, Pass& ps) {
         const int fin_cols = stat_ok ? (a_search ? (regs6 ? 2 * cdiv(ps.Mrows, 64) : s3_groups) : cdiv(ps.Ncols, s3_gw))
                                      : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
         FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : big7 ? MT7 : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
-                        std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores};
+                        std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores, ps.crange};
         CHK(launch_finish(c, fp));
     } else {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
@@ -936,10 +967,61 @@ int run_pass(Ctx& c, Pass& ps) {
                            ps.cos_j_mode, std::max(1, ps.cos_j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish_cos(c, fp));
     }
-    SelectParams sl{scores, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, ps.interval, ps.out_js,
-                    ps.out_off, ps.aux_out, ps.aux_div, ps.scores_out, ps.scores_out_ld, ps.best_out};
-    CHK(launch_select(c, sl));
+    if (!ps.no_select) {
+        SelectParams sl{scores, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, ps.interval, ps.out_js,
+                        ps.out_off, ps.aux_out, ps.aux_div, ps.scores_out, ps.scores_out_ld, ps.best_out};
+        CHK(launch_select(c, sl));
+    }
     c.ws.off = mark;   // scratch of this pass is reusable by the next one (same stream => ordered)
+    return 0;
+}
+
+// ---- exact candidate pruning ------------------------------------------------------------------------------------------------
+// (the argument is with the prune kernels, p4v_kernels.h)  A pass becomes: stage A = all candidates on the first ~1/8 of the
+// samples (its own small problem, scores only); B1 = the stage-A winners on all samples (the bound); B2 = the surviving range on
+// all samples with the unpruned kernels, tiles, finish and selection -- bit-identical totals for the survivors, hence the same
+// selection (tests: every parity case runs with and without it, desc.reserved bit 8 / variant 4194304 switch it off).  Everything
+// between the stages stays on the device.  Not used when the caller wants the full score tables, for the cosine metric (its
+// terms are not one-signed), for fp32 operands, or where the sample slice would not be small against the whole.
+bool prune_ok(const Pass& ps) {
+    if (!ps.prunable || !ps.i8 || ps.epi == EPI_COS || ps.store_out || ps.scores_out || ps.best_out || ps.crange || ps.no_select) return false;
+    if ((g_variant & 4194304) || ps.eq_n < 32 || ps.nj < 1 || ps.nj > 4096) return false;
+    return true;
+}
+int run_pass_pruned(Ctx& c, Pass& ps) {
+    if (!prune_ok(ps)) return run_pass(c, ps);
+    // the slice: whole 256-row tiles of a Linear's samples, whole images of a matmul's batch
+    Pass a = ps;
+    if (ps.Z == 1) {
+        const int m = (int)rup(std::max(1, ps.Mrows / 8), 256);
+        if (m * 5 > ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth three stages
+        a.Mrows = m; a.row.pk.R = m; if (ps.twin) a.row2.pk.R = m;
+    } else {
+        const int H = std::max(1, ps.j_mode == 2 ? ps.j_div : 1), imgs = ps.Z / H;
+        const int z = std::max(1, imgs / 8) * H;
+        if (ps.Z % H || z * 5 > ps.Z * 2 || ps.row_zs_shared || ps.col_zs_shared) return run_pass(c, ps);
+        a.Z = z; a.row.pk.Z = z; a.col.pk.Z = z; if (ps.twin) a.row2.pk.Z = z;
+    }
+    const size_t mark = c.ws.off;
+    const size_t tab = (size_t)ps.eq_n * std::max(1, ps.nj);
+    float* SA = c.ws.get<float>(tab);
+    float* SB = c.ws.get<float>(tab);
+    int* r1 = c.ws.get<int>(4);
+    int* r2 = r1 + 2;
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    a.cache = nullptr; a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
+    CHK(run_pass(c, a));
+    PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1};
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    Pass b1 = ps;
+    b1.crange = r1; b1.scores_keep = SB; b1.no_select = true;
+    CHK(run_pass(c, b1));
+    pp.r_out = r2;
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    Pass b2 = ps;
+    b2.crange = r2;
+    CHK(run_pass(c, b2));
+    c.ws.off = mark;
     return 0;
 }
 
@@ -1001,7 +1083,7 @@ int run_sos_split(Ctx& c, SosSplitJob& j) {
         else CHK(launch_sos_split_ks<100>(c, kp, j.epi));
         if (timed) {
             HIPCHK(hipEventRecord(rec.b, c.st));
-            g_stat_recs.push_back(rec);
+            rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
         }
     }
     FinishParams fp{part, (long)kp.Z * slots, (long)slots, slots, 1, kp.Z, slots, kp.C, 0, 1, 1, j.norm, scores};
@@ -1224,6 +1306,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.O = O; ps.G = G; ps.o_zs = 0; ps.o_bs = 0; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
                 ps.j_mode = 1; ps.j_div = crb_rows;
                 ps.norm = 1.0 / ((double)d->tokens * crb_rows);
+                ps.prunable = !(d->reserved & 8);
             } else {
                 // swapped: rows = features of V block z, cols = samples
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -1237,7 +1320,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 1;
                 ps.norm = 1.0 / (double)d->tokens;
             }
-            CHK(run_pass(c, ps));
+            CHK(run_pass_pruned(c, ps));
         }
         if (memo_w_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
         // ================= activation search (linear.py:497-533 / 609-642) =================
@@ -1279,6 +1362,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.O = O; ps.G = G; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
                 ps.j_mode = 0;
                 ps.norm = 1.0 / ((double)d->tokens * N);
+                ps.prunable = !(d->reserved & 8);
                 if (twin && wt_mode <= 1 && !(g_variant & 64)) {
                     // Twin activation search: the negative-range plane and the weights are candidate-invariant, so
                     // their product is folded into the target once (U = raw_out - bias - s_neg*s_w*(x_neg . W_q))
@@ -1308,7 +1392,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 0;
                 ps.norm = 1.0 / (double)d->tokens;
             }
-            CHK(run_pass(c, ps));
+            CHK(run_pass_pruned(c, ps));
         }
         if (memo_a_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
     }
@@ -1454,7 +1538,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.cands = A_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = A_iv; ps.out_js = 1;
             ps.cache = keep_planes ? &plane_A : nullptr;
             ps.scores_out = so; ps.scores_out_ld = H; ps.best_out = bo;
-            CHK(run_pass(c, ps));
+            ps.prunable = !cosm && !(d->reserved & 8);
+            CHK(run_pass_pruned(c, ps));
         } else if (sos_split_ok(M, K, N, cosm)) {
             // ---- split search against the UNQUANTISED B (matmul.py:600-631): A quantised in registers, one kernel ----
             SosSplitJob j{};
@@ -1521,7 +1606,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.cache = keep_planes ? &plane_B : nullptr;
             ps.scores_out = so_B; ps.scores_out_ld = H;
             ps.best_out = bo_B;
-            CHK(run_pass(c, ps));
+            ps.prunable = !cosm && ps.i8 && !(d->reserved & 8);
+            CHK(run_pass_pruned(c, ps));
             if (memo_on) { CHK(read_dev(c, B_iv, H, val)); memo_B.entries.push_back({key, val}); g_memo_misses++; }
         }
     }

@@ -149,6 +149,9 @@ struct PackParams {
     int mode, lo, hi;
     float qm1;            // q-1 for SOS modes
     float neg_scale;      // twin: fixed negative-range interval
+    // pruned passes: only the candidate groups (PACK_CG candidates each) that intersect [crange[0], crange[1]) - c_base are
+    // packed, and of those only the ones whose `done` flag is still 0 (planes kept across the rounds of a call)
+    const int* crange; int c_base; const unsigned char* done;
     // optional im2col gather (conv): logical r = (b, oy, ox), k = (ci, ki, kj)
     int conv, ic, H, W, kh, kw, sh, sw, ph, pw, dh, dw, fw, L;
 };
@@ -234,6 +237,11 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
     const unsigned kchunks = p.Kp / 16;
     const unsigned total = (unsigned)p.Z * p.Rp * kchunks;      // < 2^31: checked by the launcher
     const int cbeg = blockIdx.y * PACK_CG, cend = min(p.C, cbeg + PACK_CG);
+    if (p.crange) {
+        const int a = p.crange[0] - p.c_base, b = p.crange[1] - p.c_base;
+        if (cend <= a || cbeg >= b) return;
+    }
+    if (p.done && p.done[blockIdx.y]) return;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const unsigned row = i / kchunks;
         const int kc = (int)(i - row * kchunks);
@@ -467,7 +475,19 @@ enum EpiMode {
     ,EPI_FWD = 6   // quant_forward: store scale*acc (+ scale2*acc2) + bias -- the quantised layer's output
 };
 
+// Device-side candidate range of a pruned pass (exact branch-and-bound, p4v_api.hip::run_pass_pruned): when `crange` is set
+// a workgroup only evaluates the candidates of its group that lie in [crange[0], crange[1]); the others are provably not the
+// argmax and k_finish gives them the score -inf.  The range lives in device memory: it is computed by the prune kernels from
+// the scores of earlier stages of the same pass, stream-ordered, without a host round trip.
+__device__ __forceinline__ void clip_crange(const int* crange, int& lo, int& hi, bool even = false) {
+    if (!crange) return;
+    int a = __builtin_amdgcn_readfirstlane(crange[0]), b = __builtin_amdgcn_readfirstlane(crange[1]);
+    if (even) { a &= ~1; b = (b + 1) & ~1; }           // kernels that run candidate pairs: a superset on pair boundaries
+    lo = max(lo, a); hi = min(hi, b);
+}
+
 struct SweepParams {
+    const int* crange;                 // optional device-side candidate range (see clip_crange)
     const void* A;  long a_cs, a_zs;   // byte strides between candidates / batch entries (0 = shared)
     const void* A2; long a2_cs, a2_zs; // twin second plane (post-GELU negative range / SoS low range)
     const void* B;  long b_cs, b_zs;
@@ -528,7 +548,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
     // candidate groups over gridDim.z (host: choose_cgroups) -- a sweep with few tiles fills the chip this way
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
     // ---- candidate-invariant epilogue operands, kept in registers for the whole sweep -------------
@@ -802,7 +824,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int z = blockIdx.y;
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
     // Which 64 x 32 part of the tile this wave computes.  Parts that hold only padding (attn.v: N = 64 of a 128-column tile;
@@ -1067,7 +1091,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     const int z = blockIdx.y;
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
@@ -1291,7 +1317,9 @@ __global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
     const int l15 = lane & 15, l4 = lane >> 4;
     const int half = blockIdx.x, z = blockIdx.y;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
@@ -1475,7 +1503,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
     const int z = blockIdx.y;
     const int m0 = mt * SW_BM, n0 = nt * SW_BN;
     const int per = 2 * ((p.c1 - p.c0 + 2 * gridDim.z - 1) / (2 * gridDim.z));   // even: groups start on a pair
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_, true);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo, npairs = (ncand + 1) >> 1;
 
@@ -1661,6 +1691,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
 // The MFMA rows are the stationary rows: in the activation search the output tile is therefore transposed
 // (rows = output features, columns = samples); the raw_out / raw_grad tile is gathered through strides.
 struct Sweep3Params {
+    const int* crange;                  // optional device-side candidate range (clip_crange)
     const void* S; long s_zs;           // stationary plane [rows_p][ldk] (never candidate-expanded)
     const void* T; long t_cs, t_zs;     // streaming plane  [rows_p][C][ldk]: t_rs = bytes between rows (= C_chunk * ldk)
     long t_rs;
@@ -1717,7 +1748,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
     const int s0 = st * 128, t0 = tt * 128;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
     // ---- stationary operand: all k-tiles of this workgroup's 128 rows, once ------------------------------
@@ -1898,7 +1931,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
     const int s0 = st * 128, t0 = tt * 128;
     const int per = 2 * ((p.c1 - p.c0 + 2 * gridDim.z - 1) / (2 * gridDim.z));   // even: groups start on a pair
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_, true);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
     const int ld_row = wid * 16 + (lane >> 2);
@@ -2163,7 +2198,9 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
     const int s0 = st * 256 + wid * (32 * RB), t0 = tt * 64;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    const int c_lo = p.c0 + blockIdx.z * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
@@ -2483,6 +2520,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
 // Workgroup order: feature tile fastest, then sample tile, candidate group slowest -- the workgroups that share a tile
 // of the candidate-expanded operand are neighbours on one XCD and pull it through that L2 once.
 struct Sweep7Params {
+    const int* crange;                  // optional device-side candidate range (clip_crange)
     const void* R;  long r_cs;          // feature-side plane(s) [C or 1][Np][ldk] (weights): rows -> MFMA rows
     const void* Cp; long c_cs;          // sample-side plane(s)  [C or 1][Mp][ldk] (activations): rows -> MFMA columns
     const void* C2;                     // twin: second sample-side plane (never candidate-expanded)
@@ -2585,7 +2623,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
     constexpr int CM = TWIN ? 128 : 256;                 // samples per workgroup tile
     const int r0 = rt * 256, m0 = ct * CM;
     const int per = (p.c1 - p.c0 + p.cgroups - 1) / p.cgroups;
-    const int c_lo = p.c0 + cg * per, c_hi = min(p.c1, c_lo + per);
+    int c_lo_ = p.c0 + cg * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
 
@@ -3049,12 +3089,17 @@ struct FinishParams {
     int nj;
     double norm;           // score = -norm * sum
     float* scores;         // [C][nj]
+    const int* crange;     // optional: candidates outside [crange[0], crange[1]) were not evaluated -> score -inf
 };
 
 // One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
 // fixed-shape tree: the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void k_finish(FinishParams p) {
     const int c = blockIdx.x, j = blockIdx.y;
+    if (p.crange && (c < p.crange[0] || c >= p.crange[1])) {
+        if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = -__builtin_inff();
+        return;
+    }
     int nlo = 0, nhi = p.N, zstep = 1, zlo = 0;
     if (p.j_mode == 1) { nlo = j * p.j_div; nhi = min(p.N, nlo + p.j_div); if (j == p.nj - 1) nhi = p.N; }
     else if (p.j_mode == 3) { nlo = j; nhi = j + 1; }
@@ -3134,6 +3179,63 @@ __global__ __launch_bounds__(256) void k_finish_cos(FinishCosParams p) {
 
 // argmax over candidates per block (torch.argmax semantics: first maximum, NaN is the maximum) and
 // gather of the winning candidate interval (linear.py:493-494).
+// ---- exact candidate pruning (branch and bound on the score's non-negative terms) -------------------------------------------
+// Every difference metric scores a candidate with MINUS a sum of non-negative terms over the samples, so a partial sum over a
+// subset of the samples is an upper bound of the candidate's final score.  Stage A scores all candidates on a slice of the
+// samples (SA); stage B1 scores, on ALL samples, the candidates that won stage A (one per score block: the range r1) -- the best
+// of those totals, L*_j, is a lower bound of the final maximum; a candidate whose stage-A score is already below L*_j (by a
+// relative margin that covers the rounding of the two sums) cannot be the argmax of block j.  k_prune_hull writes the hull of
+// the survivors over all blocks; stage B2 evaluates exactly that range with the unpruned kernels on the unpruned tiles, so the
+// totals of the survivors -- and the selection -- are bit-identical to the unpruned pass.  NaN anywhere disables the pruning
+// (torch.argmax treats NaN as the maximum, linear.py:493).
+struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out; };
+__global__ void k_prune_pick(PruneParams p) {          // r_out = hull over the blocks of stage A's first maxima (NaN = maximum)
+    __shared__ int lo, hi;
+    if (threadIdx.x == 0) { lo = p.C; hi = 0; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < p.nj; j += blockDim.x) {
+        int best = 0;
+        float bv = p.SA[j];
+        bool bnan = bv != bv;
+        for (int c = 1; c < p.C; ++c) {
+            const float v = p.SA[(long)c * p.nj + j];
+            if (!bnan && (v != v || v > bv)) { best = c; bv = v; bnan = v != v; }
+        }
+        atomicMin(&lo, best); atomicMax(&hi, best + 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
+}
+__global__ void k_prune_hull(PruneParams p) {
+    __shared__ int lo, hi, bad;
+    const int a = p.r_in[0], b = p.r_in[1];
+    if (threadIdx.x == 0) { lo = a; hi = b; bad = 0; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < p.nj; j += blockDim.x) {
+        float L = -__builtin_inff();
+        bool nan = false;
+        for (int c = a; c < b; ++c) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+        const float thr = L - p.margin * fabsf(L);
+        int l = p.C, h = 0;
+        for (int c = 0; c < p.C; ++c) {
+            const float v = p.SA[(long)c * p.nj + j];
+            nan |= v != v;
+            if (!(v < thr)) { l = min(l, c); h = max(h, c + 1); }
+        }
+        if (nan || !(L > -__builtin_inff())) atomicOr(&bad, 1);
+        atomicMin(&lo, l); atomicMax(&hi, h);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { p.r_out[0] = bad ? 0 : lo; p.r_out[1] = bad ? p.C : hi; }
+}
+// pack groups [g * PACK_CG, +PACK_CG) that intersect the range are packed now
+__global__ void k_mark_done(unsigned char* done, int ngroups, const int* crange, int c_base) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const int a = crange[0] - c_base, b = crange[1] - c_base;
+    if (g * PACK_CG < b && (g + 1) * PACK_CG > a) done[g] = 1;
+}
+
 struct SelectParams {
     const float* scores; int C, nj;
     const float* cands; int cand_cs, cand_js, cand_off;  // cands[best*cand_cs + j*cand_js + cand_off]

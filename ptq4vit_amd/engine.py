@@ -88,7 +88,8 @@ def metric_id(name):
 
 
 def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
-                     n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False, memoize=True):
+                     n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False, memoize=True,
+                     prune=True):
     """Run calibration_step2 of a (post-GELU) Linear on the GPU.  Returns (w_interval[n_V*n_H], a_interval[n_a], scores, best)."""
     lib = _lib.load()
     dev = device_of(x, weight)
@@ -100,7 +101,8 @@ def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alp
     tokens = x.numel() // (batch * K)
     N = weight.shape[0]
     d = _lib.LinearDesc(batch, tokens, K, N, n_V, n_H, n_a, w_bit, a_bit, metric_id(metric), eq_n, search_round,
-                        int(postgelu), int(init_layerwise), int(bias is not None), int(force_f32) | (0 if memoize else 2))
+                        int(postgelu), int(init_layerwise), int(bias is not None),
+                        int(force_f32) | (0 if memoize else 2) | (0 if prune else 8))
     need = lib.p4v_linear_workspace_bytes(C.byref(d))
     if need == 0:
         _lib.check(-1 if not lib.p4v_last_error() else -2, "p4v_linear_workspace_bytes")
@@ -172,7 +174,7 @@ def matmul_quant_forward(*, A, B, A_interval, B_interval, split, A_bit, B_bit, s
 
 
 def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
-                     sos=False, init_layerwise=False, want_scores=False):
+                     sos=False, init_layerwise=False, want_scores=False, prune=True):
     """Run calibration_step2 of a MatMul (head-wise; optional split-of-softmax on A) on the GPU."""
     lib = _lib.load()
     dev = device_of(A, B)
@@ -187,7 +189,7 @@ def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta
         d.a_stride[i] = A.stride(i)
         d.b_stride[i] = B.stride(i)
     d.A_bit, d.B_bit, d.metric, d.eq_n, d.search_round = A_bit, B_bit, metric_id(metric), eq_n, search_round
-    d.sos, d.init_layerwise, d.reserved = int(sos), int(init_layerwise), 0
+    d.sos, d.init_layerwise, d.reserved = int(sos), int(init_layerwise), (0 if prune else 8)
     need = lib.p4v_matmul_workspace_bytes(C.byref(d))
     if need == 0:
         _lib.check(-2, "p4v_matmul_workspace_bytes")

@@ -619,3 +619,52 @@ def test_block16_sweep_matches_the_128_tile_sweep(eng, b, H, S, D):
             assert torch.equal(x, y), "k_sweep9 is not run-to-run deterministic"
     assert_scores_close(new[3].cpu().numpy(), old[3].cpu().numpy(), rtol=2e-6, what="k_sweep9 vs k_sweep8")
     assert torch.equal(new[4], old[4]) and torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# exact candidate pruning (p4v_api.hip::run_pass_pruned): same intervals with and without, bit for bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(b=8, T=197, K=768, N=768, n_V=1, bit=8, metric="hessian", postgelu=False),          # ViT-B proj at 8 images: k_sweep6
+    dict(b=8, T=197, K=768, N=2304, n_V=3, bit=8, metric="hessian", postgelu=False),         # qkv: three score blocks, three hulls
+    dict(b=6, T=197, K=3072, N=768, n_V=1, bit=8, metric="hessian", postgelu=True),          # fc2: k_sweep7 plain + merged twin
+    dict(b=6, T=197, K=768, N=3072, n_V=1, bit=6, metric="L2_norm", postgelu=False),         # fc1, W6A6, unweighted
+    dict(b=5, T=131, K=1024, N=320, n_V=5, bit=8, metric="L1_norm", postgelu=False),         # ragged tiles, 5 blocks, |.| terms
+    dict(b=16, T=50, K=384, N=200, n_V=1, bit=8, metric="linear_weighted_L2_norm", postgelu=True),   # twin on k_sweep6 sizes
+    dict(b=3, T=40, K=192, N=96, n_V=1, bit=8, metric="hessian", postgelu=False),            # too few samples for a slice: unpruned
+], ids=lambda c: f"K{c['K']}-N{c['N']}-nV{c['n_V']}-b{c['b']}-w{c['bit']}-{c['metric'][:6]}-{'gelu' if c['postgelu'] else 'plain'}")
+def test_candidate_pruning_is_exact_linear(eng, cfg):
+    """Stage A (all candidates, first eighth of the samples) + B1 (the bound) + B2 (the surviving range on all samples) must
+    select exactly what the sweep of every candidate over every sample selects: three rounds, memo on, both searches."""
+    cfg = dict(cfg)
+    b, T, K, N, bit, postgelu = (cfg.pop(k) for k in ("b", "T", "K", "N", "bit", "postgelu"))
+    w, bias, x, out, grad = _mk_linear(31, b, T, K, N, postgelu)
+    hp = dict(w_bit=bit, a_bit=bit, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, n_H=1, n_a=1, postgelu=postgelu, **cfg)
+    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad))
+    pruned = eng.linear_calibrate(**args, **hp)
+    again = eng.linear_calibrate(**args, **hp)
+    full = eng.linear_calibrate(prune=False, **args, **hp)
+    nomemo = eng.linear_calibrate(memoize=False, **args, **hp)
+    torch.cuda.synchronize()
+    for k, what in ((0, "w_interval"), (1, "a_interval")):
+        assert torch.equal(pruned[k], again[k]), f"pruned search is not run-to-run deterministic ({what})"
+        assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}: {pruned[k].tolist()} vs {full[k].tolist()}"
+        assert torch.equal(pruned[k], nomemo[k]), f"pruned search without the pass memo differs ({what})"
+
+
+@pytest.mark.parametrize("kind,b,H,S,D,bit,metric", [("qk", 16, 12, 197, 64, 8, "hessian"), ("sv", 16, 12, 197, 64, 8, "hessian"),
+                                                      ("qk", 128, 4, 144, 32, 8, "hessian"), ("sv", 64, 4, 144, 32, 6, "L2_norm"),
+                                                      ("qk", 9, 3, 250, 64, 8, "L1_norm"), ("qk", 4, 3, 49, 32, 8, "hessian")],
+                         ids=["vit-b-qk", "vit-b-sv-sos", "swin-w12-qk", "swin-w12-sv-w6", "250-tokens", "4-images-unpruned"])
+def test_candidate_pruning_is_exact_matmul(eng, kind, b, H, S, D, bit, metric):
+    """The same for the attention matmuls (per-head score blocks: one hull over the heads; stage A = the first images)."""
+    A, B, out, grad = _mk_attention(41, b, H, S, D, kind)
+    hp = dict(A_bit=bit, B_bit=bit, metric=metric, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, sos=(kind == "sv"))
+    Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1) if kind == "qk" else _t(B)
+    args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(grad))
+    pruned = eng.matmul_calibrate(**args, **hp)
+    full = eng.matmul_calibrate(prune=False, **args, **hp)
+    torch.cuda.synchronize()
+    for k, what in ((0, "A_interval"), (1, "B_interval"), (2, "split")):
+        if pruned[k] is not None:
+            assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}"
