@@ -841,6 +841,7 @@ int run_pass(Ctx& c, Pass& ps) {
             HIPCHK(hipStreamSynchronize(c.st));
             const int lo = std::max(h[0], c0), hi = std::min(h[1], c0 + nc);
             g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
+            if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] pruned stage: candidates [%d, %d) of %d  (M %d N %d K %d Z %d nj %d)\n", h[0], h[1], ps.eq_n, ps.Mrows, ps.Ncols, ps.K, ps.Z, ps.nj);
         } else g_exec_frac = 1.0;
         if (stat_ok) {
             Sweep3Params q{};
@@ -988,39 +989,107 @@ bool prune_ok(const Pass& ps) {
     if ((g_variant & 4194304) || ps.eq_n < 32 || ps.nj < 1 || ps.nj > 4096) return false;
     return true;
 }
+int launch_pass_select(Ctx& c, const Pass& ps, const float* scores) {
+    SelectParams sl{scores, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, ps.interval, ps.out_js,
+                    ps.out_off, ps.aux_out, ps.aux_div, ps.scores_out, ps.scores_out_ld, ps.best_out};
+    return launch_select(c, sl);
+}
+
 int run_pass_pruned(Ctx& c, Pass& ps) {
     if (!prune_ok(ps)) return run_pass(c, ps);
-    // the slice: whole 256-row tiles of a Linear's samples, whole images of a matmul's batch
-    Pass a = ps;
-    if (ps.Z == 1) {
-        const int m = (int)rup(std::max(1, ps.Mrows / 8), 256);
-        if (m * 5 > ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth three stages
-        a.Mrows = m; a.row.pk.R = m; if (ps.twin) a.row2.pk.R = m;
+    const bool lin = ps.Z == 1;
+    // geometry of the slice: samples of a Linear (rows of x / raw_out / raw_grad), whole images of a matmul (all heads)
+    const int H = lin ? 1 : std::max(1, ps.j_mode == 2 ? ps.j_div : 1);
+    const int units = lin ? ps.Mrows : ps.Z / H;                     // what is ranked by its share of the metric weight
+    int k;
+    if (lin) {
+        k = (int)std::min<long>(rup(std::max(1, ps.Mrows / 16), 256), rup(ps.Mrows, 256));
+        if ((long)k * 5 > (long)ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth the stages
+        if (ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.o_bs || ps.o_nbs || ps.row.pk.conv || ps.row.pk.s_k != 1 ||
+            ps.row.pk.s_r != ps.K || ps.row.pk.zdiv > 0) return run_pass(c, ps);   // dense row-major operands only
     } else {
-        const int H = std::max(1, ps.j_mode == 2 ? ps.j_div : 1), imgs = ps.Z / H;
-        const int z = std::max(1, imgs / 8) * H;
-        if (ps.Z % H || z * 5 > ps.Z * 2 || ps.row_zs_shared || ps.col_zs_shared) return run_pass(c, ps);
-        a.Z = z; a.row.pk.Z = z; a.col.pk.Z = z; if (ps.twin) a.row2.pk.Z = z;
+        k = std::max(1, units / 8);
+        if (ps.Z % H || units < 8 || ps.row_zs_shared || ps.col_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols ||
+            ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.row.pk.zdiv != H || ps.col.pk.zdiv != H) return run_pass(c, ps);
     }
     const size_t mark = c.ws.off;
     const size_t tab = (size_t)ps.eq_n * std::max(1, ps.nj);
     float* SA = c.ws.get<float>(tab);
     float* SB = c.ws.get<float>(tab);
+    float* S2 = c.ws.get<float>(tab);
     int* r1 = c.ws.get<int>(4);
     int* r2 = r1 + 2;
+    const long zrows = lin ? ps.Mrows : ps.Z;                        // rows of the mass table
+    const long per_row = lin ? ps.Ncols : (long)ps.Mrows * ps.Ncols; // elements of raw_out / raw_grad per mass row
+    float* mass = c.ws.get<float>((size_t)zrows);
+    float* mass_u = lin ? mass : c.ws.get<float>((size_t)units);
+    int* idx = c.ws.get<int>((size_t)k);
+    const long out_elems = (long)k * (lin ? ps.Ncols : (long)H * ps.Mrows * ps.Ncols);
+    float* Os = c.ws.get<float>((size_t)out_elems);
+    float* Gs = ps.G ? c.ws.get<float>((size_t)out_elems) : nullptr;
+    const long row_elems = (long)k * (lin ? ps.K : (long)H * ps.Mrows * ps.K);
+    const long col_elems = lin ? 0 : (long)k * H * ps.Ncols * ps.K;
+    float* Rs = c.ws.get<float>((size_t)row_elems);
+    float* Cs = lin ? nullptr : c.ws.get<float>((size_t)col_elems);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    Pass a = ps;
+    if (!c.dry) {
+        // the k heaviest samples / images by their share of the metric weight
+        hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, ps.G ? ps.G : ps.O, ps.O, zrows, per_row, ps.wt_mode, mass);
+        if (!lin) hipLaunchKernelGGL(k_group_mass, dim3(cdiv(units, 64)), dim3(64), 0, c.st, mass, units, H, mass_u);
+        hipLaunchKernelGGL(k_topk_rows, dim3(1), dim3(1024), 0, c.st, mass_u, units, k, idx);
+        auto gather = [&](const float* src, long s0, long s1, long s2, long s3, int d1, int d2, int d3, float* dst) {
+            GatherParams gp{src, s0, s1, s2, s3, d1, d2, d3, idx, k, dst};
+            const long total = (long)k * d1 * d2 * d3;
+            hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, gp);
+        };
+        if (lin) {
+            gather(ps.O, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Os);
+            if (Gs) gather(ps.G, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Gs);
+            gather(ps.row.pk.src, ps.row.pk.s_r, 0, 0, 1, 1, 1, ps.K, Rs);
+        } else {
+            const long img = (long)H * ps.Mrows * ps.Ncols;
+            gather(ps.O, img, 0, 0, 1, 1, 1, (int)img, Os);
+            if (Gs) gather(ps.G, img, 0, 0, 1, 1, 1, (int)img, Gs);
+            // operands: logical [image][head][rows][K] views through the pack strides -> dense
+            gather(ps.row.pk.src, ps.row.pk.s_z2, ps.row.pk.s_z, ps.row.pk.s_r, ps.row.pk.s_k, H, ps.row.pk.R, ps.K, Rs);
+            gather(ps.col.pk.src, ps.col.pk.s_z2, ps.col.pk.s_z, ps.col.pk.s_r, ps.col.pk.s_k, H, ps.col.pk.R, ps.K, Cs);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // stage A: all candidates on the slice
+    a.O = Os; a.G = ps.G ? Gs : nullptr;
+    if (lin) {
+        a.Mrows = k; a.row.pk.src = Rs; a.row.pk.R = k;
+        if (ps.twin) { a.row2.pk.src = Rs; a.row2.pk.R = k; }
+    } else {
+        const int z = k * H;
+        a.Z = z;
+        auto dense = [&](PackParams& pk, float* buf) {
+            pk.src = buf; pk.Z = z; pk.s_k = 1; pk.s_r = ps.K; pk.s_z = (long)pk.R * ps.K; pk.s_z2 = (long)H * pk.R * ps.K;
+        };
+        dense(a.row.pk, Rs); dense(a.col.pk, Cs);
+        if (ps.twin) dense(a.row2.pk, Rs);
+    }
     a.cache = nullptr; a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
     CHK(run_pass(c, a));
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1};
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
     b1.crange = r1; b1.scores_keep = SB; b1.no_select = true;
     CHK(run_pass(c, b1));
     pp.r_out = r2;
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    // stage B2: whatever else survives, on all samples (an empty range when stage B1 already covers the survivors)
     Pass b2 = ps;
-    b2.crange = r2;
+    b2.crange = r2; b2.scores_keep = S2; b2.no_select = true;
     CHK(run_pass(c, b2));
+    if (!c.dry) {
+        hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
+        HIPCHK(hipGetLastError());
+        CHK(launch_pass_select(c, ps, S2));
+    }
     c.ws.off = mark;
     return 0;
 }

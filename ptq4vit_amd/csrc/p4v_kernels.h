@@ -3188,6 +3188,110 @@ __global__ __launch_bounds__(256) void k_finish_cos(FinishCosParams p) {
 // the survivors over all blocks; stage B2 evaluates exactly that range with the unpruned kernels on the unpruned tiles, so the
 // totals of the survivors -- and the selection -- are bit-identical to the unpruned pass.  NaN anywhere disables the pruning
 // (torch.argmax treats NaN as the maximum, linear.py:493).
+// Which samples form the slice of stage A: the ones that carry the most of the metric's weight.  In a ViT calibrated with the
+// Hessian-guided metric the weight raw_grad^2 is concentrated on a handful of samples (the class-token rows: measured on
+// ViT-B/224 x 32, the heaviest 1/8 of a Linear's 6304 samples hold 99.9 % of the mass, the first 1/8 hold 2 %,
+// tools/row_mass.py), so the scores of a small slice are very tight upper bounds and only a few candidates survive.
+//   k_row_mass:  mass[r] = sum over the row's `cols` elements of the metric weight (g^2 | o^2 | |o| | 1)
+//   k_topk_rows: indices of the k heaviest rows, ascending (radix select on the float bits + ordered compaction; one
+//                workgroup; deterministic)
+//   k_gather:    dst[i][...] = src[idx[i]][...] for a 3-D strided inner block (dense destination)
+__global__ __launch_bounds__(256) void k_row_mass(const float* W, const float* O, long rows, long cols, int wt_mode, float* mass) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = (wt_mode == 1 ? W : O) + r * cols;
+    float s = 0.0f;
+    if (wt_mode == 0) s = lane == 0 ? 1.0f : 0.0f;
+    else
+        for (long i = lane; i < cols; i += 64) {
+            const float v = src[i];
+            s += wt_mode == 2 ? fabsf(v) : v * v;
+        }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) mass[r] = s;
+}
+// mass2[i] = sum of `group` consecutive masses (matmul: the heads of one image)
+__global__ void k_group_mass(const float* mass, int n_groups, int group, float* out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    float s = 0.0f;
+    for (int i = 0; i < group; ++i) s += mass[(long)g * group + i];
+    out[g] = s;
+}
+__global__ __launch_bounds__(1024) void k_topk_rows(const float* mass, int n, int k, int* idx) {
+    __shared__ int cnt[1024];
+    __shared__ unsigned prefix_s;
+    __shared__ int base_s, gt_s;
+    const int t = threadIdx.x;
+    auto key = [&](int i) -> unsigned { const unsigned b = __float_as_uint(mass[i]); return (b & 0x80000000u) ? 0u : b; };   // negative / -0: lightest
+    auto block_sum = [&](int v) -> int {
+        cnt[t] = v;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if (t < o) cnt[t] += cnt[t + o]; __syncthreads(); }
+        const int r = cnt[0];
+        __syncthreads();
+        return r;
+    };
+    if (t == 0) prefix_s = 0;
+    __syncthreads();
+    for (int bit = 31; bit >= 0; --bit) {          // largest T with count(key >= T) >= k
+        const unsigned cand = prefix_s | (1u << bit);
+        int c = 0;
+        for (int i = t; i < n; i += 1024) c += key(i) >= cand;
+        const int tot = block_sum(c);
+        if (t == 0 && tot >= k) prefix_s = cand;
+        __syncthreads();
+    }
+    const unsigned T = prefix_s;
+    int c = 0;
+    for (int i = t; i < n; i += 1024) c += key(i) > T;
+    const int n_gt = block_sum(c);
+    if (t == 0) { base_s = 0; gt_s = 0; }
+    __syncthreads();
+    // ordered compaction, 1024 rows at a time: rows above the threshold, and rows AT it until k are taken
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const unsigned kv = i < n ? key(i) : 0u;
+        const int is_gt = i < n && kv > T, is_eq = i < n && kv == T;
+        // exclusive scans of the two flags
+        cnt[t] = is_gt | (is_eq << 16);
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = t >= o ? cnt[t - o] : 0;
+            __syncthreads();
+            cnt[t] += v;
+            __syncthreads();
+        }
+        const int incl = cnt[t], tot = cnt[1023];
+        const int gt_before = (incl & 0xffff) - is_gt, eq_before = (incl >> 16) - is_eq;
+        const int eq_taken_before = gt_s;            // equal-to-threshold rows taken in earlier chunks
+        const int eq_room = (k - n_gt) - eq_taken_before;
+        const bool take = is_gt || (is_eq && eq_before < eq_room);
+        const int eq_taken_here_before = min(eq_before, max(eq_room, 0));
+        if (take) idx[base_s + gt_before + eq_taken_here_before] = i;
+        __syncthreads();
+        if (t == 0) {
+            const int eq_tot = tot >> 16, gt_tot = tot & 0xffff;
+            const int eq_take = min(eq_tot, max(eq_room, 0));
+            base_s += gt_tot + eq_take;
+            gt_s += eq_take;
+        }
+        __syncthreads();
+    }
+}
+struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; };
+__global__ __launch_bounds__(256) void k_gather(GatherParams p) {
+    const long inner = (long)p.d1 * p.d2 * p.d3, total = inner * p.k;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / inner);
+        long rem = i - (long)r * inner;
+        const int a = (int)(rem / ((long)p.d2 * p.d3)); rem -= (long)a * p.d2 * p.d3;
+        const int b = (int)(rem / p.d3), cidx = (int)(rem - (long)b * p.d3);
+        p.dst[i] = p.src[(long)p.idx[r] * p.s0 + (long)a * p.s1 + (long)b * p.s2 + (long)cidx * p.s3];
+    }
+}
+
 struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out; };
 __global__ void k_prune_pick(PruneParams p) {          // r_out = hull over the blocks of stage A's first maxima (NaN = maximum)
     __shared__ int lo, hi;
@@ -3226,7 +3330,17 @@ __global__ void k_prune_hull(PruneParams p) {
         atomicMin(&lo, l); atomicMax(&hi, h);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { p.r_out[0] = bad ? 0 : lo; p.r_out[1] = bad ? p.C : hi; }
+    if (threadIdx.x == 0) {
+        int l = bad ? 0 : lo, h = bad ? p.C : hi;
+        if (l == a && h == b) l = h = 0;               // nothing survives outside stage B1's range: its totals decide
+        p.r_out[0] = l; p.r_out[1] = h;
+    }
+}
+// final score table of a pruned pass: stage B2's where it evaluated the candidate, stage B1's otherwise (the two agree bit for bit
+// where both did)
+__global__ void k_merge_scores(float* S2, const float* SB, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && S2[i] == -__builtin_inff()) S2[i] = SB[i];
 }
 // pack groups [g * PACK_CG, +PACK_CG) that intersect the range are packed now
 __global__ void k_mark_done(unsigned char* done, int ngroups, const int* crange, int c_base) {
