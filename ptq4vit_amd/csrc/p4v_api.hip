@@ -615,6 +615,18 @@ struct PlaneCache {
     bool assigned = false, valid = false;
     unsigned char* done = nullptr;    // pruned passes: device flags, one per pack group of PACK_CG candidates already in `buf`
 };
+// The sample slice of the pruned passes (run_pass_pruned, stage A): which samples carry the metric weight depends on raw_grad /
+// raw_out only, so the ranking, the gathered rows of raw_out / raw_grad and of the row operand are built by the first pruned pass
+// of a module and reused by the others (both searches, all rounds); a buffer is gathered again only when its source changed
+// (the folded target of the twin activation search is rebuilt per pass).
+struct SliceCache {
+    bool assigned = false;
+    int k = 0;
+    int* idx = nullptr; float* mass = nullptr; float* mass_u = nullptr;
+    float* Os = nullptr; float* Gs = nullptr; float* Rs = nullptr; float* Cs = nullptr;
+    const void* idx_src = nullptr; int idx_wt = -1;      // what the ranking was computed from
+    const void* o_src = nullptr; const void* g_src = nullptr; const void* r_src = nullptr; const void* c_src = nullptr;
+};
 // The same for the epilogue operands of k_sweep6 in fragment order (k_prep_epi6): raw_out, raw_grad and the bias are fixed
 // for the whole call, so the tile image of one search orientation is built by its first pass and read by the later rounds.
 typedef PlaneCache EpiCache;
@@ -657,6 +669,9 @@ struct Pass {
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
+    SliceCache* scache;       // optional: the module's sample slice, shared by its pruned passes
+    bool host_sync_ok;        // the caller synchronises the stream after the pass anyway (pass memo): the pruned pass may read
+                              // the 8-byte survivor range back and skip the launches of an empty stage B2
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
     EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
 };
@@ -1012,6 +1027,24 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         if (ps.Z % H || units < 8 || ps.row_zs_shared || ps.col_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols ||
             ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.row.pk.zdiv != H || ps.col.pk.zdiv != H) return run_pass(c, ps);
     }
+    const long zrows = lin ? ps.Mrows : ps.Z;                        // rows of the mass table
+    const long per_row = lin ? ps.Ncols : (long)ps.Mrows * ps.Ncols; // elements of raw_out / raw_grad per mass row
+    const long out_elems = (long)k * (lin ? ps.Ncols : (long)H * ps.Mrows * ps.Ncols);
+    const long row_elems = (long)k * (lin ? ps.K : (long)H * ps.row.pk.R * ps.K);
+    const long col_elems = lin ? 0 : (long)k * H * ps.col.pk.R * ps.K;
+    SliceCache local;
+    SliceCache* sc = ps.scache ? ps.scache : &local;
+    if (sc->assigned && sc->k != k) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
+    if (ps.scache && !sc->assigned) {        // top of the workspace: lives for the whole *_calibrate call
+        sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)k * sizeof(int)));
+        sc->mass = reinterpret_cast<float*>(c.ws.get_top((size_t)zrows * sizeof(float)));
+        sc->mass_u = lin ? sc->mass : reinterpret_cast<float*>(c.ws.get_top((size_t)units * sizeof(float)));
+        sc->Os = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
+        sc->Gs = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
+        sc->Rs = reinterpret_cast<float*>(c.ws.get_top((size_t)row_elems * sizeof(float)));
+        sc->Cs = lin ? nullptr : reinterpret_cast<float*>(c.ws.get_top((size_t)col_elems * sizeof(float)));
+        sc->assigned = true; sc->k = k;
+    }
     const size_t mark = c.ws.off;
     const size_t tab = (size_t)ps.eq_n * std::max(1, ps.nj);
     float* SA = c.ws.get<float>(tab);
@@ -1019,41 +1052,46 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     float* S2 = c.ws.get<float>(tab);
     int* r1 = c.ws.get<int>(4);
     int* r2 = r1 + 2;
-    const long zrows = lin ? ps.Mrows : ps.Z;                        // rows of the mass table
-    const long per_row = lin ? ps.Ncols : (long)ps.Mrows * ps.Ncols; // elements of raw_out / raw_grad per mass row
-    float* mass = c.ws.get<float>((size_t)zrows);
-    float* mass_u = lin ? mass : c.ws.get<float>((size_t)units);
-    int* idx = c.ws.get<int>((size_t)k);
-    const long out_elems = (long)k * (lin ? ps.Ncols : (long)H * ps.Mrows * ps.Ncols);
-    float* Os = c.ws.get<float>((size_t)out_elems);
-    float* Gs = ps.G ? c.ws.get<float>((size_t)out_elems) : nullptr;
-    const long row_elems = (long)k * (lin ? ps.K : (long)H * ps.Mrows * ps.K);
-    const long col_elems = lin ? 0 : (long)k * H * ps.Ncols * ps.K;
-    float* Rs = c.ws.get<float>((size_t)row_elems);
-    float* Cs = lin ? nullptr : c.ws.get<float>((size_t)col_elems);
+    if (!ps.scache) {
+        sc->idx = c.ws.get<int>((size_t)k);
+        sc->mass = c.ws.get<float>((size_t)zrows);
+        sc->mass_u = lin ? sc->mass : c.ws.get<float>((size_t)units);
+        sc->Os = c.ws.get<float>((size_t)out_elems);
+        sc->Gs = c.ws.get<float>((size_t)out_elems);
+        sc->Rs = c.ws.get<float>((size_t)row_elems);
+        sc->Cs = lin ? nullptr : c.ws.get<float>((size_t)col_elems);
+        sc->k = k;
+    }
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    float *Os = sc->Os, *Gs = ps.G ? sc->Gs : nullptr, *Rs = sc->Rs, *Cs = sc->Cs;
     Pass a = ps;
     if (!c.dry) {
-        // the k heaviest samples / images by their share of the metric weight
-        hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, ps.G ? ps.G : ps.O, ps.O, zrows, per_row, ps.wt_mode, mass);
-        if (!lin) hipLaunchKernelGGL(k_group_mass, dim3(cdiv(units, 64)), dim3(64), 0, c.st, mass, units, H, mass_u);
-        hipLaunchKernelGGL(k_topk_rows, dim3(1), dim3(1024), 0, c.st, mass_u, units, k, idx);
+        const void* wsrc = ps.G ? (const void*)ps.G : (const void*)ps.O;
+        const bool new_idx = sc->idx_src != wsrc || sc->idx_wt != ps.wt_mode || (ps.wt_mode != 1 && sc->o_src != ps.O);
+        if (new_idx) {
+            // the k heaviest samples / images by their share of the metric weight
+            hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, ps.G ? ps.G : ps.O, ps.O, zrows, per_row, ps.wt_mode, sc->mass);
+            if (!lin) hipLaunchKernelGGL(k_group_mass, dim3(cdiv(units, 64)), dim3(64), 0, c.st, sc->mass, units, H, sc->mass_u);
+            hipLaunchKernelGGL(k_topk_rows, dim3(1), dim3(1024), 0, c.st, sc->mass_u, units, k, sc->idx);
+            sc->idx_src = wsrc; sc->idx_wt = ps.wt_mode;
+            sc->o_src = sc->g_src = sc->r_src = sc->c_src = nullptr;
+        }
         auto gather = [&](const float* src, long s0, long s1, long s2, long s3, int d1, int d2, int d3, float* dst) {
-            GatherParams gp{src, s0, s1, s2, s3, d1, d2, d3, idx, k, dst};
+            GatherParams gp{src, s0, s1, s2, s3, d1, d2, d3, sc->idx, k, dst};
             const long total = (long)k * d1 * d2 * d3;
             hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, gp);
         };
         if (lin) {
-            gather(ps.O, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Os);
-            if (Gs) gather(ps.G, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Gs);
-            gather(ps.row.pk.src, ps.row.pk.s_r, 0, 0, 1, 1, 1, ps.K, Rs);
+            if (sc->o_src != ps.O) { gather(ps.O, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Os); sc->o_src = ps.O; }
+            if (Gs && sc->g_src != ps.G) { gather(ps.G, ps.o_ms, 0, 0, 1, 1, 1, ps.Ncols, Gs); sc->g_src = ps.G; }
+            if (sc->r_src != ps.row.pk.src) { gather(ps.row.pk.src, ps.row.pk.s_r, 0, 0, 1, 1, 1, ps.K, Rs); sc->r_src = ps.row.pk.src; }
         } else {
             const long img = (long)H * ps.Mrows * ps.Ncols;
-            gather(ps.O, img, 0, 0, 1, 1, 1, (int)img, Os);
-            if (Gs) gather(ps.G, img, 0, 0, 1, 1, 1, (int)img, Gs);
+            if (sc->o_src != ps.O) { gather(ps.O, img, 0, 0, 1, 1, 1, (int)img, Os); sc->o_src = ps.O; }
+            if (Gs && sc->g_src != ps.G) { gather(ps.G, img, 0, 0, 1, 1, 1, (int)img, Gs); sc->g_src = ps.G; }
             // operands: logical [image][head][rows][K] views through the pack strides -> dense
-            gather(ps.row.pk.src, ps.row.pk.s_z2, ps.row.pk.s_z, ps.row.pk.s_r, ps.row.pk.s_k, H, ps.row.pk.R, ps.K, Rs);
-            gather(ps.col.pk.src, ps.col.pk.s_z2, ps.col.pk.s_z, ps.col.pk.s_r, ps.col.pk.s_k, H, ps.col.pk.R, ps.K, Cs);
+            if (sc->r_src != ps.row.pk.src) { gather(ps.row.pk.src, ps.row.pk.s_z2, ps.row.pk.s_z, ps.row.pk.s_r, ps.row.pk.s_k, H, ps.row.pk.R, ps.K, Rs); sc->r_src = ps.row.pk.src; }
+            if (sc->c_src != ps.col.pk.src) { gather(ps.col.pk.src, ps.col.pk.s_z2, ps.col.pk.s_z, ps.col.pk.s_r, ps.col.pk.s_k, H, ps.col.pk.R, ps.K, Cs); sc->c_src = ps.col.pk.src; }
         }
         HIPCHK(hipGetLastError());
     }
@@ -1081,6 +1119,18 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     CHK(run_pass(c, b1));
     pp.r_out = r2;
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    if (ps.host_sync_ok && !c.dry && !g_stat_on) {
+        // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
+        // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made
+        int h[2] = {0, 1};
+        HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
+        HIPCHK(hipStreamSynchronize(c.st));
+        if (h[0] >= h[1]) {
+            CHK(launch_pass_select(c, ps, SB));
+            c.ws.off = mark;
+            return 0;
+        }
+    }
     // stage B2: whatever else survives, on all samples (an empty range when stage B1 already covers the survivors)
     Pass b2 = ps;
     b2.crange = r2; b2.scores_keep = S2; b2.no_select = true;
@@ -1322,8 +1372,10 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     PassMemo memo_w, memo_a;
     PlaneCache plane_w, plane_a;
     EpiCache epi_w, epi_a;
+    SliceCache slice;
     const bool keep_planes = sg.full() && d->search_round > 1;
-    std::vector<float> key, val;
+    std::vector<float> key, val, host_w, host_a;     // host copies of the current intervals, when a pass just moved them
+    bool host_w_ok = false, host_a_ok = false;
     const int n_rounds = sg.full() ? d->search_round : 1;
     auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
     for (int round = 0; round < n_rounds; ++round) {
@@ -1335,8 +1387,8 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         const bool memo_w_on = memo_on && nH == 1, memo_a_on = memo_on && nA == 1;
         bool skip_w = false;
         if (memo_w_on) {
-            CHK(read_dev(c, a_iv, nA, key));
-            if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; }
+            if (host_a_ok) key = host_a; else CHK(read_dev(c, a_iv, nA, key));     // (just read back / written by the last pass)
+            if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; host_w = *hit; host_w_ok = true; }
         }
         for (int h = 0; h < nH && !skip_w && (sg.mask & ST_S1); ++h) {
             Pass ps{};
@@ -1375,7 +1427,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.O = O; ps.G = G; ps.o_zs = 0; ps.o_bs = 0; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
                 ps.j_mode = 1; ps.j_div = crb_rows;
                 ps.norm = 1.0 / ((double)d->tokens * crb_rows);
-                ps.prunable = !(d->reserved & 8);
+                ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.host_sync_ok = memo_w_on;
             } else {
                 // swapped: rows = features of V block z, cols = samples
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -1391,12 +1443,13 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass_pruned(c, ps));
         }
-        if (memo_w_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
+        if (memo_w_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; host_w = val; host_w_ok = true; }
+        else if (!skip_w) host_w_ok = false;
         // ================= activation search (linear.py:497-533 / 609-642) =================
         bool skip_a = false;
         if (memo_a_on) {
-            CHK(read_dev(c, w_iv, nV * nH, key));
-            if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; }
+            if (host_w_ok) key = host_w; else CHK(read_dev(c, w_iv, nV * nH, key));
+            if (const auto* hit = memo_a.find(key)) { CHK(write_dev(c, a_iv, *hit)); skip_a = true; g_memo_hits++; host_a = *hit; host_a_ok = true; }
         }
         for (int a = 0; a < nA && !skip_a && (sg.mask & ST_S2); ++a) {
             Pass ps{};
@@ -1431,7 +1484,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 ps.O = O; ps.G = G; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
                 ps.j_mode = 0;
                 ps.norm = 1.0 / ((double)d->tokens * N);
-                ps.prunable = !(d->reserved & 8);
+                ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.host_sync_ok = memo_a_on;
                 if (twin && wt_mode <= 1 && !(g_variant & 64)) {
                     // Twin activation search: the negative-range plane and the weights are candidate-invariant, so
                     // their product is folded into the target once (U = raw_out - bias - s_neg*s_w*(x_neg . W_q))
@@ -1448,6 +1501,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     // Ufold depends on the CURRENT w_interval: it is rebuilt for every activation pass that runs, so the
                     // fragment-order image of k_sweep6's epilogue operands (built from ps.O) must be rebuilt with it
                     ps.ecache = nullptr;
+                    slice.o_src = nullptr;          // ... and so are the gathered rows of the target in the sample slice
                 }
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -1463,7 +1517,8 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             }
             CHK(run_pass_pruned(c, ps));
         }
-        if (memo_a_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; }
+        if (memo_a_on && !skip_a) { CHK(read_dev(c, a_iv, nA, val)); memo_a.entries.push_back({key, val}); g_memo_misses++; host_a = val; host_a_ok = true; }
+        else if (!skip_a) host_a_ok = false;
     }
     return 0;
 }
@@ -1572,6 +1627,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_A, memo_B;
     PlaneCache plane_A, plane_B;
+    SliceCache slice;
     const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int nAiv = d->sos ? 1 : H;
@@ -1607,7 +1663,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.cands = A_cands; ps.cand_cs = H; ps.cand_js = 1; ps.interval = A_iv; ps.out_js = 1;
             ps.cache = keep_planes ? &plane_A : nullptr;
             ps.scores_out = so; ps.scores_out_ld = H; ps.best_out = bo;
-            ps.prunable = !cosm && !(d->reserved & 8);
+            ps.prunable = !cosm && !(d->reserved & 8); ps.scache = &slice; ps.host_sync_ok = memo_on;
             CHK(run_pass_pruned(c, ps));
         } else if (sos_split_ok(M, K, N, cosm)) {
             // ---- split search against the UNQUANTISED B (matmul.py:600-631): A quantised in registers, one kernel ----
@@ -1675,7 +1731,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             ps.cache = keep_planes ? &plane_B : nullptr;
             ps.scores_out = so_B; ps.scores_out_ld = H;
             ps.best_out = bo_B;
-            ps.prunable = !cosm && ps.i8 && !(d->reserved & 8);
+            ps.prunable = !cosm && ps.i8 && !(d->reserved & 8); ps.scache = &slice; ps.host_sync_ok = memo_on;
             CHK(run_pass_pruned(c, ps));
             if (memo_on) { CHK(read_dev(c, B_iv, H, val)); memo_B.entries.push_back({key, val}); g_memo_misses++; }
         }
