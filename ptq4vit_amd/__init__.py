@@ -5,7 +5,14 @@ Sub-packages mirror the reference's top-level packages: ``quant_layers``, ``util
 hahnyuan/PTQ4ViT (``from utils.quant_calib import HessianQuantCalibrator`` ...) run unchanged.
 """
 import importlib
+import os
 import sys
+
+# The search runs one module per host thread and HIP stream; the ROCm runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4) and kernels of streams that share a queue serialise.  With the pruned passes a module is a chain of
+# small kernels, so more of them in flight pay (8 queues + 8 streams: +6 % on ViT-B/224 x 32).  Only effective when this
+# package is imported before the process touches the GPU; never overrides the user's setting.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __version__ = "0.1.0"
 

@@ -3219,7 +3219,10 @@ __global__ void k_group_mass(const float* mass, int n_groups, int group, float* 
     for (int i = 0; i < group; ++i) s += mass[(long)g * group + i];
     out[g] = s;
 }
-__global__ __launch_bounds__(1024) void k_topk_rows(const float* mass, int n, int k, int* idx) {
+__global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n, int k, int* idx_all) {
+    // one workgroup per segment (matmul: the rows of one (image, head); Linear: a single segment); indices are segment-local
+    const float* mass = mass_all + (long)blockIdx.x * n;
+    int* idx = idx_all + (long)blockIdx.x * k;
     __shared__ int cnt[1024];
     __shared__ unsigned prefix_s;
     __shared__ int base_s, gt_s;
@@ -3280,7 +3283,9 @@ __global__ __launch_bounds__(1024) void k_topk_rows(const float* mass, int n, in
         __syncthreads();
     }
 }
-struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; };
+// dst[r][a][b][c] = src[seg_off(r / seg) + idx[r] * s0 + a * s1 + b * s2 + c * s3]; seg = rows per segment (0: one segment),
+// seg_off(z) = (z / zdiv) * sz2 + (z % zdiv) * sz (two-level batch stride: image, head)
+struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; int seg, zdiv; long sz2, sz; };
 __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
     const long inner = (long)p.d1 * p.d2 * p.d3, total = inner * p.k;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -3288,7 +3293,9 @@ __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
         long rem = i - (long)r * inner;
         const int a = (int)(rem / ((long)p.d2 * p.d3)); rem -= (long)a * p.d2 * p.d3;
         const int b = (int)(rem / p.d3), cidx = (int)(rem - (long)b * p.d3);
-        p.dst[i] = p.src[(long)p.idx[r] * p.s0 + (long)a * p.s1 + (long)b * p.s2 + (long)cidx * p.s3];
+        long off = 0;
+        if (p.seg > 0) { const int z = r / p.seg; off = (long)(z / p.zdiv) * p.sz2 + (long)(z % p.zdiv) * p.sz; }
+        p.dst[i] = p.src[off + (long)p.idx[r] * p.s0 + (long)a * p.s1 + (long)b * p.s2 + (long)cidx * p.s3];
     }
 }
 
