@@ -479,6 +479,26 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_t)
 
+    # the same kernels on FULL sweeps (every candidate over every sample: exact pruning and nothing else switched off, one
+    # more untimed single-stream step): what the sweep kernels sustain when a launch is not a short candidate range
+    if roof is not None and world == 1:
+        engine.debug_variant(4194304)
+        engine.stats_reset()
+        engine.stats_enable(True)
+        with quiet:
+            one_step(search_streams=1)
+        sync()
+        st2 = engine.stats_get()
+        engine.stats_enable(False)
+        engine.debug_variant(0)
+
+        def cls2(prefix):
+            n, ms = st2[prefix + "_launches"], st2[prefix + "_ms"]
+            return None if not n else {"launches": n, "ms": ms, "avg_launch_ms": ms / n,
+                                       "achieved": 2.0 * st2[prefix + "_alg_macs"] / (ms * 1e-3) / 1e12,
+                                       "frac": 2.0 * st2[prefix + "_alg_macs"] / (ms * 1e-3) / 1e12 / 5000.0}
+        roof["full_sweeps_without_pruning"] = {"k_sweep6": cls2("sweep6"), "k_sweep7": cls2("sweep7"), "all_int8_sweeps": cls2("sweep_i8")}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_model, threads, logical = _cpu_info()

@@ -717,7 +717,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()
-            n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "3"))
+            n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "4"))
             if batching and not self.sequential and n_streams > 1 and _dev_of(self.net).type == "cuda" and len(grp) > 1:
                 self._search_concurrent(grp, n_streams)
             else:
