@@ -15,7 +15,7 @@ for step in "$@"; do
              tail -1 $O/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], d.get('breakdown'), d.get('first_calibration_s')); print({k:(round(v['ms'],1), round(v['frac'],3)) for k,v in r.get('by_kernel',{}).items() if v}, r.get('all_int8_sweeps',{}).get('frac'), d['cpu_baseline'].get('value'))" ;;
     kstats1|kstats3)
              n=${name#kstats}
-             ( cd /tmp && P4V_SEARCH_STREAMS=$n timeout 600 rocprofv3 --kernel-trace -d $O/prof$n -o b -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
+             ( cd /tmp && P4V_SEARCH_STREAMS=$n timeout 600 rocprofv3 --kernel-trace -d $O/prof$n -o b -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 )
              python tools/kstats_db.py "$O/prof$n/*.db" > $O/bench_${n}stream_kernel_stats.txt
              [ $n = 3 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
              head -24 $O/bench_${n}stream_kernel_stats.txt | cut -c1-180; rm -rf $O/prof$n ;;
