@@ -96,6 +96,8 @@ thread_local long g_memo_hits = 0, g_memo_misses = 0;
 //   8192 no candidate groups for the generic k_sweep
 //   16384 k_sweep6 without the separate launch of the last, partial wave of workgroups
 //   32768 no k_sweep7 (K >= 1024 sweeps on k_sweep2 / k_sweep2g)      65536 no k_sweep8 (single-k-tile sweeps on k_sweep2)
+//   2097152 post-GELU twin of k_sweep7 on two streamed planes (not the merged one)
+//   4194304 no exact candidate pruning (every candidate over every sample)   8388608 prune even where the slice's bounds are loose
 //   1, 2: kernel debug flags (SweepParams::dbg)
 //   bit 30: route every int8 sweep through the generic k_sweep
 std::atomic<int> g_variant_word{0};
@@ -626,6 +628,8 @@ struct SliceCache {
     float* Os = nullptr; float* Gs = nullptr; float* Rs = nullptr; float* Cs = nullptr;
     const void* idx_src = nullptr; int idx_wt = -1;      // what the ranking was computed from
     const void* o_src = nullptr; const void* g_src = nullptr; const void* r_src = nullptr; const void* c_src = nullptr;
+    float* frac = nullptr;            // device: share of the metric weight the slice holds
+    bool loose = false;               // that share is too small for the stages to pay (Swin: no class token): full sweeps
 };
 // The same for the epilogue operands of k_sweep6 in fragment order (k_prep_epi6): raw_out, raw_grad and the bias are fixed
 // for the whole call, so the tile image of one search orientation is built by its first pass and read by the later rounds.
@@ -1036,6 +1040,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     const long row_elems = (long)segs * k * ps.K;
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
+    if (sc->loose) return run_pass(c, ps);
     if (sc->assigned && sc->k != k) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
     if (ps.scache && !sc->assigned) {        // top of the workspace: lives for the whole *_calibrate call
         sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)segs * k * sizeof(int)));
@@ -1043,6 +1048,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         sc->Os = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
         sc->Gs = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
         sc->Rs = reinterpret_cast<float*>(c.ws.get_top((size_t)row_elems * sizeof(float)));
+        sc->frac = reinterpret_cast<float*>(c.ws.get_top(256));
         sc->assigned = true; sc->k = k;
     }
     const size_t mark = c.ws.off;
@@ -1072,6 +1078,17 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
             hipLaunchKernelGGL(k_topk_rows, dim3(segs), dim3(1024), 0, c.st, sc->mass, seg_rows, k, sc->idx);
             sc->idx_src = wsrc; sc->idx_wt = ps.wt_mode;
             sc->o_src = sc->g_src = sc->r_src = nullptr;
+            if (sc->frac && ps.host_sync_ok && !(g_variant & 8388608)) {
+                // once per module: is the slice worth it?  The bounds are as tight as the share of the metric weight the slice
+                // holds (ViT class-token rows: > 0.99); below 0.9 most candidates survive and the three stages cost more than
+                // the full sweep they replace -- this module then keeps the full sweep (variant 8388608: always prune)
+                float f = 1.0f;
+                hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, segs, seg_rows, k, sc->frac);
+                HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
+                HIPCHK(hipStreamSynchronize(c.st));
+                if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, segs, k, seg_rows);
+                if (!(f >= 0.9f)) { sc->loose = true; c.ws.off = mark; return run_pass(c, ps); }
+            }
         }
         const int rows = segs * k;
         auto gather = [&](const float* src, long s0, long s3, int d3, float* dst, int seg, int zdiv, long sz2, long sz) {

@@ -3285,6 +3285,22 @@ __global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n
 }
 // dst[r][a][b][c] = src[seg_off(r / seg) + idx[r] * s0 + a * s1 + b * s2 + c * s3]; seg = rows per segment (0: one segment),
 // seg_off(z) = (z / zdiv) * sz2 + (z % zdiv) * sz (two-level batch stride: image, head)
+// frac[0] = (weight of the selected rows) / (weight of all rows): how tight the slice's bounds are
+__global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long n, const int* idx, int segs, int seg_rows, int k, float* frac) {
+    __shared__ double red[1024];
+    double tot = 0.0, sel = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) tot += (double)mass[i];
+    for (long i = threadIdx.x; i < (long)segs * k; i += 1024) sel += (double)mass[(i / k) * seg_rows + idx[i]];
+    for (int pass = 0; pass < 2; ++pass) {
+        red[threadIdx.x] = pass ? sel : tot;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) { if (pass) sel = red[0]; else tot = red[0]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frac[0] = tot > 0.0 ? (float)(sel / tot) : 0.0f;
+}
+
 struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; int seg, zdiv; long sz2, sz; };
 __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
     const long inner = (long)p.d1 * p.d2 * p.d3, total = inner * p.k;

@@ -640,12 +640,29 @@ def test_candidate_pruning_is_exact_linear(eng, cfg):
     b, T, K, N, bit, postgelu = (cfg.pop(k) for k in ("b", "T", "K", "N", "bit", "postgelu"))
     w, bias, x, out, grad = _mk_linear(31, b, T, K, N, postgelu)
     hp = dict(w_bit=bit, a_bit=bit, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, n_H=1, n_a=1, postgelu=postgelu, **cfg)
-    args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad))
-    pruned = eng.linear_calibrate(**args, **hp)
-    again = eng.linear_calibrate(**args, **hp)
-    full = eng.linear_calibrate(prune=False, **args, **hp)
-    nomemo = eng.linear_calibrate(memoize=False, **args, **hp)
-    torch.cuda.synchronize()
+    # two weight profiles: spread evenly over the samples (loose bounds: many survivors -- the engine would not prune such a
+    # module by itself, variant 8388608 forces it) and concentrated on a few samples as in a ViT (tight bounds)
+    rng = np.random.default_rng(5)
+    heavy = grad.copy().reshape(-1, N)
+    heavy[rng.choice(heavy.shape[0], size=max(1, heavy.shape[0] // 40), replace=False)] *= 300.0
+    for g_ in (grad, heavy.reshape(grad.shape)):
+        args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(g_))
+        try:
+            eng.debug_variant(8388608)
+            pruned = eng.linear_calibrate(**args, **hp)
+            again = eng.linear_calibrate(**args, **hp)
+            nomemo = eng.linear_calibrate(memoize=False, **args, **hp)
+        finally:
+            eng.debug_variant(0)
+        auto = eng.linear_calibrate(**args, **hp)                  # the engine's own choice (fraction of the weight in the slice)
+        full = eng.linear_calibrate(prune=False, **args, **hp)
+        torch.cuda.synchronize()
+        for k, what in ((0, "w_interval"), (1, "a_interval")):
+            assert torch.equal(pruned[k], again[k]), f"pruned search is not run-to-run deterministic ({what})"
+            assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}: {pruned[k].tolist()} vs {full[k].tolist()}"
+            assert torch.equal(pruned[k], nomemo[k]), f"pruned search without the pass memo differs ({what})"
+            assert torch.equal(auto[k], full[k]), f"adaptive search selected another {what}"
+    return
     for k, what in ((0, "w_interval"), (1, "a_interval")):
         assert torch.equal(pruned[k], again[k]), f"pruned search is not run-to-run deterministic ({what})"
         assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}: {pruned[k].tolist()} vs {full[k].tolist()}"
@@ -661,10 +678,19 @@ def test_candidate_pruning_is_exact_matmul(eng, kind, b, H, S, D, bit, metric):
     A, B, out, grad = _mk_attention(41, b, H, S, D, kind)
     hp = dict(A_bit=bit, B_bit=bit, metric=metric, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3, sos=(kind == "sv"))
     Bt = _t(np.ascontiguousarray(B.transpose(0, 1, 3, 2))).transpose(-2, -1) if kind == "qk" else _t(B)
-    args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(grad))
-    pruned = eng.matmul_calibrate(**args, **hp)
-    full = eng.matmul_calibrate(prune=False, **args, **hp)
-    torch.cuda.synchronize()
-    for k, what in ((0, "A_interval"), (1, "B_interval"), (2, "split")):
-        if pruned[k] is not None:
-            assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}"
+    heavy = grad.copy()
+    heavy[:, :, 0, :] *= 300.0                                    # the class-token query row carries the weight, as in a ViT
+    for g_ in (grad, heavy):
+        args = dict(A=_t(A), B=Bt, out=_t(out), grad=_t(g_))
+        try:
+            eng.debug_variant(8388608)
+            pruned = eng.matmul_calibrate(**args, **hp)
+        finally:
+            eng.debug_variant(0)
+        auto = eng.matmul_calibrate(**args, **hp)
+        full = eng.matmul_calibrate(prune=False, **args, **hp)
+        torch.cuda.synchronize()
+        for k, what in ((0, "A_interval"), (1, "B_interval"), (2, "split")):
+            if pruned[k] is not None:
+                assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}"
+                assert torch.equal(auto[k], full[k]), f"adaptive search selected another {what}"
