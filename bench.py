@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--capture-batch", type=int, default=0,
                     help="images per capture pass of the timed steps (0 = batch_size = 4, the reference's passes)")
+    ap.add_argument("--tune", default="", help="key=value,... engine tuning overrides (p4v_debug_set_tuning), experiments only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -319,6 +320,8 @@ def main():
     from ptq4vit_amd.utils import models, net_wrap
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
 
+    for kv in filter(None, args.tune.split(",")):
+        engine.debug_tuning(*(int(v) for v in kv.split("=")))
     net = models.get_net(args.model, seed=0, device=dev)
     if args.bits != 8:      # what the reference's drivers do to the config module (example/test_all.py:53-78)
         PTQ4ViT.bit = args.bits

@@ -105,7 +105,8 @@ std::atomic<int> g_variant_word{0};
 #define g_force_v1 ((g_variant_word.load(std::memory_order_relaxed) >> 30) & 1)
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[16];
-enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8 };   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8,
+       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10 };   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -1025,7 +1026,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     const int seg_rows = ps.Mrows;                                   // rows ranked per segment
     int k;                                                           // rows taken per segment
     if (lin) {
-        k = (int)std::min<long>(rup(std::max(1, ps.Mrows / 16), 256), rup(ps.Mrows, 256));
+        k = (int)std::min<long>(rup(std::max(1, ps.Mrows / (tune(TUNE_SLICE_DIV) > 0 ? tune(TUNE_SLICE_DIV) : 16)), 256), rup(ps.Mrows, 256));
         if ((long)k * 5 > (long)ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth the stages
         if (ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.o_bs || ps.o_nbs || ps.row.pk.conv || ps.row.pk.s_k != 1 ||
             ps.row.pk.s_r != ps.K || ps.row.pk.zdiv > 0) return run_pass(c, ps);   // dense row-major operands only
@@ -1080,14 +1081,16 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
             sc->o_src = sc->g_src = sc->r_src = nullptr;
             if (sc->frac && ps.host_sync_ok && !(g_variant & 8388608)) {
                 // once per module: is the slice worth it?  The bounds are as tight as the share of the metric weight the slice
-                // holds (ViT class-token rows: > 0.99); below 0.9 most candidates survive and the three stages cost more than
-                // the full sweep they replace -- this module then keeps the full sweep (variant 8388608: always prune)
+                // holds (ViT class-token rows: > 0.99; the qkv layers, whose keys and values of every token feed the class token:
+                // 0.72 -- still worth it, measured: 187 -> 168 ms per ViT-B calibration); below 0.5 most candidates survive and
+                // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
+                // (variant 8388608: always prune)
                 float f = 1.0f;
                 hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, segs, seg_rows, k, sc->frac);
                 HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
                 HIPCHK(hipStreamSynchronize(c.st));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, segs, k, seg_rows);
-                if (!(f >= 0.9f)) { sc->loose = true; c.ws.off = mark; return run_pass(c, ps); }
+                if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : 0.5f))) { sc->loose = true; c.ws.off = mark; return run_pass(c, ps); }
             }
         }
         const int rows = segs * k;

@@ -4,7 +4,7 @@ import glob
 import sqlite3
 import sys
 
-for path in ([] if (len(sys.argv) > 1 and sys.argv[1] == "--busy") else sys.argv[1:]):
+for path in ([] if (len(sys.argv) > 1 and sys.argv[1] in ("--busy", "--hist")) else sys.argv[1:]):
     for db in sorted(glob.glob(path) if any(ch in path for ch in "*?") else [path]):
         con = sqlite3.connect(db)
         rows = con.execute("select name, count(*), avg(end-start), sum(end-start), min(end-start), max(end-start) from kernels "
@@ -45,3 +45,29 @@ if len(sys.argv) > 2 and sys.argv[1] == "--busy":
     for path in sys.argv[2:]:
         for db in sorted(glob.glob(path)):
             busy(db)
+
+
+def hist(db, pattern):
+    """Duration histogram of the kernels whose name contains `pattern` (python tools/kstats_db.py --hist <pattern> <db>)."""
+    con = sqlite3.connect(db)
+    rows = con.execute("select end-start from kernels where name like ?", (f"%{pattern}%",)).fetchall()
+    edges = [2, 5, 10, 20, 50, 100, 200, 500, 1000, 5000, 1e9]
+    cnt, tot = [0] * len(edges), [0.0] * len(edges)
+    for (d,) in rows:
+        us = d / 1e3
+        for i, e in enumerate(edges):
+            if us <= e:
+                cnt[i] += 1
+                tot[i] += us
+                break
+    print(f"== {pattern}: {len(rows)} launches, {sum(tot) / 1e3:.1f} ms")
+    lo = 0
+    for e, c, t in zip(edges, cnt, tot):
+        if c:
+            print(f"   {lo:>6g} - {e:<6g} us: n={c:6d}  {t / 1e3:8.2f} ms")
+        lo = e
+
+
+if len(sys.argv) > 3 and sys.argv[1] == "--hist":
+    for db in sorted(glob.glob(sys.argv[3])):
+        hist(db, sys.argv[2])
