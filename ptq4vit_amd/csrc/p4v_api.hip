@@ -599,7 +599,7 @@ int launch_finish_cos(Ctx& c, const FinishCosParams& p) {
 
 int launch_select(Ctx& c, const SelectParams& p) {
     if (c.dry) return 0;
-    hipLaunchKernelGGL(k_select, dim3(cdiv(p.nj, 64)), dim3(64), 0, c.st, p);
+    hipLaunchKernelGGL(k_select, dim3(p.nj), dim3(128), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1120,19 +1120,20 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     sliced(a.row.pk);
     if (ps.twin) sliced(a.row2.pk);
     if (!lin) a.o_zs = (long)k * ps.Ncols;
-    // the candidate-expanded plane of the module is shared with stage A when the slice leaves that operand whole (matmul,
-    // column operand searched): stage A packs all candidates into the module's plane cache, B1 / B2 find them there
-    a.cache = (!lin && ps.col.expanded) ? ps.cache : nullptr;
+    // the candidate-expanded plane of the module is shared with stage A when the slice leaves that operand whole (the column
+    // operand: weights of a Linear, B of a matmul): stage A packs all candidates into the module's plane cache once, the later
+    // stages and rounds find them there -- as the unpruned passes do
+    a.cache = ps.col.expanded ? ps.cache : nullptr;
     a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
     CHK(run_pass(c, a));
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1};
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
     b1.crange = r1; b1.scores_keep = SB; b1.no_select = true;
     CHK(run_pass(c, b1));
     pp.r_out = r2;
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(64), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     if (ps.host_sync_ok && !c.dry && !g_stat_on) {
         // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
         // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made

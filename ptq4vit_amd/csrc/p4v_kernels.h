@@ -3315,46 +3315,74 @@ __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
     }
 }
 
-struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out; };
-__global__ void k_prune_pick(PruneParams p) {          // r_out = hull over the blocks of stage A's first maxima (NaN = maximum)
-    __shared__ int lo, hi;
-    if (threadIdx.x == 0) { lo = p.C; hi = 0; }
+// torch.argmax(dim=0) over the candidates of one score block: first maximum, NaN counts as the maximum (the first NaN wins).
+// `a` beats `b` if it is NaN and b is not, or both are / neither is NaN and (its value is larger, or equal with a lower index).
+__device__ __forceinline__ bool score_beats(float av, int ai, float bv, int bi) {
+    const bool an = av != av, bn = bv != bv;
+    if (an != bn) return an;
+    if (an) return ai < bi;
+    return av > bv || (av == bv && ai < bi);
+}
+// all threads of the block (a power of two <= 256) call it with their running best; returns the block's winner to every thread
+__device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) {
+    const int t = threadIdx.x;
+    sv[t] = v; si[t] = i;
     __syncthreads();
-    for (int j = threadIdx.x; j < p.nj; j += blockDim.x) {
-        int best = 0;
-        float bv = p.SA[j];
-        bool bnan = bv != bv;
-        for (int c = 1; c < p.C; ++c) {
-            const float v = p.SA[(long)c * p.nj + j];
-            if (!bnan && (v != v || v > bv)) { best = c; bv = v; bnan = v != v; }
-        }
-        atomicMin(&lo, best); atomicMax(&hi, best + 1);
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if (t < o && score_beats(sv[t + o], si[t + o], sv[t], si[t])) { sv[t] = sv[t + o]; si[t] = si[t + o]; }
+        __syncthreads();
     }
+    const int r = si[0];
     __syncthreads();
+    return r;
+}
+struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out; };
+// (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
+__global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {     // r_out = hull over the blocks of stage A's first maxima
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    int lo = p.C, hi = 0;
+    for (int j = 0; j < p.nj; ++j) {
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < p.C; c += 256) {
+            const float v = p.SA[(long)c * p.nj + j];
+            if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
+        }
+        const int best = block_argmax(bv, bi, sv, si);
+        lo = min(lo, best); hi = max(hi, best + 1);
+    }
     if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
 }
-__global__ void k_prune_hull(PruneParams p) {
-    __shared__ int lo, hi, bad;
+__global__ __launch_bounds__(256) void k_prune_hull(PruneParams p) {
+    __shared__ float sv[256];
+    __shared__ int lo_s, hi_s, bad_s;
     const int a = p.r_in[0], b = p.r_in[1];
-    if (threadIdx.x == 0) { lo = a; hi = b; bad = 0; }
+    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; }
     __syncthreads();
-    for (int j = threadIdx.x; j < p.nj; j += blockDim.x) {
+    for (int j = 0; j < p.nj; ++j) {
+        // L* = the best complete score among stage B1's candidates
         float L = -__builtin_inff();
         bool nan = false;
-        for (int c = a; c < b; ++c) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+        for (int c = a + threadIdx.x; c < b; c += 256) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+        sv[threadIdx.x] = L;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+        L = sv[0];
+        __syncthreads();
         const float thr = L - p.margin * fabsf(L);
         int l = p.C, h = 0;
-        for (int c = 0; c < p.C; ++c) {
+        for (int c = threadIdx.x; c < p.C; c += 256) {
             const float v = p.SA[(long)c * p.nj + j];
             nan |= v != v;
             if (!(v < thr)) { l = min(l, c); h = max(h, c + 1); }
         }
-        if (nan || !(L > -__builtin_inff())) atomicOr(&bad, 1);
-        atomicMin(&lo, l); atomicMax(&hi, h);
+        if (nan || !(L > -__builtin_inff())) atomicOr(&bad_s, 1);
+        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int l = bad ? 0 : lo, h = bad ? p.C : hi;
+        int l = bad_s ? 0 : lo_s, h = bad_s ? p.C : hi_s;
         if (l == a && h == b) l = h = 0;               // nothing survives outside stage B1's range: its totals decide
         p.r_out[0] = l; p.r_out[1] = h;
     }
@@ -3382,22 +3410,24 @@ struct SelectParams {
     int scores_out_ld;
     int32_t* best_out;  // optional [nj]
 };
-__global__ void k_select(SelectParams p) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= p.nj) return;
-    int best = 0;
-    float bv = p.scores[j];
-    bool bnan = bv != bv;
-    if (p.scores_out) p.scores_out[j] = bv;
-    for (int c = 1; c < p.C; ++c) {
+__global__ __launch_bounds__(128) void k_select(SelectParams p) {          // one workgroup per score block
+    __shared__ float sv[128];
+    __shared__ int si[128];
+    const int j = blockIdx.x;
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < p.C; c += 128) {
         const float v = p.scores[(long)c * p.nj + j];
         if (p.scores_out) p.scores_out[(long)c * p.scores_out_ld + j] = v;
-        if (!bnan && (v != v || v > bv)) { best = c; bv = v; bnan = v != v; }
+        if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
     }
-    const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
-    p.interval[(long)j * p.out_js + p.out_off] = sel;
-    if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
-    if (p.best_out) p.best_out[j] = best;
+    const int best = block_argmax(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
+        p.interval[(long)j * p.out_js + p.out_off] = sel;
+        if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
+        if (p.best_out) p.best_out[j] = best;
+    }
 }
 
 }  // namespace p4v
