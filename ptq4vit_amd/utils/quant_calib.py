@@ -546,17 +546,23 @@ class HessianQuantCalibrator(QuantCalibrator):
         deterministic and every call has its own scratch (engine.workspace is per stream).
         """
         import threading
+        import time
         dev = _dev_of(self.net)
         main = torch.cuda.current_stream(dev)
         from .. import engine
         streams = engine.side_streams(dev, n_streams)
+        if not hasattr(self, "_module_ms"):
+            self._module_ms = {}
         for s in streams:
             s.wait_stream(main)                       # the captured tensors were produced on the current stream
         # the caches are freed by calibration_step2 (reference linear.py:554) while the other stream may still be
         # running: hold them until everything has been joined so that the allocator cannot hand the memory out again
         keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
         todo = list(names)
-        if os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt":
+        measured = self.net.__dict__.get("_p4v_module_ms") or {}
+        if os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt" and all(n in measured for n in names):
+            todo.sort(key=lambda n: measured[n], reverse=True)        # what each search took last time on this network
+        elif os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt":
             # longest first (by the size of what a search sweeps: rows x K x N), so that the last modules in flight are the
             # small ones and the streams run dry together; the results do not depend on the order
             def work(n):
@@ -581,8 +587,10 @@ class HessianQuantCalibrator(QuantCalibrator):
                                 return
                             n = todo.pop(0)
                         module = self.wrapped_modules[n]
+                        t_mod = time.perf_counter()
                         module.calibration_step2()
                         module.mode = "raw"
+                        self._module_ms[n] = (time.perf_counter() - t_mod) * 1e3
             except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
                 errors.append(e)
 
@@ -653,6 +661,12 @@ class HessianQuantCalibrator(QuantCalibrator):
             # balance by predicted search time (needs every module's captured size: one single-image probe forward)
             all_sizes = self._estimate_cache_bytes(names)
             costs = {n: shard.module_cost_ms(self.wrapped_modules[n], all_sizes.get(n, 0)) for n in names}
+            # from the second calibration of a network on: what every module's search actually took last time (gathered from
+            # all ranks at the end of that calibration, hence the same on every rank) -- the cost model does not know whether
+            # the exact pruning applies to a module (it depends on where raw_grad^2 sits), the clock does
+            measured = self.net.__dict__.get("_p4v_module_ms") or {}
+            if all(n in measured for n in names):
+                costs = {n: float(measured[n]) for n in names}
             owner = shard.assign_modules(self.wrapped_modules, world, costs)
         else:
             all_sizes = None
@@ -774,10 +788,16 @@ class HessianQuantCalibrator(QuantCalibrator):
             t_cap += dc
             t_cal += ds
         t_ex = 0.0
+        mine_ms = dict(getattr(self, "_module_ms", {}))
         if world > 1 and not self.sequential:
             t1 = time.time()
             shard.exchange_intervals(self.wrapped_modules, owner)
             t_ex = time.time() - t1          # includes waiting for the slowest rank's search (the collective is the barrier)
+            parts = [None] * world
+            shard.dist.all_gather_object(parts, mine_ms)                 # a few hundred floats: next calibration's LPT costs
+            mine_ms = {k: v for part in parts for k, v in (part or {}).items()}
+        if mine_ms:
+            self.net.__dict__.setdefault("_p4v_module_ms", {}).update(mine_ms)
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
         self.net.__dict__["_p4v_calibrations"] = self.net.__dict__.get("_p4v_calibrations", 0) + 1
