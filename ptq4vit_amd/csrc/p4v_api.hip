@@ -1059,6 +1059,8 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     float* S2 = c.ws.get<float>(tab);
     int* r1 = c.ws.get<int>(4);
     int* r2 = r1 + 2;
+    int* best_idx = c.ws.get<int>((size_t)std::max(1, ps.nj));
+    float* vrow = c.ws.get<float>((size_t)std::max(1, ps.cand_cs));
     if (!ps.scache) {
         sc->idx = c.ws.get<int>((size_t)segs * k);
         sc->mass = c.ws.get<float>((size_t)zrows);
@@ -1126,11 +1128,20 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     a.cache = ps.col.expanded ? ps.cache : nullptr;
     a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
     CHK(run_pass(c, a));
-    PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1};
+    // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
+    const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
+    PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
-    b1.crange = r1; b1.scores_keep = SB; b1.no_select = true;
+    b1.scores_keep = SB; b1.no_select = true;
+    if (virt) {
+        b1.eq_n = 1; b1.cache = nullptr;
+        auto swap = [&](const float*& ptr) { if (ptr == ps.cands) ptr = vrow; };
+        swap(b1.row.pk.scales); swap(b1.row2.pk.scales); swap(b1.col.pk.scales);
+        swap(b1.s1.x); swap(b1.s1.y); swap(b1.s2.x); swap(b1.s2.y);
+        b1.cands = vrow;
+    } else b1.crange = r1;
     CHK(run_pass(c, b1));
     pp.r_out = r2;
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
@@ -1141,7 +1152,12 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
         if (h[0] >= h[1]) {
-            CHK(launch_pass_select(c, ps, SB));
+            if (virt) {          // every block's only survivor is its stage-A winner: the table with those entries filled in
+                hipLaunchKernelGGL(k_fill_f32, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, -INFINITY, (int)tab);
+                hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
+                HIPCHK(hipGetLastError());
+                CHK(launch_pass_select(c, ps, S2));
+            } else CHK(launch_pass_select(c, ps, SB));
             c.ws.off = mark;
             return 0;
         }
@@ -1151,7 +1167,8 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     b2.crange = r2; b2.scores_keep = S2; b2.no_select = true;
     CHK(run_pass(c, b2));
     if (!c.dry) {
-        hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
+        if (virt) hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
+        else hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
         HIPCHK(hipGetLastError());
         CHK(launch_pass_select(c, ps, S2));
     }

@@ -3336,7 +3336,12 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) 
     __syncthreads();
     return r;
 }
-struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out; };
+// virt (several score blocks): stage B1 evaluates ONE synthetic candidate whose scale in block j is the scale of block j's own
+// stage-A winner (the blocks -- heads of a matmul, V blocks of a Linear -- are scored independently, so its score in block j IS
+// that winner's total) instead of the hull of the winners (a dozen heads: 20-30 candidates).  vrow = that candidate's row of the
+// candidate table, best[j] = the winners.
+struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out;
+                     int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow; };
 // (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
 __global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {     // r_out = hull over the blocks of stage A's first maxima
     __shared__ float sv[256];
@@ -3351,20 +3356,25 @@ __global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {     // r_ou
         }
         const int best = block_argmax(bv, bi, sv, si);
         lo = min(lo, best); hi = max(hi, best + 1);
+        if (p.virt && threadIdx.x == 0) {
+            p.best[j] = best;
+            p.vrow[j * p.cand_js + p.cand_off] = p.cands[(long)best * p.cand_cs + j * p.cand_js + p.cand_off];
+        }
     }
     if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
 }
 __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p) {
     __shared__ float sv[256];
-    __shared__ int lo_s, hi_s, bad_s;
+    __shared__ int lo_s, hi_s, bad_s, more_s;
     const int a = p.r_in[0], b = p.r_in[1];
-    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; }
+    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; more_s = 0; }
     __syncthreads();
     for (int j = 0; j < p.nj; ++j) {
-        // L* = the best complete score among stage B1's candidates
+        // L* = the best complete score among stage B1's candidates (virt: the one synthetic candidate's score in this block)
         float L = -__builtin_inff();
         bool nan = false;
-        for (int c = a + threadIdx.x; c < b; c += 256) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+        if (p.virt) { L = p.SB[j]; nan = L != L; }
+        else for (int c = a + threadIdx.x; c < b; c += 256) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
         sv[threadIdx.x] = L;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
@@ -3375,7 +3385,10 @@ __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p) {
         for (int c = threadIdx.x; c < p.C; c += 256) {
             const float v = p.SA[(long)c * p.nj + j];
             nan |= v != v;
-            if (!(v < thr)) { l = min(l, c); h = max(h, c + 1); }
+            if (!(v < thr)) {
+                l = min(l, c); h = max(h, c + 1);
+                if (p.virt && c != p.best[j]) atomicOr(&more_s, 1);     // a survivor besides the block's winner: stage B2 decides
+            }
         }
         if (nan || !(L > -__builtin_inff())) atomicOr(&bad_s, 1);
         if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
@@ -3383,9 +3396,21 @@ __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p) {
     __syncthreads();
     if (threadIdx.x == 0) {
         int l = bad_s ? 0 : lo_s, h = bad_s ? p.C : hi_s;
-        if (l == a && h == b) l = h = 0;               // nothing survives outside stage B1's range: its totals decide
+        // nothing survives outside what stage B1 evaluated: its totals decide
+        if (p.virt ? (!bad_s && !more_s) : (l == a && h == b)) l = h = 0;
         p.r_out[0] = l; p.r_out[1] = h;
     }
+}
+__global__ void k_fill_f32(float* p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// virt: the final table is stage B2's; where B2 did not run a block's winner (empty B2), the synthetic candidate's score stands in
+__global__ void k_merge_virtual(float* S2, const float* SB, const int* best, int nj) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nj) return;
+    float* d = S2 + (long)best[j] * nj + j;
+    if (*d == -__builtin_inff()) *d = SB[j];
 }
 // final score table of a pruned pass: stage B2's where it evaluated the candidate, stage B1's otherwise (the two agree bit for bit
 // where both did)
