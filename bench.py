@@ -515,7 +515,7 @@ def main():
         what = ("oracle/torch_port.py (torch-CPU restatement of the reference's calibration_step2 on all host threads, validated "
                 "against the reference's golden files)" if backend == "torch" else
                 "numpy oracle (port of the reference's calibration_step2, pinned by tests/golden)")
-        cpu = {"value": n_mod / est_s, "unit": "layers/s", "cores": threads, "kind": "port-torch" if backend == "torch" else "port",
+        cpu = {"value": n_mod / est_s, "unit": "layers/s", "cores": threads, "kind": "port", "port_backend": backend,
                "cpu_model": cpu_model, "logical_cpus": logical, "est_calibration_s": round(est_s, 1),
                "sample": f"{what}, ONE search round of each "
                          f"ViT-B/224 layer type at 4 images ({spent:.1f} s of CPU work), scaled x{args.calib / 4:g} images x 3 rounds x layer "

@@ -1,7 +1,7 @@
 """Multi-threaded torch-CPU restatement of step 2 for the five hot classes.
 
 TEST INFRASTRUCTURE ONLY, like ``oracle/ptq4vit_oracle.py``: imported by ``tests/`` and by ``bench.py``'s
-``cpu_baseline`` leg (``kind: "port-torch"``), never by ``ptq4vit_amd``.
+``cpu_baseline`` leg (``kind: "port"``, ``port_backend: "torch"``), never by ``ptq4vit_amd``.
 
 Why a second restatement: the numpy oracle is the parity checker -- written for clarity, its elementwise passes run on one
 thread.  The reference's CPU path is torch: ``F.linear`` / ``@`` / ``F.conv2d`` on all host cores and multi-threaded
