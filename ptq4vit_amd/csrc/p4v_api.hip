@@ -1004,6 +1004,81 @@ int run_pass(Ctx& c, Pass& ps) {
 // selection (tests: every parity case runs with and without it, desc.reserved bit 8 / variant 4194304 switch it off).  Everything
 // between the stages stays on the device.  Not used when the caller wants the full score tables, for the cosine metric (its
 // terms are not one-signed), for fp32 operands, or where the sample slice would not be small against the whole.
+// The sample slice of a module (see SliceCache): geometry, allocation (top of the workspace when the module keeps it, the bump
+// region otherwise) and contents (ranking, share of the metric weight, gathered rows; only what changed is redone).
+struct SliceGeo {
+    bool lin; int segs, seg_rows, k, Ncols, K;
+    const float* O; const float* G; int wt_mode; long o_ms;
+    const float* row_src; long s_r, s_k; int zdiv; long s_z2, s_z;
+};
+int slice_alloc(Ctx& c, SliceCache* sc, const SliceGeo& g, bool keep, bool bump) {
+    if (sc->assigned) {
+        if (sc->k != g.k) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
+        return 0;
+    }
+    if (!keep && !bump) return 0;                 // a pass-local slice is allocated later, in the bump region
+    const long zrows = (long)g.segs * g.seg_rows, out_elems = (long)g.segs * g.k * g.Ncols, row_elems = (long)g.segs * g.k * g.K;
+    if (keep) {
+        sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)g.segs * g.k * sizeof(int)));
+        sc->mass = reinterpret_cast<float*>(c.ws.get_top((size_t)zrows * sizeof(float)));
+        sc->Os = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
+        sc->Gs = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
+        sc->Rs = reinterpret_cast<float*>(c.ws.get_top((size_t)row_elems * sizeof(float)));
+        sc->frac = reinterpret_cast<float*>(c.ws.get_top(256));
+        sc->assigned = true;
+    } else {
+        sc->idx = c.ws.get<int>((size_t)g.segs * g.k);
+        sc->mass = c.ws.get<float>((size_t)zrows);
+        sc->Os = c.ws.get<float>((size_t)out_elems);
+        sc->Gs = c.ws.get<float>((size_t)out_elems);
+        sc->Rs = c.ws.get<float>((size_t)row_elems);
+    }
+    sc->k = g.k;
+    return 0;
+}
+int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
+    const long zrows = (long)g.segs * g.seg_rows;
+    const void* wsrc = g.G ? (const void*)g.G : (const void*)g.O;
+    const bool new_idx = sc->idx_src != wsrc || sc->idx_wt != g.wt_mode || (g.wt_mode != 1 && sc->o_src != g.O);
+    if (new_idx) {
+        // the heaviest rows of every segment by their share of the metric weight
+        hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, g.G ? g.G : g.O, g.O, zrows, (long)g.Ncols, g.wt_mode, sc->mass);
+        hipLaunchKernelGGL(k_topk_rows, dim3(g.segs), dim3(1024), 0, c.st, sc->mass, g.seg_rows, g.k, sc->idx);
+        sc->idx_src = wsrc; sc->idx_wt = g.wt_mode;
+        sc->o_src = sc->g_src = sc->r_src = nullptr;
+        if (sc->frac && host_sync_ok && !(g_variant & 8388608)) {
+            // once per module: is the slice worth it?  The bounds are as tight as the share of the metric weight the slice
+            // holds (ViT class-token rows: > 0.99; the qkv layers, whose keys and values of every token feed the class token:
+            // 0.72 -- still worth it, measured: 187 -> 168 ms per ViT-B calibration); below 0.5 most candidates survive and
+            // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
+            // (variant 8388608: always prune)
+            float f = 1.0f;
+            hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, g.segs, g.seg_rows, g.k, sc->frac);
+            HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
+            HIPCHK(hipStreamSynchronize(c.st));
+            if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, g.segs, g.k, g.seg_rows);
+            if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : 0.5f))) { sc->loose = true; return 0; }
+        }
+    }
+    const int rows = g.segs * g.k;
+    auto gather = [&](const float* src, long s0, long s3, int d3, float* dst, int seg, int zdiv, long sz2, long sz) {
+        GatherParams gp{src, s0, 0, 0, s3, 1, 1, d3, sc->idx, rows, dst, seg, zdiv, sz2, sz};
+        const long total = (long)rows * d3;
+        hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, gp);
+    };
+    const int seg = g.lin ? 0 : g.k;
+    const long o_seg = (long)g.seg_rows * g.Ncols;                // raw_out / raw_grad: dense [Z][M][N]
+    if (sc->o_src != g.O) { gather(g.O, g.o_ms, 1, g.Ncols, sc->Os, seg, 1, o_seg, 0); sc->o_src = g.O; }
+    if (g.G && sc->g_src != g.G) { gather(g.G, g.o_ms, 1, g.Ncols, sc->Gs, seg, 1, o_seg, 0); sc->g_src = g.G; }
+    if (sc->r_src != g.row_src) {
+        if (g.lin) gather(g.row_src, g.s_r, 1, g.K, sc->Rs, 0, 1, 0, 0);
+        else gather(g.row_src, g.s_r, g.s_k, g.K, sc->Rs, g.k, g.zdiv, g.s_z2, g.s_z);
+        sc->r_src = g.row_src;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 bool prune_ok(const Pass& ps) {
     if (!ps.prunable || !ps.i8 || ps.epi == EPI_COS || ps.store_out || ps.scores_out || ps.best_out || ps.crange || ps.no_select) return false;
     if ((g_variant & 4194304) || ps.eq_n < 32 || ps.nj < 1 || ps.nj > 4096) return false;
@@ -1035,23 +1110,12 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         if (ps.Mrows < 64 || ps.row_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols || ps.o_ms != ps.Ncols || ps.o_ns != 1 ||
             ps.o_bs || ps.o_nbs || ps.row.pk.zdiv <= 0 || ps.row.pk.conv) return run_pass(c, ps);
     }
-    const long zrows = (long)segs * seg_rows;                        // rows of the mass table
-    const long per_row = ps.Ncols;                                   // elements of raw_out / raw_grad per mass row
-    const long out_elems = (long)segs * k * ps.Ncols;
-    const long row_elems = (long)segs * k * ps.K;
+    SliceGeo geo{lin, segs, seg_rows, k, ps.Ncols, ps.K, ps.O, ps.G, ps.wt_mode, ps.o_ms, ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k,
+                 ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z};
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
     if (sc->loose) return run_pass(c, ps);
-    if (sc->assigned && sc->k != k) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
-    if (ps.scache && !sc->assigned) {        // top of the workspace: lives for the whole *_calibrate call
-        sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)segs * k * sizeof(int)));
-        sc->mass = reinterpret_cast<float*>(c.ws.get_top((size_t)zrows * sizeof(float)));
-        sc->Os = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
-        sc->Gs = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
-        sc->Rs = reinterpret_cast<float*>(c.ws.get_top((size_t)row_elems * sizeof(float)));
-        sc->frac = reinterpret_cast<float*>(c.ws.get_top(256));
-        sc->assigned = true; sc->k = k;
-    }
+    CHK(slice_alloc(c, sc, geo, ps.scache != nullptr, /*bump=*/false));
     const size_t mark = c.ws.off;
     const size_t tab = (size_t)ps.eq_n * std::max(1, ps.nj);
     float* SA = c.ws.get<float>(tab);
@@ -1061,56 +1125,13 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     int* r2 = r1 + 2;
     int* best_idx = c.ws.get<int>((size_t)std::max(1, ps.nj));
     float* vrow = c.ws.get<float>((size_t)std::max(1, ps.cand_cs));
-    if (!ps.scache) {
-        sc->idx = c.ws.get<int>((size_t)segs * k);
-        sc->mass = c.ws.get<float>((size_t)zrows);
-        sc->Os = c.ws.get<float>((size_t)out_elems);
-        sc->Gs = c.ws.get<float>((size_t)out_elems);
-        sc->Rs = c.ws.get<float>((size_t)row_elems);
-        sc->k = k;
-    }
+    if (!ps.scache) CHK(slice_alloc(c, sc, geo, false, /*bump=*/true));
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     float *Os = sc->Os, *Gs = ps.G ? sc->Gs : nullptr, *Rs = sc->Rs;
     Pass a = ps;
     if (!c.dry) {
-        const void* wsrc = ps.G ? (const void*)ps.G : (const void*)ps.O;
-        const bool new_idx = sc->idx_src != wsrc || sc->idx_wt != ps.wt_mode || (ps.wt_mode != 1 && sc->o_src != ps.O);
-        if (new_idx) {
-            // the heaviest rows of every segment by their share of the metric weight
-            hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, ps.G ? ps.G : ps.O, ps.O, zrows, per_row, ps.wt_mode, sc->mass);
-            hipLaunchKernelGGL(k_topk_rows, dim3(segs), dim3(1024), 0, c.st, sc->mass, seg_rows, k, sc->idx);
-            sc->idx_src = wsrc; sc->idx_wt = ps.wt_mode;
-            sc->o_src = sc->g_src = sc->r_src = nullptr;
-            if (sc->frac && ps.host_sync_ok && !(g_variant & 8388608)) {
-                // once per module: is the slice worth it?  The bounds are as tight as the share of the metric weight the slice
-                // holds (ViT class-token rows: > 0.99; the qkv layers, whose keys and values of every token feed the class token:
-                // 0.72 -- still worth it, measured: 187 -> 168 ms per ViT-B calibration); below 0.5 most candidates survive and
-                // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
-                // (variant 8388608: always prune)
-                float f = 1.0f;
-                hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, segs, seg_rows, k, sc->frac);
-                HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
-                HIPCHK(hipStreamSynchronize(c.st));
-                if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, segs, k, seg_rows);
-                if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : 0.5f))) { sc->loose = true; c.ws.off = mark; return run_pass(c, ps); }
-            }
-        }
-        const int rows = segs * k;
-        auto gather = [&](const float* src, long s0, long s3, int d3, float* dst, int seg, int zdiv, long sz2, long sz) {
-            GatherParams gp{src, s0, 0, 0, s3, 1, 1, d3, sc->idx, rows, dst, seg, zdiv, sz2, sz};
-            const long total = (long)rows * d3;
-            hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, gp);
-        };
-        const int seg = lin ? 0 : k;
-        const long o_seg = (long)ps.Mrows * ps.Ncols;                // raw_out / raw_grad: dense [Z][M][N]
-        if (sc->o_src != ps.O) { gather(ps.O, ps.o_ms, 1, ps.Ncols, Os, seg, 1, o_seg, 0); sc->o_src = ps.O; }
-        if (Gs && sc->g_src != ps.G) { gather(ps.G, ps.o_ms, 1, ps.Ncols, Gs, seg, 1, o_seg, 0); sc->g_src = ps.G; }
-        if (sc->r_src != ps.row.pk.src) {
-            if (lin) gather(ps.row.pk.src, ps.row.pk.s_r, 1, ps.K, Rs, 0, 1, 0, 0);
-            else gather(ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k, ps.K, Rs, k, ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z);
-            sc->r_src = ps.row.pk.src;
-        }
-        HIPCHK(hipGetLastError());
+        CHK(slice_fill(c, sc, geo, ps.host_sync_ok));
+        if (sc->loose) { c.ws.off = mark; return run_pass(c, ps); }
     }
     // stage A: all candidates on the slice
     a.O = Os; a.G = ps.G ? Gs : nullptr;
@@ -1178,6 +1199,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
 
 // ---- split search of the split-of-softmax matmul in one kernel (k_sos_split) -------------------------------------------------
 struct SosSplitJob {
+    SliceCache* scache; bool host_sync_ok, prunable;      // exact candidate pruning (run_sos_split_pruned)
     SosSplitParams kp;
     int epi; double norm;
     const float* cands; float* split; float* A_iv; float aux_div;
@@ -1208,25 +1230,30 @@ template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int 
     HIPCHK(hipGetLastError());
     return 0;
 }
-int run_sos_split(Ctx& c, SosSplitJob& j) {
-    SosSplitParams& kp = j.kp;
-    const size_t mark = c.ws.off;
+// one launch of the split-search kernel on `kp` (+ k_finish into `scores`, [C] floats); `crange`: device-side candidate range
+int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, float* scores) {
     const int slots = kp.halves * 4;
     float* part = c.ws.get<float>((size_t)kp.C * kp.Z * slots);
-    float* scores = c.ws.get<float>((size_t)kp.C);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
-    kp.part = part;
+    kp.part = part; kp.crange = crange;
     if (!c.dry) {
         HIPCHK(hipMemsetAsync(part, 0, sizeof(float) * (size_t)kp.C * kp.Z * slots, c.st));   // slots of all-padding waves
         const bool timed = g_stat_on;
         StatRec rec{};
         const int KS = kp.K <= 64 ? 32 : kp.K <= 144 ? 72 : 100;
         if (timed) {
+            double frac = 1.0;
+            if (crange) {
+                int h[2] = {0, kp.C};
+                HIPCHK(hipMemcpyAsync(h, crange, sizeof h, hipMemcpyDeviceToHost, c.st));
+                HIPCHK(hipStreamSynchronize(c.st));
+                frac = (double)std::max(0, std::min(h[1], kp.C) - std::max(h[0], 0)) / kp.C;
+            }
             HIPCHK(hipEventCreate(&rec.a));
             HIPCHK(hipEventCreate(&rec.b));
             rec.kind = 1;
-            rec.macs = (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C;
-            rec.alg = (double)kp.Z * kp.M * kp.K * kp.N * kp.C;
+            rec.macs = frac * (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C;
+            rec.alg = frac * (double)kp.Z * kp.M * kp.K * kp.N * kp.C;
             HIPCHK(hipEventRecord(rec.a, c.st));
         }
         if (KS == 32) CHK(launch_sos_split_ks<32>(c, kp, j.epi));
@@ -1234,13 +1261,68 @@ int run_sos_split(Ctx& c, SosSplitJob& j) {
         else CHK(launch_sos_split_ks<100>(c, kp, j.epi));
         if (timed) {
             HIPCHK(hipEventRecord(rec.b, c.st));
-            rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
+            g_stat_recs.push_back(rec);
         }
     }
-    FinishParams fp{part, (long)kp.Z * slots, (long)slots, slots, 1, kp.Z, slots, kp.C, 0, 1, 1, j.norm, scores};
-    CHK(launch_finish(c, fp));
-    SelectParams sl{scores, kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
-    CHK(launch_select(c, sl));
+    FinishParams fp{part, (long)kp.Z * slots, (long)slots, slots, 1, kp.Z, slots, kp.C, 0, 1, 1, j.norm, scores, crange};
+    return launch_finish(c, fp);
+}
+int sos_select(Ctx& c, SosSplitJob& j, const float* scores) {
+    SelectParams sl{scores, j.kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
+    return launch_select(c, sl);
+}
+int run_sos_split(Ctx& c, SosSplitJob& j) {
+    const size_t mark = c.ws.off;
+    float* scores = c.ws.get<float>((size_t)j.kp.C);
+    CHK(sos_sweep(c, j, j.kp, nullptr, scores));
+    CHK(sos_select(c, j, scores));
+    c.ws.off = mark;
+    return 0;
+}
+// The split search with the exact pruning of run_pass_pruned: the 20 splits on the 16 heaviest query rows of every (image, head),
+// the winner on everything (the bound), whatever survives on everything.  Runs once per module (its result does not depend on
+// the intervals: the later rounds are memo hits), before any other pass of the module -- it is what builds the module's slice.
+int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
+    const SosSplitParams& kp = j.kp;
+    const int k = 16;
+    if (!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304) || kp.M < 64 || j.scache->loose)
+        return run_sos_split(c, j);
+    SliceGeo geo{false, kp.Z, kp.M, k, kp.N, kp.K, kp.O, (kp.wt_mode == 1 ? kp.G : nullptr), kp.wt_mode, (long)kp.N, kp.A, kp.a_r, kp.a_k,
+                 kp.zdiv, kp.a_z2, kp.a_z};
+    SliceCache* sc = j.scache;
+    CHK(slice_alloc(c, sc, geo, true, false));
+    const size_t mark = c.ws.off;
+    float* SA = c.ws.get<float>((size_t)kp.C);
+    float* SB = c.ws.get<float>((size_t)kp.C);
+    float* S2 = c.ws.get<float>((size_t)kp.C);
+    int* r1 = c.ws.get<int>(4);
+    int* r2 = r1 + 2;
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    if (!c.dry) {
+        CHK(slice_fill(c, sc, geo, j.host_sync_ok));
+        if (sc->loose) { c.ws.off = mark; return run_sos_split(c, j); }
+    }
+    SosSplitParams a = kp;                       // stage A: dense slices [Z][16][K] / [Z][16][N]
+    a.A = sc->Rs; a.a_k = 1; a.a_r = kp.K; a.a_z = (long)k * kp.K; a.a_z2 = (long)kp.zdiv * k * kp.K;
+    a.O = sc->Os; a.G = (kp.wt_mode == 1) ? sc->Gs : sc->Os; a.M = k; a.halves = 1;
+    CHK(sos_sweep(c, j, a, nullptr, SA));
+    PruneParams pp{SA, SB, kp.C, 1, 1e-4f, r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    CHK(sos_sweep(c, j, kp, r1, SB));             // B1
+    pp.r_out = r2;
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    if (j.host_sync_ok && !c.dry && !g_stat_on) {
+        int h[2] = {0, 1};
+        HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
+        HIPCHK(hipStreamSynchronize(c.st));
+        if (h[0] >= h[1]) { CHK(sos_select(c, j, SB)); c.ws.off = mark; return 0; }
+    }
+    CHK(sos_sweep(c, j, kp, r2, S2));             // B2
+    if (!c.dry) {
+        hipLaunchKernelGGL(k_merge_scores, dim3(1), dim3(256), 0, c.st, S2, SB, kp.C);
+        HIPCHK(hipGetLastError());
+    }
+    CHK(sos_select(c, j, S2));
     c.ws.off = mark;
     return 0;
 }
@@ -1712,7 +1794,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
             j.epi = epi; j.norm = 1.0 / ((double)H * M * N);
             j.cands = split_cands; j.split = split; j.A_iv = A_iv; j.aux_div = (float)(Aq - 1);   // A_interval = split/(qmax-1) (matmul.py:629)
             j.scores_out = (d->eq_n >= NSPLIT) ? so : nullptr; j.scores_out_ld = H; j.best_out = bo;
-            CHK(run_sos_split(c, j));
+            j.scache = &slice; j.host_sync_ok = memo_on; j.prunable = !(d->reserved & 8);
+            CHK(run_sos_split_pruned(c, j));
         } else {
             // ---- split search against the UNQUANTISED B (matmul.py:600-631): fp32 operands ----
             Pass ps{};

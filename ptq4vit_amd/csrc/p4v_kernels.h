@@ -2974,6 +2974,7 @@ struct SosSplitParams {
     float qm1, c_inv, lo_top;              // q-1, fl(1 / (q-1)), min(rint(fl(1 / c_inv)), q-1)
     float* part;                           // [C][Z][halves * 4]
     int halves;
+    const int* crange;                     // optional device-side candidate range (clip_crange)
 };
 
 #ifndef P4V_SOS_DBG
@@ -3028,7 +3029,9 @@ __global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
 
     typedef float v16f __attribute__((ext_vector_type(16)));
     const float* b0 = Bt + g * 64 + l31;      // B fragment of k-step ks, column block cb: b0[ks * 128 + cb * 32]
-    for (int c = 0; c < p.C; ++c) {
+    int c_lo_ = 0, c_hi_ = p.C;
+    clip_crange(p.crange, c_lo_, c_hi_);
+    for (int c = c_lo_; c < c_hi_; ++c) {
         const float s = p.splits[c];
         const float inv_s = 1.0f / s;                           // 2^i, exact
         const float a_int = s / p.qm1;                          // matmul.py:609
