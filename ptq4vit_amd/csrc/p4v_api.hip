@@ -674,6 +674,7 @@ struct Pass {
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
+    float* S1_pre; float* S2_pre; bool s_ready;   // scale tables shared by the stages of a pruned pass (same table, same scales)
     SliceCache* scache;       // optional: the module's sample slice, shared by its pruned passes
     bool host_sync_ok;        // the caller synchronises the stream after the pass anyway (pass memo): the pruned pass may read
                               // the 8-byte survivor range back and skip the launches of an empty stage B2
@@ -768,8 +769,8 @@ int run_pass(Ctx& c, Pass& ps) {
     const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
-    float* S1 = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
-    float* S2 = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
+    float* S1 = !ps.use_s1 ? nullptr : ps.S1_pre ? ps.S1_pre : c.ws.get<float>((size_t)ps.eq_n * ps.s_cs);
+    float* S2 = !(ps.use_s1 && ps.twin) ? nullptr : ps.S2_pre ? ps.S2_pre : c.ws.get<float>((size_t)ps.eq_n * ps.s_cs);
     float* scores = ps.scores_keep ? ps.scores_keep : c.ws.get<float>((size_t)ps.eq_n * std::max(1, ps.nj));
     float* zero_bias = (stat_ok && !ps.bias) ? c.ws.get<float>((size_t)std::max(Mp, Np)) : nullptr;
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
@@ -808,7 +809,7 @@ int run_pass(Ctx& c, Pass& ps) {
     }
 
     if (zero_bias && !c.dry) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
-    if (ps.use_s1) {
+    if (ps.use_s1 && !ps.s_ready) {
         ps.s1.S = S1; ps.s1.C = ps.eq_n; ps.s1.nblk = ps.s_cs;
         CHK(launch_scale(c, ps.s1));
         if (ps.twin) { ps.s2.S = S2; ps.s2.C = ps.eq_n; ps.s2.nblk = ps.s_cs; CHK(launch_scale(c, ps.s2)); }
@@ -1125,6 +1126,8 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     int* r2 = r1 + 2;
     int* best_idx = c.ws.get<int>((size_t)std::max(1, ps.nj));
     float* vrow = c.ws.get<float>((size_t)std::max(1, ps.cand_cs));
+    float* S1s = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;             // one scale table for all stages
+    float* S2s = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
     if (!ps.scache) CHK(slice_alloc(c, sc, geo, false, /*bump=*/true));
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     float *Os = sc->Os, *Gs = ps.G ? sc->Gs : nullptr, *Rs = sc->Rs;
@@ -1148,6 +1151,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     // stages and rounds find them there -- as the unpruned passes do
     a.cache = ps.col.expanded ? ps.cache : nullptr;
     a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
+    a.S1_pre = S1s; a.S2_pre = S2s; a.s_ready = false;
     CHK(run_pass(c, a));
     // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
@@ -1156,6 +1160,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
     b1.scores_keep = SB; b1.no_select = true;
+    if (!virt) { b1.S1_pre = S1s; b1.S2_pre = S2s; b1.s_ready = true; }
     if (virt) {
         b1.eq_n = 1; b1.cache = nullptr;
         auto swap = [&](const float*& ptr) { if (ptr == ps.cands) ptr = vrow; };
@@ -1186,6 +1191,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     // stage B2: whatever else survives, on all samples (an empty range when stage B1 already covers the survivors)
     Pass b2 = ps;
     b2.crange = r2; b2.scores_keep = S2; b2.no_select = true;
+    b2.S1_pre = S1s; b2.S2_pre = S2s; b2.s_ready = true;
     CHK(run_pass(c, b2));
     if (!c.dry) {
         if (virt) hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
