@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--capture-batch", type=int, default=0,
                     help="images per capture pass of the timed steps (0 = batch_size = 4, the reference's passes)")
     ap.add_argument("--tune", default="", help="key=value,... engine tuning overrides (p4v_debug_set_tuning), experiments only")
+    ap.add_argument("--variant", type=int, default=0, help="engine A/B switch word (p4v_debug_set_variant), experiments only: use with --no-roofline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -322,6 +323,8 @@ def main():
 
     for kv in filter(None, args.tune.split(",")):
         engine.debug_tuning(*(int(v) for v in kv.split("=")))
+    if args.variant:
+        engine.debug_variant(args.variant)
     net = models.get_net(args.model, seed=0, device=dev)
     if args.bits != 8:      # what the reference's drivers do to the config module (example/test_all.py:53-78)
         PTQ4ViT.bit = args.bits

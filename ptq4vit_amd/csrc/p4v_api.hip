@@ -827,11 +827,7 @@ int run_pass(Ctx& c, Pass& ps) {
             pk.done = (pc && pc->done) ? pc->done : nullptr;
         }
         CHK(ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk));
-        if (op.expanded && ps.crange && pc && pc->done && !c.dry) {
-            hipLaunchKernelGGL(k_mark_done, dim3(cdiv(pack_groups, 64)), dim3(64), 0, c.st, pc->done, pack_groups, ps.crange, c0);
-            HIPCHK(hipGetLastError());
-        }
-        return 0;
+        return 0;      // (the finish of this pass flags the groups as packed: FinishParams.mark_done)
     };
     // fixed planes once
     if (merged7) {
@@ -852,7 +848,7 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.row.expanded && !packed) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
-        if (pc && !ps.crange) {          // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
+        if (pc && !ps.crange && !packed) {   // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
             pc->valid = true;
             if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)pack_groups, c.st));
         }
@@ -970,9 +966,13 @@ int run_pass(Ctx& c, Pass& ps) {
     }
     g_exec_frac = 1.0;
     if (ps.store_out) { c.ws.off = mark; return 0; }
+    auto with_marks = [&](FinishParams& fp) {     // a pruned pass flags the candidate groups it packed into the module's plane
+        if (ps.crange && pc && pc->done) { fp.mark_done = pc->done; fp.mark_groups = pack_groups; }
+    };
     if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
         const int slots = nine_halves * SW9_NW;
         FinishParams fp{part, (long)slots * ps.Z, (long)slots, slots, 1, ps.Z, slots, ps.eq_n, ps.j_mode, std::max(1, ps.j_div), ps.nj, ps.norm, scores, ps.crange};
+        with_marks(fp);
         CHK(launch_finish(c, fp));
     } else if (!cosm) {
         const int gdiv = stat_ok ? s3_gw : 32;
@@ -982,6 +982,7 @@ int run_pass(Ctx& c, Pass& ps) {
                                      : fast ? cdiv(ps.Ncols, 32) : ps.Ncols;
         FinishParams fp{part, p_cs, p_zs, NpP, stat_ok ? s3_slabs : big7 ? MT7 : MT, ps.Z, fin_cols, ps.eq_n, ps.j_mode,
                         std::max(1, (fast || stat_ok) && ps.j_mode == 1 ? cdiv(ps.j_div, gdiv) : ps.j_div), ps.nj, ps.norm, scores, ps.crange};
+        with_marks(fp);
         CHK(launch_finish(c, fp));
     } else {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
@@ -1152,10 +1153,10 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     a.cache = ps.col.expanded ? ps.cache : nullptr;
     a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
     a.S1_pre = S1s; a.S2_pre = S2s; a.s_ready = false;
-    CHK(run_pass(c, a));
     // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
+    CHK(run_pass(c, a));
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
@@ -1169,8 +1170,12 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         b1.cands = vrow;
     } else b1.crange = r1;
     CHK(run_pass(c, b1));
+    // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2;
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    const bool hull_selects = !ps.scores_out && ps.interval;
+    SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
+                     ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl); HIPCHK(hipGetLastError()); }
     if (ps.host_sync_ok && !c.dry && !g_stat_on) {
         // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
         // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made
@@ -1178,7 +1183,8 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
         if (h[0] >= h[1]) {
-            if (virt) {          // every block's only survivor is its stage-A winner: the table with those entries filled in
+            if (hull_selects) {}          // k_prune_hull made the selection
+            else if (virt) {          // every block's only survivor is its stage-A winner: the table with those entries filled in
                 hipLaunchKernelGGL(k_fill_f32, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, -INFINITY, (int)tab);
                 hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
                 HIPCHK(hipGetLastError());
@@ -1237,6 +1243,9 @@ template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int 
     return 0;
 }
 // one launch of the split-search kernel on `kp` (+ k_finish into `scores`, [C] floats); `crange`: device-side candidate range
+SelectParams sos_select_params(const SosSplitJob& j, const float* scores) {
+    return SelectParams{scores, j.kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
+}
 int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, float* scores) {
     const int slots = kp.halves * 4;
     float* part = c.ws.get<float>((size_t)kp.C * kp.Z * slots);
@@ -1274,8 +1283,7 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
     return launch_finish(c, fp);
 }
 int sos_select(Ctx& c, SosSplitJob& j, const float* scores) {
-    SelectParams sl{scores, j.kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
-    return launch_select(c, sl);
+    return launch_select(c, sos_select_params(j, scores));
 }
 int run_sos_split(Ctx& c, SosSplitJob& j) {
     const size_t mark = c.ws.off;
@@ -1311,17 +1319,17 @@ int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
     SosSplitParams a = kp;                       // stage A: dense slices [Z][16][K] / [Z][16][N]
     a.A = sc->Rs; a.a_k = 1; a.a_r = kp.K; a.a_z = (long)k * kp.K; a.a_z2 = (long)kp.zdiv * k * kp.K;
     a.O = sc->Os; a.G = (kp.wt_mode == 1) ? sc->Gs : sc->Os; a.M = k; a.halves = 1;
-    CHK(sos_sweep(c, j, a, nullptr, SA));
     PruneParams pp{SA, SB, kp.C, 1, 1e-4f, r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
+    CHK(sos_sweep(c, j, a, nullptr, SA));
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     CHK(sos_sweep(c, j, kp, r1, SB));             // B1
-    pp.r_out = r2;
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    pp.r_out = r2;                                // (+ the selection from its totals when nothing else survives)
+    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, sos_select_params(j, SB)); HIPCHK(hipGetLastError()); }
     if (j.host_sync_ok && !c.dry && !g_stat_on) {
         int h[2] = {0, 1};
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
-        if (h[0] >= h[1]) { CHK(sos_select(c, j, SB)); c.ws.off = mark; return 0; }
+        if (h[0] >= h[1]) { c.ws.off = mark; return 0; }
     }
     CHK(sos_sweep(c, j, kp, r2, S2));             // B2
     if (!c.dry) {

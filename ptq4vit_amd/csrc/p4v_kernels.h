@@ -3086,6 +3086,158 @@ __global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
 // ------------------------------------------------------------------------------------------
 // k_finish / k_select
 // ------------------------------------------------------------------------------------------
+// torch.argmax(dim=0) over the candidates of one score block: first maximum, NaN counts as the maximum (the first NaN wins).
+// `a` beats `b` if it is NaN and b is not, or both are / neither is NaN and (its value is larger, or equal with a lower index).
+__device__ __forceinline__ bool score_beats(float av, int ai, float bv, int bi) {
+    const bool an = av != av, bn = bv != bv;
+    if (an != bn) return an;
+    if (an) return ai < bi;
+    return av > bv || (av == bv && ai < bi);
+}
+// all threads of the block (a power of two <= 256) call it with their running best; returns the block's winner to every thread
+__device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) {
+    const int t = threadIdx.x;
+    sv[t] = v; si[t] = i;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if (t < o && score_beats(sv[t + o], si[t + o], sv[t], si[t])) { sv[t] = sv[t + o]; si[t] = si[t + o]; }
+        __syncthreads();
+    }
+    const int r = si[0];
+    __syncthreads();
+    return r;
+}
+
+struct SelectParams {
+    const float* scores; int C, nj;
+    const float* cands; int cand_cs, cand_js, cand_off;  // cands[best*cand_cs + j*cand_js + cand_off]
+    float* interval; int out_js, out_off;
+    float* aux_out; float aux_div;                        // optional: aux_out[0] = selected / aux_div (SoS A_interval)
+    float* scores_out;  // optional copy [C][scores_out_ld]
+    int scores_out_ld;
+    int32_t* best_out;  // optional [nj]
+};
+// the selection of score block j over the candidates [c_lo, c_hi) (all threads of the workgroup; sv / si: blockDim.x entries)
+__device__ __forceinline__ void select_block(const SelectParams& p, int j, int c_lo, int c_hi, float* sv, int* si) {
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
+        const float v = p.scores[(long)c * p.nj + j];
+        if (p.scores_out) p.scores_out[(long)c * p.scores_out_ld + j] = v;
+        if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
+    }
+    const int best = block_argmax(bv, bi, sv, si);
+    if (threadIdx.x == 0) {
+        const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
+        p.interval[(long)j * p.out_js + p.out_off] = sel;
+        if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
+        if (p.best_out) p.best_out[j] = best;
+    }
+}
+__global__ __launch_bounds__(128) void k_select(SelectParams p) {          // one workgroup per score block
+    __shared__ float sv[128];
+    __shared__ int si[128];
+    select_block(p, blockIdx.x, 0, p.C, sv, si);
+}
+
+// ---- exact candidate pruning: the kernels between the stages (run_pass_pruned, p4v_api.hip) ------------------------------------
+// virt (several score blocks): stage B1 evaluates ONE synthetic candidate whose scale in block j is the scale of block j's own
+// stage-A winner (the blocks -- heads of a matmul, V blocks of a Linear -- are scored independently, so its score in block j IS
+// that winner's total) instead of the hull of the winners (a dozen heads: 20-30 candidates).  vrow = that candidate's row of the
+// candidate table, best[j] = the winners.
+struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out;
+                     int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow; };
+// (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
+// r_out = hull over the blocks of stage A's first maxima
+__device__ __forceinline__ void prune_pick(const PruneParams& p, float* sv, int* si) {
+    int lo = p.C, hi = 0;
+    for (int j = 0; j < p.nj; ++j) {
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < p.C; c += 256) {
+            const float v = p.SA[(long)c * p.nj + j];
+            if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
+        }
+        const int best = block_argmax(bv, bi, sv, si);
+        lo = min(lo, best); hi = max(hi, best + 1);
+        if (p.virt && threadIdx.x == 0) {
+            p.best[j] = best;
+            p.vrow[j * p.cand_js + p.cand_off] = p.cands[(long)best * p.cand_cs + j * p.cand_js + p.cand_off];
+        }
+    }
+    if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
+}
+__global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    prune_pick(p, sv, si);
+}
+// r_out = what stage B2 has to evaluate: the hull of the candidates whose stage-A bound reaches the best complete score, or the
+// empty range when stage B1 already evaluated all of them.  Returns (to every thread) whether the range is empty.
+__device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int* sh) {
+    int &lo_s = sh[0], &hi_s = sh[1], &bad_s = sh[2], &more_s = sh[3], &empty_s = sh[4];
+    const int a = p.r_in[0], b = p.r_in[1];
+    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; more_s = 0; }
+    __syncthreads();
+    for (int j = 0; j < p.nj; ++j) {
+        // L* = the best complete score among stage B1's candidates (virt: the one synthetic candidate's score in this block)
+        float L = -__builtin_inff();
+        bool nan = false;
+        if (p.virt) { L = p.SB[j]; nan = L != L; }
+        else for (int c = a + threadIdx.x; c < b; c += 256) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+        sv[threadIdx.x] = L;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
+        L = sv[0];
+        __syncthreads();
+        const float thr = L - p.margin * fabsf(L);
+        int l = p.C, h = 0;
+        for (int c = threadIdx.x; c < p.C; c += 256) {
+            const float v = p.SA[(long)c * p.nj + j];
+            nan |= v != v;
+            if (!(v < thr)) {
+                l = min(l, c); h = max(h, c + 1);
+                if (p.virt && c != p.best[j]) atomicOr(&more_s, 1);     // a survivor besides the block's winner: stage B2 decides
+            }
+        }
+        if (nan || !(L > -__builtin_inff())) atomicOr(&bad_s, 1);
+        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int l = bad_s ? 0 : lo_s, h = bad_s ? p.C : hi_s;
+        // nothing survives outside what stage B1 evaluated: its totals decide
+        if (p.virt ? (!bad_s && !more_s) : (l == a && h == b)) l = h = 0;
+        p.r_out[0] = l; p.r_out[1] = h;
+        empty_s = l >= h;
+    }
+    __syncthreads();
+    return empty_s != 0;
+}
+// ... and, when the range is empty, the pass's selection (sl.interval != nullptr) from stage B1's totals: what k_select would pick
+// from the table that holds them and -inf elsewhere.  (Tried and dropped: running these one-workgroup steps as the tail of the last
+// workgroup of k_finish -- the agent-scope release/acquire it needs writes back and invalidates the L2 of every XCD per workgroup;
+// +20 us per k_finish, 3 ms per calibration slower than the separate launches.)
+__global__ __launch_bounds__(256) void k_prune_hull(PruneParams p, SelectParams sl) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ int sh[8];
+    const bool empty = prune_hull(p, sv, sh);
+    if (!empty || !sl.interval) return;
+    if (p.virt) {                                  // every block's only survivor is its stage-A winner
+        for (int j = threadIdx.x; j < sl.nj; j += 256) {
+            const int best = p.best[j];
+            const float sel = sl.cands[(long)best * sl.cand_cs + (long)j * sl.cand_js + sl.cand_off];
+            sl.interval[(long)j * sl.out_js + sl.out_off] = sel;
+            if (sl.aux_out) sl.aux_out[j] = sel / sl.aux_div;
+            if (sl.best_out) sl.best_out[j] = best;
+        }
+    } else {
+        const int a = p.r_in[0], b = p.r_in[1];
+        for (int j = 0; j < sl.nj; ++j) select_block(sl, j, a, b, sv, si);
+    }
+}
+
 struct FinishParams {
     const float* part; long p_cs, p_zs; int Np, MT, Z, N, C;
     int j_mode, j_div;     // 0: one block; 1: j = n / j_div; 2: j = z % j_div; 3: j = n
@@ -3093,38 +3245,45 @@ struct FinishParams {
     double norm;           // score = -norm * sum
     float* scores;         // [C][nj]
     const int* crange;     // optional: candidates outside [crange[0], crange[1]) were not evaluated -> score -inf
+    unsigned char* mark_done; int mark_groups;   // optional, with crange: the pack groups this pass packed into the module's plane
 };
 
 // One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
 // fixed-shape tree: the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void k_finish(FinishParams p) {
     const int c = blockIdx.x, j = blockIdx.y;
+    __shared__ double red[256];
+    if (p.mark_done && c == 0 && j == 0) {
+        // (k_pack read the flags earlier on this stream; the next reader is a later launch)
+        const int a = p.crange[0], b = p.crange[1];
+        for (int g = threadIdx.x; g < p.mark_groups; g += 256)
+            if (g * PACK_CG < b && (g + 1) * PACK_CG > a) p.mark_done[g] = 1;
+    }
     if (p.crange && (c < p.crange[0] || c >= p.crange[1])) {
         if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = -__builtin_inff();
-        return;
-    }
-    int nlo = 0, nhi = p.N, zstep = 1, zlo = 0;
-    if (p.j_mode == 1) { nlo = j * p.j_div; nhi = min(p.N, nlo + p.j_div); if (j == p.nj - 1) nhi = p.N; }
-    else if (p.j_mode == 3) { nlo = j; nhi = j + 1; }
-    else if (p.j_mode == 2) { zlo = j; zstep = p.j_div; }
-    const int wn = nhi - nlo;
-    const int nz = (p.Z - zlo + zstep - 1) / zstep;
-    const long total = (long)nz * p.MT * wn;
-    double s = 0.0;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int nn = (int)(i % wn);
-        const int mt = (int)((i / wn) % p.MT);
-        const int zz = zlo + (int)(i / ((long)wn * p.MT)) * zstep;
-        s += (double)p.part[(long)c * p.p_cs + (long)zz * p.p_zs + (long)mt * p.Np + nlo + nn];
-    }
-    __shared__ double red[256];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    } else {
+        int nlo = 0, nhi = p.N, zstep = 1, zlo = 0;
+        if (p.j_mode == 1) { nlo = j * p.j_div; nhi = min(p.N, nlo + p.j_div); if (j == p.nj - 1) nhi = p.N; }
+        else if (p.j_mode == 3) { nlo = j; nhi = j + 1; }
+        else if (p.j_mode == 2) { zlo = j; zstep = p.j_div; }
+        const int wn = nhi - nlo;
+        const int nz = (p.Z - zlo + zstep - 1) / zstep;
+        const long total = (long)nz * p.MT * wn;
+        double s = 0.0;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int nn = (int)(i % wn);
+            const int mt = (int)((i / wn) % p.MT);
+            const int zz = zlo + (int)(i / ((long)wn * p.MT)) * zstep;
+            s += (double)p.part[(long)c * p.p_cs + (long)zz * p.p_zs + (long)mt * p.Np + nlo + nn];
+        }
+        red[threadIdx.x] = s;
         __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(-p.norm * red[0]);
     }
-    if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(-p.norm * red[0]);
 }
 
 // Cosine finish.  `part` holds triples (dot, |sim|^2, |raw|^2) laid out [C][ZB][ZV][FS][Sp][3]:
@@ -3318,92 +3477,6 @@ __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
     }
 }
 
-// torch.argmax(dim=0) over the candidates of one score block: first maximum, NaN counts as the maximum (the first NaN wins).
-// `a` beats `b` if it is NaN and b is not, or both are / neither is NaN and (its value is larger, or equal with a lower index).
-__device__ __forceinline__ bool score_beats(float av, int ai, float bv, int bi) {
-    const bool an = av != av, bn = bv != bv;
-    if (an != bn) return an;
-    if (an) return ai < bi;
-    return av > bv || (av == bv && ai < bi);
-}
-// all threads of the block (a power of two <= 256) call it with their running best; returns the block's winner to every thread
-__device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) {
-    const int t = threadIdx.x;
-    sv[t] = v; si[t] = i;
-    __syncthreads();
-    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-        if (t < o && score_beats(sv[t + o], si[t + o], sv[t], si[t])) { sv[t] = sv[t + o]; si[t] = si[t + o]; }
-        __syncthreads();
-    }
-    const int r = si[0];
-    __syncthreads();
-    return r;
-}
-// virt (several score blocks): stage B1 evaluates ONE synthetic candidate whose scale in block j is the scale of block j's own
-// stage-A winner (the blocks -- heads of a matmul, V blocks of a Linear -- are scored independently, so its score in block j IS
-// that winner's total) instead of the hull of the winners (a dozen heads: 20-30 candidates).  vrow = that candidate's row of the
-// candidate table, best[j] = the winners.
-struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out;
-                     int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow; };
-// (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
-__global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {     // r_out = hull over the blocks of stage A's first maxima
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    int lo = p.C, hi = 0;
-    for (int j = 0; j < p.nj; ++j) {
-        float bv = -__builtin_inff();
-        int bi = 0x7fffffff;
-        for (int c = threadIdx.x; c < p.C; c += 256) {
-            const float v = p.SA[(long)c * p.nj + j];
-            if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
-        }
-        const int best = block_argmax(bv, bi, sv, si);
-        lo = min(lo, best); hi = max(hi, best + 1);
-        if (p.virt && threadIdx.x == 0) {
-            p.best[j] = best;
-            p.vrow[j * p.cand_js + p.cand_off] = p.cands[(long)best * p.cand_cs + j * p.cand_js + p.cand_off];
-        }
-    }
-    if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
-}
-__global__ __launch_bounds__(256) void k_prune_hull(PruneParams p) {
-    __shared__ float sv[256];
-    __shared__ int lo_s, hi_s, bad_s, more_s;
-    const int a = p.r_in[0], b = p.r_in[1];
-    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; more_s = 0; }
-    __syncthreads();
-    for (int j = 0; j < p.nj; ++j) {
-        // L* = the best complete score among stage B1's candidates (virt: the one synthetic candidate's score in this block)
-        float L = -__builtin_inff();
-        bool nan = false;
-        if (p.virt) { L = p.SB[j]; nan = L != L; }
-        else for (int c = a + threadIdx.x; c < b; c += 256) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
-        sv[threadIdx.x] = L;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + o]); __syncthreads(); }
-        L = sv[0];
-        __syncthreads();
-        const float thr = L - p.margin * fabsf(L);
-        int l = p.C, h = 0;
-        for (int c = threadIdx.x; c < p.C; c += 256) {
-            const float v = p.SA[(long)c * p.nj + j];
-            nan |= v != v;
-            if (!(v < thr)) {
-                l = min(l, c); h = max(h, c + 1);
-                if (p.virt && c != p.best[j]) atomicOr(&more_s, 1);     // a survivor besides the block's winner: stage B2 decides
-            }
-        }
-        if (nan || !(L > -__builtin_inff())) atomicOr(&bad_s, 1);
-        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int l = bad_s ? 0 : lo_s, h = bad_s ? p.C : hi_s;
-        // nothing survives outside what stage B1 evaluated: its totals decide
-        if (p.virt ? (!bad_s && !more_s) : (l == a && h == b)) l = h = 0;
-        p.r_out[0] = l; p.r_out[1] = h;
-    }
-}
 __global__ void k_fill_f32(float* p, float v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -3420,42 +3493,6 @@ __global__ void k_merge_virtual(float* S2, const float* SB, const int* best, int
 __global__ void k_merge_scores(float* S2, const float* SB, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && S2[i] == -__builtin_inff()) S2[i] = SB[i];
-}
-// pack groups [g * PACK_CG, +PACK_CG) that intersect the range are packed now
-__global__ void k_mark_done(unsigned char* done, int ngroups, const int* crange, int c_base) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups) return;
-    const int a = crange[0] - c_base, b = crange[1] - c_base;
-    if (g * PACK_CG < b && (g + 1) * PACK_CG > a) done[g] = 1;
-}
-
-struct SelectParams {
-    const float* scores; int C, nj;
-    const float* cands; int cand_cs, cand_js, cand_off;  // cands[best*cand_cs + j*cand_js + cand_off]
-    float* interval; int out_js, out_off;
-    float* aux_out; float aux_div;                        // optional: aux_out[0] = selected / aux_div (SoS A_interval)
-    float* scores_out;  // optional copy [C][scores_out_ld]
-    int scores_out_ld;
-    int32_t* best_out;  // optional [nj]
-};
-__global__ __launch_bounds__(128) void k_select(SelectParams p) {          // one workgroup per score block
-    __shared__ float sv[128];
-    __shared__ int si[128];
-    const int j = blockIdx.x;
-    float bv = -__builtin_inff();
-    int bi = 0x7fffffff;
-    for (int c = threadIdx.x; c < p.C; c += 128) {
-        const float v = p.scores[(long)c * p.nj + j];
-        if (p.scores_out) p.scores_out[(long)c * p.scores_out_ld + j] = v;
-        if (bi == 0x7fffffff || score_beats(v, c, bv, bi)) { bv = v; bi = c; }
-    }
-    const int best = block_argmax(bv, bi, sv, si);
-    if (threadIdx.x == 0) {
-        const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
-        p.interval[(long)j * p.out_js + p.out_off] = sel;
-        if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
-        if (p.best_out) p.best_out[j] = best;
-    }
 }
 
 }  // namespace p4v
