@@ -630,6 +630,8 @@ struct SliceCache {
     const void* idx_src = nullptr; int idx_wt = -1;      // what the ranking was computed from
     const void* o_src = nullptr; const void* g_src = nullptr; const void* r_src = nullptr; const void* c_src = nullptr;
     float* frac = nullptr;            // device: share of the metric weight the slice holds
+    PlaneCache aplane;                // stage A's candidate-expanded plane of the SLICED operand (the search whose row operand is
+                                      // expanded): candidates and slice rows are fixed for the call, the later rounds find it packed
     bool loose = false;               // that share is too small for the stages to pay (Swin: no class token): full sweeps
 };
 // The same for the epilogue operands of k_sweep6 in fragment order (k_prep_epi6): raw_out, raw_grad and the bias are fixed
@@ -1076,6 +1078,7 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
         if (g.lin) gather(g.row_src, g.s_r, 1, g.K, sc->Rs, 0, 1, 0, 0);
         else gather(g.row_src, g.s_r, g.s_k, g.K, sc->Rs, g.k, g.zdiv, g.s_z2, g.s_z);
         sc->r_src = g.row_src;
+        sc->aplane.valid = false;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1150,7 +1153,8 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     // the candidate-expanded plane of the module is shared with stage A when the slice leaves that operand whole (the column
     // operand: weights of a Linear, B of a matmul): stage A packs all candidates into the module's plane cache once, the later
     // stages and rounds find them there -- as the unpruned passes do
-    a.cache = ps.col.expanded ? ps.cache : nullptr;
+    // ... and when it is the sliced operand that is expanded (activation search), its slice plane is kept with the slice
+    a.cache = ps.col.expanded ? ps.cache : (ps.cache && ps.scache) ? &sc->aplane : nullptr;
     a.ecache = nullptr; a.scores_keep = SA; a.no_select = true;
     a.S1_pre = S1s; a.S2_pre = S2s; a.s_ready = false;
     // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
