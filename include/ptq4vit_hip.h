@@ -146,7 +146,7 @@ typedef struct p4v_conv_desc {
     int32_t channelwise;
     int32_t init_layerwise;
     int32_t has_bias;
-    int32_t reserved;
+    int32_t reserved;           /* bit 3: disable the exact candidate pruning */
 } p4v_conv_desc;
 
 size_t p4v_conv_workspace_bytes(const p4v_conv_desc* desc);

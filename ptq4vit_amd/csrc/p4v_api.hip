@@ -676,6 +676,7 @@ struct Pass {
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
+    bool prunable_f32;        // ... and which may be pruned although their operands are fp32 planes (conv with a_bit >= 32)
     float* S1_pre; float* S2_pre; bool s_ready;   // scale tables shared by the stages of a pruned pass (same table, same scales)
     SliceCache* scache;       // optional: the module's sample slice, shared by its pruned passes
     bool host_sync_ok;        // the caller synchronises the stream after the pass anyway (pass memo): the pruned pass may read
@@ -1014,6 +1015,7 @@ struct SliceGeo {
     bool lin; int segs, seg_rows, k, Ncols, K;
     const float* O; const float* G; int wt_mode; long o_ms;
     const float* row_src; long s_r, s_k; int zdiv; long s_z2, s_z;
+    bool conv; PackParams conv_pk;     // the row operand is the im2col view of a conv input (flat: rows = (image, pixel))
 };
 int slice_alloc(Ctx& c, SliceCache* sc, const SliceGeo& g, bool keep, bool bump) {
     if (sc->assigned) {
@@ -1075,7 +1077,10 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
     if (sc->o_src != g.O) { gather(g.O, g.o_ms, 1, g.Ncols, sc->Os, seg, 1, o_seg, 0); sc->o_src = g.O; }
     if (g.G && sc->g_src != g.G) { gather(g.G, g.o_ms, 1, g.Ncols, sc->Gs, seg, 1, o_seg, 0); sc->g_src = g.G; }
     if (sc->r_src != g.row_src) {
-        if (g.lin) gather(g.row_src, g.s_r, 1, g.K, sc->Rs, 0, 1, 0, 0);
+        if (g.conv) {
+            const long total = (long)rows * g.K;
+            hipLaunchKernelGGL(k_gather_im2col, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, g.conv_pk, sc->idx, rows, sc->Rs);
+        } else if (g.lin) gather(g.row_src, g.s_r, 1, g.K, sc->Rs, 0, 1, 0, 0);
         else gather(g.row_src, g.s_r, g.s_k, g.K, sc->Rs, g.k, g.zdiv, g.s_z2, g.s_z);
         sc->r_src = g.row_src;
         sc->aplane.valid = false;
@@ -1085,7 +1090,7 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
 }
 
 bool prune_ok(const Pass& ps) {
-    if (!ps.prunable || !ps.i8 || ps.epi == EPI_COS || ps.store_out || ps.scores_out || ps.best_out || ps.crange || ps.no_select) return false;
+    if (!ps.prunable || !(ps.i8 || ps.prunable_f32) || ps.epi == EPI_COS || ps.store_out || ps.scores_out || ps.best_out || ps.crange || ps.no_select) return false;
     if ((g_variant & 4194304) || ps.eq_n < 32 || ps.nj < 1 || ps.nj > 4096) return false;
     return true;
 }
@@ -1108,15 +1113,17 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     if (lin) {
         k = (int)std::min<long>(rup(std::max(1, ps.Mrows / (tune(TUNE_SLICE_DIV) > 0 ? tune(TUNE_SLICE_DIV) : 16)), 256), rup(ps.Mrows, 256));
         if ((long)k * 5 > (long)ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth the stages
-        if (ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.o_bs || ps.o_nbs || ps.row.pk.conv || ps.row.pk.s_k != 1 ||
-            ps.row.pk.s_r != ps.K || ps.row.pk.zdiv > 0) return run_pass(c, ps);   // dense row-major operands only
+        // dense row-major operands only (or the im2col rows of a conv input, gathered element by element)
+        const bool conv_rows = ps.row.pk.conv && ps.row.pk.Z == 1 && !ps.twin;
+        if (ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.o_bs || ps.o_nbs || ps.row.pk.zdiv > 0 ||
+            (!conv_rows && (ps.row.pk.conv || ps.row.pk.s_k != 1 || ps.row.pk.s_r != ps.K))) return run_pass(c, ps);
     } else {
         k = 16;
         if (ps.Mrows < 64 || ps.row_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols || ps.o_ms != ps.Ncols || ps.o_ns != 1 ||
             ps.o_bs || ps.o_nbs || ps.row.pk.zdiv <= 0 || ps.row.pk.conv) return run_pass(c, ps);
     }
     SliceGeo geo{lin, segs, seg_rows, k, ps.Ncols, ps.K, ps.O, ps.G, ps.wt_mode, ps.o_ms, ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k,
-                 ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z};
+                 ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z, lin && ps.row.pk.conv != 0, ps.row.pk};
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
     if (sc->loose) return run_pass(c, ps);
@@ -1144,7 +1151,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     a.O = Os; a.G = ps.G ? Gs : nullptr;
     a.Mrows = k;
     auto sliced = [&](PackParams& pk) {
-        pk.src = Rs; pk.R = k; pk.s_k = 1; pk.s_r = ps.K;
+        pk.src = Rs; pk.R = k; pk.s_k = 1; pk.s_r = ps.K; pk.conv = 0;
         if (!lin) { pk.s_z = (long)k * ps.K; pk.s_z2 = (long)pk.zdiv * k * ps.K; }
     };
     sliced(a.row.pk);
@@ -1176,7 +1183,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     CHK(run_pass(c, b1));
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2;
-    const bool hull_selects = !ps.scores_out && ps.interval;
+    const bool hull_selects = !ps.scores_out && ps.interval && (virt || ps.nj <= 32);   // (its non-virt selection is serial over the blocks)
     SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
                      ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl); HIPCHK(hipGetLastError()); }
@@ -1917,6 +1924,19 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
         }
     }
     if (!sg.searches()) return 0;
+    // The difference metrics read raw_out / raw_grad as rows of the im2col GEMM, [b * L][oc]: one transposition of the [b][oc][L]
+    // tensors (same elements, same sums) gives the sweeps a dense epilogue operand and lets the weight search be pruned like a
+    // Linear's (run_pass_pruned: slices are rows).
+    const bool prunable = !cosm && sg.full() && !scores_out && !best_out && !(d->reserved & 8) && d->eq_n >= 32;
+    float* Ot = prunable ? c.ws.get<float>((size_t)M * oc) : nullptr;
+    float* Gt = (prunable && G) ? c.ws.get<float>((size_t)M * oc) : nullptr;
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
+    if (prunable && !c.dry) {
+        const dim3 grid(cdiv(L, 32), cdiv(oc, 32), b);
+        hipLaunchKernelGGL(k_nchw_to_rows, grid, dim3(256), 0, c.st, O, oc, L, Ot);
+        if (G) hipLaunchKernelGGL(k_nchw_to_rows, grid, dim3(256), 0, c.st, G, oc, L, Gt);
+        HIPCHK(hipGetLastError());
+    }
     // x as im2col rows.  per_image: Z = batch, rows = pixels of one image (channel-wise cosine reduces over pixels)
     auto x_operand = [&](bool expanded, const float* scales, int sc_cs, bool per_image) {
         Operand op{};
@@ -1950,6 +1970,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             // rows = (image, pixel), cols = oc;  out[b][oc][l]
             ps.Z = 1; ps.Mrows = M; ps.Ncols = oc; ps.row = xo; ps.col = wo;
             ps.o_inner = L; ps.o_bs = (long)oc * L; ps.o_ms = 1; ps.o_ns = L; ps.bias_axis = 0;
+            if (prunable) { ps.O = Ot; ps.G = G ? Gt : nullptr; ps.o_inner = INT_MAX; ps.o_bs = 0; ps.o_ms = oc; ps.o_ns = 1; }
         } else if (d->channelwise) {
             // cosine over the pixels of one image per (image, oc) (conv.py:504-508): rows = pixels, z = image
             ps.Z = b; ps.Mrows = L; ps.Ncols = oc; ps.row = xo; ps.col = wo; ps.col_zs_shared = 1;
@@ -1968,6 +1989,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
     PlaneCache plane_w, plane_a;
+    SliceCache slice;
     const bool keep_planes = sg.full() && d->search_round > 1;
     std::vector<float> key, val;
     const int n_rounds = sg.full() ? d->search_round : 1;
@@ -1992,7 +2014,8 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
             ps.cands = w_cands; ps.cand_cs = nw; ps.cand_js = 1; ps.interval = w_iv; ps.out_js = 1;
             ps.cache = keep_planes ? &plane_w : nullptr;
             ps.scores_out = so; ps.scores_out_ld = nw; ps.best_out = bo;
-            CHK(run_pass(c, ps));
+            ps.prunable = ps.prunable_f32 = prunable; ps.scache = &slice; ps.host_sync_ok = memo_on;
+            CHK(run_pass_pruned(c, ps));
             if (memo_on) { CHK(read_dev(c, w_iv, nw, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; }
         }
         bool skip_a = false;

@@ -3149,8 +3149,32 @@ struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; 
                      int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow; };
 // (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
 // r_out = hull over the blocks of stage A's first maxima
+#define PRUNE_WIDE_NJ 64        // from this many score blocks on: one THREAD per block (channel-wise weights: hundreds of blocks)
 __device__ __forceinline__ void prune_pick(const PruneParams& p, float* sv, int* si) {
     int lo = p.C, hi = 0;
+    if (p.nj >= PRUNE_WIDE_NJ) {
+        for (int j = threadIdx.x; j < p.nj; j += 256) {
+            float bv = p.SA[j];
+            int best = 0;
+            for (int c = 1; c < p.C; ++c) {
+                const float v = p.SA[(long)c * p.nj + j];
+                if (score_beats(v, c, bv, best)) { bv = v; best = c; }
+            }
+            lo = min(lo, best); hi = max(hi, best + 1);
+            if (p.virt) {
+                p.best[j] = best;
+                p.vrow[j * p.cand_js + p.cand_off] = p.cands[(long)best * p.cand_cs + j * p.cand_js + p.cand_off];
+            }
+        }
+        si[threadIdx.x] = lo; si[256 + threadIdx.x] = hi;       // (si: 512 ints in the callers' shared arrays, see k_prune_pick)
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) { si[threadIdx.x] = min(si[threadIdx.x], si[threadIdx.x + o]); si[256 + threadIdx.x] = max(si[256 + threadIdx.x], si[256 + threadIdx.x + o]); }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { p.r_out[0] = si[0]; p.r_out[1] = si[256]; }
+        return;
+    }
     for (int j = 0; j < p.nj; ++j) {
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
@@ -3169,7 +3193,7 @@ __device__ __forceinline__ void prune_pick(const PruneParams& p, float* sv, int*
 }
 __global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {
     __shared__ float sv[256];
-    __shared__ int si[256];
+    __shared__ int si[512];
     prune_pick(p, sv, si);
 }
 // r_out = what stage B2 has to evaluate: the hull of the candidates whose stage-A bound reaches the best complete score, or the
@@ -3179,6 +3203,27 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
     const int a = p.r_in[0], b = p.r_in[1];
     if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; more_s = 0; }
     __syncthreads();
+    if (p.nj >= PRUNE_WIDE_NJ) {          // one thread per score block
+        int l = p.C, h = 0;
+        bool bad = false, more = false;
+        for (int j = threadIdx.x; j < p.nj; j += 256) {
+            float L = -__builtin_inff();
+            bool nan = false;
+            if (p.virt) { L = p.SB[j]; nan = L != L; }
+            else for (int c = a; c < b; ++c) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
+            const float thr = L - p.margin * fabsf(L);
+            const int bj = p.virt ? p.best[j] : -1;
+            for (int c = 0; c < p.C; ++c) {
+                const float v = p.SA[(long)c * p.nj + j];
+                nan |= v != v;
+                if (!(v < thr)) { l = min(l, c); h = max(h, c + 1); more |= p.virt && c != bj; }
+            }
+            bad |= nan || !(L > -__builtin_inff());
+        }
+        if (bad) atomicOr(&bad_s, 1);
+        if (more) atomicOr(&more_s, 1);
+        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
+    } else
     for (int j = 0; j < p.nj; ++j) {
         // L* = the best complete score among stage B1's candidates (virt: the one synthetic candidate's score in this block)
         float L = -__builtin_inff();
@@ -3232,7 +3277,7 @@ __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p, SelectParams 
             if (sl.aux_out) sl.aux_out[j] = sel / sl.aux_div;
             if (sl.best_out) sl.best_out[j] = best;
         }
-    } else {
+    } else {                                       // (the caller leaves many-block non-virt selections to k_select)
         const int a = p.r_in[0], b = p.r_in[1];
         for (int j = 0; j < sl.nj; ++j) select_block(sl, j, a, b, sv, si);
     }
@@ -3477,6 +3522,25 @@ __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
     }
 }
 
+// rows idx[0..k) of the im2col matrix of a conv input (PackParams' conv fields; flat layout, Z = 1), dense [k][K]
+__global__ __launch_bounds__(256) void k_gather_im2col(PackParams p, const int* idx, int k, float* dst) {
+    const long total = (long)k * p.K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / p.K), kk = (int)(i - (long)r * p.K);
+        dst[i] = pack_load(p, p.src, idx[r], kk);
+    }
+}
+// conv output / gradient [b][oc][L] -> rows of the im2col GEMM [b * L][oc] (32 x 32 tiles through LDS; grid (L/32, oc/32, b))
+__global__ __launch_bounds__(256) void k_nchw_to_rows(const float* src, int oc, int L, float* dst) {
+    __shared__ float t[32][33];
+    const int l0 = blockIdx.x * 32, c0 = blockIdx.y * 32, bi = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < oc && l0 + tx < L) t[i][tx] = src[((long)bi * oc + c0 + i) * L + l0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (l0 + i < L && c0 + tx < oc) dst[((long)bi * L + l0 + i) * oc + c0 + tx] = t[tx][i];
+}
 __global__ void k_fill_f32(float* p, float v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -208,8 +208,8 @@ def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta
 
 
 def conv_calibrate(*, weight, bias, x, out, grad, stride, padding, dilation, w_bit, a_bit, metric, eq_alpha, eq_beta,
-                   eq_n, search_round, channelwise=True, init_layerwise=False, want_scores=False):
-    """Run calibration_step2 of the patch-embedding Conv2d on the GPU."""
+                   eq_n, search_round, channelwise=True, init_layerwise=False, want_scores=False, prune=True):
+    """Run calibration_step2 of the patch-embedding Conv2d on the GPU (prune=False: no exact candidate pruning)."""
     lib = _lib.load()
     dev = device_of(x, weight)
     weight, bias, x, out, grad = (to_dev(t, dev) for t in (weight, bias, x, out, grad))
@@ -219,7 +219,7 @@ def conv_calibrate(*, weight, bias, x, out, grad, stride, padding, dilation, w_b
     oc, _, kh, kw = weight.shape
     d = _lib.ConvDesc(b, ic, H, W, oc, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                       w_bit, a_bit, metric_id(metric), eq_n, search_round, int(channelwise), int(init_layerwise),
-                      int(bias is not None), 0)
+                      int(bias is not None), 0 if prune else 8)
     need = lib.p4v_conv_workspace_bytes(C.byref(d))
     if need == 0:
         _lib.check(-2, "p4v_conv_workspace_bytes")

@@ -662,11 +662,43 @@ def test_candidate_pruning_is_exact_linear(eng, cfg):
             assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}: {pruned[k].tolist()} vs {full[k].tolist()}"
             assert torch.equal(pruned[k], nomemo[k]), f"pruned search without the pass memo differs ({what})"
             assert torch.equal(auto[k], full[k]), f"adaptive search selected another {what}"
-    return
-    for k, what in ((0, "w_interval"), (1, "a_interval")):
-        assert torch.equal(pruned[k], again[k]), f"pruned search is not run-to-run deterministic ({what})"
-        assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}: {pruned[k].tolist()} vs {full[k].tolist()}"
-        assert torch.equal(pruned[k], nomemo[k]), f"pruned search without the pass memo differs ({what})"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=16, hw=224, oc=768, k=16, channelwise=True, w_bit=8, metric="hessian"),    # ViT-B patch embedding, 768 score blocks
+    dict(b=16, hw=224, oc=192, k=16, channelwise=False, w_bit=6, metric="hessian"),   # layer-wise: one block
+    dict(b=4, hw=384, oc=128, k=4, channelwise=True, w_bit=8, metric="L2_norm"),      # Swin-B/384 patch embedding, unweighted
+], ids=lambda c: f"{'cw' if c['channelwise'] else 'lw'}-{c['metric']}-w{c['w_bit']}-b{c['b']}-{c['hw']}-oc{c['oc']}")
+def test_candidate_pruning_is_exact_conv(eng, cfg):
+    """The same for the patch-embedding weight search (fp32 planes, a_bit = 32; slices are rows of the im2col GEMM gathered from
+    the image, raw_out / raw_grad transposed to rows once): forced, the engine's own choice and unpruned select the same."""
+    rng = np.random.default_rng(13)
+    b, hw, oc, k = cfg["b"], cfg["hw"], cfg["oc"], cfg["k"]
+    w = (rng.standard_normal((oc, 3, k, k)) * 0.05 * np.linspace(0.3, 3.0, oc)[:, None, None, None]).astype(np.float32)
+    bias = (rng.standard_normal(oc) * 0.1).astype(np.float32)
+    x = rng.standard_normal((b, 3, hw, hw)).astype(np.float32)
+    out = torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(bias), stride=k).numpy()
+    grad = (rng.standard_normal(out.shape) * 1e-3).astype(np.float32)
+    heavy = grad.copy()
+    mask = rng.random((b, 1) + out.shape[2:]) < 0.03                 # a few pixels carry the weight
+    heavy = np.where(mask, heavy * 300.0, heavy).astype(np.float32)
+    hp = dict(w_bit=cfg["w_bit"], a_bit=32, metric=cfg["metric"], eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=3,
+              stride=(k, k), padding=(0, 0), dilation=(1, 1), channelwise=cfg["channelwise"])
+    for g_ in (grad, heavy):
+        args = dict(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(g_))
+        try:
+            eng.debug_variant(8388608)
+            pruned = eng.conv_calibrate(**args, **hp)
+            again = eng.conv_calibrate(**args, **hp)
+        finally:
+            eng.debug_variant(0)
+        auto = eng.conv_calibrate(**args, **hp)
+        full = eng.conv_calibrate(prune=False, **args, **hp)
+        torch.cuda.synchronize()
+        assert torch.equal(pruned[0], again[0]), "pruned conv search is not run-to-run deterministic"
+        assert torch.equal(pruned[0], full[0]), f"pruned conv search selected other intervals at {(pruned[0] != full[0]).sum().item()} channels"
+        assert torch.equal(auto[0], full[0]), "adaptive conv search selected other intervals"
+        assert torch.equal(pruned[1], full[1])
 
 
 @pytest.mark.parametrize("kind,b,H,S,D,bit,metric", [("qk", 16, 12, 197, 64, 8, "hessian"), ("sv", 16, 12, 197, 64, 8, "hessian"),

@@ -25,6 +25,8 @@ for n, m in wrapped.items():
             row = (g * g).sum(-1).reshape(-1)
         elif g.dim() == 4 and not hasattr(_m, "weight"):   # matmul (b, H, M, N): per image
             row = (g * g).sum(dim=(1, 2, 3))
+        elif g.dim() == 4:    # conv (b, oc, H, W): per (image, pixel) -- the rows of its im2col GEMM
+            row = (g * g).sum(1).reshape(-1)
         else:
             row = (g * g).reshape(g.shape[0], -1).sum(-1)
         srt = torch.sort(row, descending=True).values
