@@ -616,7 +616,7 @@ int launch_select(Ctx& c, const SelectParams& p) {
 struct PlaneCache {
     char* buf = nullptr;
     bool assigned = false, valid = false;
-    unsigned char* done = nullptr;    // pruned passes: device flags, one per pack group of PACK_CG candidates already in `buf`
+    unsigned char* done = nullptr;    // pruned passes: device flags, one per candidate already in `buf`
 };
 // The sample slice of the pruned passes (run_pass_pruned, stage A): which samples carry the metric weight depends on raw_grad /
 // raw_out only, so the ranking, the gathered rows of raw_out / raw_grad and of the row operand are built by the first pruned pass
@@ -747,12 +747,11 @@ int run_pass(Ctx& c, Pass& ps) {
     PlaneCache* pc = (ps.cache && chunk >= ps.eq_n && !ps.store_out && ps.row.expanded != ps.col.expanded &&
                       !(ps.twin && ps.row2.expanded) && exp_plane * (long)ps.eq_n <= PLANE_CACHE_MAX &&
                       !(g_variant & 1024)) ? ps.cache : nullptr;
-    const int pack_groups = cdiv(ps.eq_n, PACK_CG);
     if (pc && !pc->assigned) {
         pc->buf = c.ws.get_top((size_t)exp_plane * chunk_al + slack);
-        pc->done = reinterpret_cast<unsigned char*>(c.ws.get_top((size_t)rup(pack_groups, 256)));
+        pc->done = reinterpret_cast<unsigned char*>(c.ws.get_top((size_t)rup(ps.eq_n, 256)));
         pc->assigned = true; pc->valid = false;
-        if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 0, (size_t)pack_groups, c.st));
+        if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 0, (size_t)ps.eq_n, c.st));
     }
     char* rowbuf = (pc && ps.row.expanded) ? pc->buf : c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
@@ -853,7 +852,7 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
         if (pc && !ps.crange && !packed) {   // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
             pc->valid = true;
-            if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)pack_groups, c.st));
+            if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)ps.eq_n, c.st));
         }
         if (g_stat_on && ps.crange && !c.dry) {     // roofline step only: how many of this launch's candidates run
             int h[2] = {0, 0};
@@ -969,8 +968,8 @@ int run_pass(Ctx& c, Pass& ps) {
     }
     g_exec_frac = 1.0;
     if (ps.store_out) { c.ws.off = mark; return 0; }
-    auto with_marks = [&](FinishParams& fp) {     // a pruned pass flags the candidate groups it packed into the module's plane
-        if (ps.crange && pc && pc->done) { fp.mark_done = pc->done; fp.mark_groups = pack_groups; }
+    auto with_marks = [&](FinishParams& fp) {     // a pruned pass flags the candidates it packed into the module's plane
+        if (ps.crange && pc && pc->done) { fp.mark_done = pc->done; fp.mark_n = ps.eq_n; }
     };
     if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
         const int slots = nine_halves * SW9_NW;

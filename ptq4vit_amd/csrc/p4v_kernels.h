@@ -149,8 +149,8 @@ struct PackParams {
     int mode, lo, hi;
     float qm1;            // q-1 for SOS modes
     float neg_scale;      // twin: fixed negative-range interval
-    // pruned passes: only the candidate groups (PACK_CG candidates each) that intersect [crange[0], crange[1]) - c_base are
-    // packed, and of those only the ones whose `done` flag is still 0 (planes kept across the rounds of a call)
+    // pruned passes: only the candidates in [crange[0], crange[1]) - c_base are packed, and of those only the ones whose `done`
+    // flag (one per candidate) is still 0 (planes kept across the rounds of a call)
     const int* crange; int c_base; const unsigned char* done;
     // optional im2col gather (conv): logical r = (b, oy, ox), k = (ci, ki, kj)
     int conv, ic, H, W, kh, kw, sh, sw, ph, pw, dh, dw, fw, L;
@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
     const unsigned kchunks = p.Kp / 16;
     const unsigned total = (unsigned)p.Z * p.Rp * kchunks;      // < 2^31: checked by the launcher
     const int cbeg = blockIdx.y * PACK_CG, cend = min(p.C, cbeg + PACK_CG);
+    unsigned need = (1u << (cend - cbeg)) - 1u;            // the candidates of this group to pack (bit j: candidate cbeg + j)
     if (p.crange) {
         const int a = p.crange[0] - p.c_base, b = p.crange[1] - p.c_base;
         if (cend <= a || cbeg >= b) return;
+        for (int j = 0; j < PACK_CG; ++j)
+            if (cbeg + j < a || cbeg + j >= b || (p.done && cbeg + j < cend && p.done[cbeg + j])) need &= ~(1u << j);
+        if (!need) return;
     }
-    if (p.done && p.done[blockIdx.y]) return;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const unsigned row = i / kchunks;
         const int kc = (int)(i - row * kchunks);
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         for (int j = 0; j < PACK_CG; ++j) {     // not unrolled: one candidate's body is already ~150 instructions
             const int c = cbeg + j;
             if (c >= cend) break;
+            if (!((need >> j) & 1u)) continue;
             const long o = p.c_inner == 3 ? ((long)z * p.Rp * p.Kp + (((((long)(r >> 6) * (p.Kp >> 6) + (kc >> 2)) * 2 + ((r >> 5) & 1)) * 2 + ((kc >> 1) & 1)) * 64 + (kc & 1) * 32 + (r & 31)) * 16)
                          : p.c_inner == 2 ? ((((long)z * p.Rp + r) * ((p.C + 1) & ~1) + (c & ~1)) * p.Kp + (long)(kc >> 2) * 128 + (c & 1) * 64 + (kc & 3) * 16)
                          : p.c_inner ? ((((long)z * p.Rp + r) * p.C + c) * p.Kp + (long)kc * 16)
@@ -3290,7 +3294,7 @@ struct FinishParams {
     double norm;           // score = -norm * sum
     float* scores;         // [C][nj]
     const int* crange;     // optional: candidates outside [crange[0], crange[1]) were not evaluated -> score -inf
-    unsigned char* mark_done; int mark_groups;   // optional, with crange: the pack groups this pass packed into the module's plane
+    unsigned char* mark_done; int mark_n;        // optional, with crange: the candidates this pass packed into the module's plane (flags, count)
 };
 
 // One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
@@ -3301,8 +3305,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishParams p) {
     if (p.mark_done && c == 0 && j == 0) {
         // (k_pack read the flags earlier on this stream; the next reader is a later launch)
         const int a = p.crange[0], b = p.crange[1];
-        for (int g = threadIdx.x; g < p.mark_groups; g += 256)
-            if (g * PACK_CG < b && (g + 1) * PACK_CG > a) p.mark_done[g] = 1;
+        for (int cc = max(a, 0) + (int)threadIdx.x; cc < min(b, p.mark_n); cc += 256) p.mark_done[cc] = 1;
     }
     if (p.crange && (c < p.crange[0] || c >= p.crange[1])) {
         if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = -__builtin_inff();
