@@ -280,7 +280,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on;
+    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
@@ -393,7 +393,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on;
+    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
     StatRec rec{};
     if (timed) {   // one record per kernel launch; a split sweep books its work in proportion to the tiles of each part
         const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
@@ -537,7 +537,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     Sweep7Params q = p;
     q.cgroups = cgroups;
     dim3 grid(p.rtiles * p.ctiles * cgroups, 1, 1);
-    const bool timed = g_stat_on;
+    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
@@ -557,7 +557,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
 
 int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
-    const bool timed = g_stat_on;
+    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));

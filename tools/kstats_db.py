@@ -7,11 +7,19 @@ import sys
 for path in ([] if (len(sys.argv) > 1 and sys.argv[1] in ("--busy", "--hist")) else sys.argv[1:]):
     for db in sorted(glob.glob(path) if any(ch in path for ch in "*?") else [path]):
         con = sqlite3.connect(db)
+        # KSTATS_TAIL=f: only the kernels that start in the last fraction f of the trace (the steady calibrations of a bench
+        # run, without the cold first ones); the conv transposition runs twice per calibration -> calibrations in the window
+        import os
+        tail = float(os.environ.get("KSTATS_TAIL", "0"))
+        t0, t1 = con.execute("select min(start), max(end) from kernels").fetchone()
+        cut = t1 - tail * (t1 - t0) if tail > 0 else t0
         rows = con.execute("select name, count(*), avg(end-start), sum(end-start), min(end-start), max(end-start) from kernels "
-                           "group by name order by 4 desc").fetchall()
+                           "where start >= ? group by name order by 4 desc", (cut,)).fetchall()
         tot = sum(r[3] for r in rows)
-        print(f"== {db}: {tot / 1e6:.2f} ms of kernels")
-        for r in rows[:14]:
+        ncal = sum(r[1] for r in rows if "k_nchw_to_rows" in r[0]) / 2.0
+        print(f"== {db}: {tot / 1e6:.2f} ms of kernels" + (f" in the last {tail:.0%} of the trace ({(t1 - cut) / 1e6:.1f} ms of wall-clock, "
+              f"{ncal:g} calibrations: {tot / 1e6 / max(ncal, 1):.1f} ms of kernels each)" if tail > 0 else ""))
+        for r in rows[:int(os.environ.get("KSTATS_TOP", "14"))]:
             print(f"  {r[0][:84]:84s} n={r[1]:5d} avg={r[2] / 1e3:9.1f} us  {100 * r[3] / tot:5.1f} %")
 
 
