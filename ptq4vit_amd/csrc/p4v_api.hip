@@ -98,6 +98,8 @@ thread_local long g_memo_hits = 0, g_memo_misses = 0;
 //   32768 no k_sweep7 (K >= 1024 sweeps on k_sweep2 / k_sweep2g)      65536 no k_sweep8 (single-k-tile sweeps on k_sweep2)
 //   2097152 post-GELU twin of k_sweep7 on two streamed planes (not the merged one)
 //   4194304 no exact candidate pruning (every candidate over every sample)   8388608 prune even where the slice's bounds are loose
+//   16777216 pruned passes with several score blocks: stage B1 on the hull of the winners (no synthetic candidate)
+//   33554432 the two fixed planes of a twin row operand from two k_pack launches (not k_pack_dual)
 //   1, 2: kernel debug flags (SweepParams::dbg)
 //   bit 30: route every int8 sweep through the generic k_sweep
 std::atomic<int> g_variant_word{0};
@@ -704,6 +706,15 @@ int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_u
     return best;
 }
 
+// the two fixed planes of a twin row operand can come from one launch: same source view, one scale each, plain modes
+bool dual_pack_ok(const PackParams& a, const PackParams& b) {
+    auto plain = [](const PackParams& p) {
+        return (p.mode == PACK_SYM || p.mode == PACK_SOS_HI || p.mode == PACK_SOS_LO) && p.blk_mode == 0 && !p.conv && !p.crange;
+    };
+    return plain(a) && plain(b) && a.src == b.src && a.R == b.R && a.K == b.K && a.s_r == b.s_r && a.s_k == b.s_k &&
+           a.s_z == b.s_z && a.s_z2 == b.s_z2 && a.zdiv == b.zdiv;
+}
+
 int run_pass(Ctx& c, Pass& ps) {
     const int esz = ps.i8 ? 1 : 4;
     g_alg_macs_cand = (double)ps.Mrows * ps.Ncols * ps.K * ps.Z;
@@ -837,6 +848,17 @@ int run_pass(Ctx& c, Pass& ps) {
         both.pk.mode = PACK_TWIN_I8;
         both.pk.lo = ps.row2.pk.lo; both.pk.neg_scale = ps.row2.pk.neg_scale;
         CHK(pack(both, rowbuf, Mp, ps.row_zs_shared, 0, 1));
+    } else if (ps.twin && ps.i8 && !ps.row.expanded && !ps.row2.expanded && dual_pack_ok(ps.row.pk, ps.row2.pk) && !(g_variant & 33554432)) {
+        // both planes of the twin row operand from one read of the source (k_pack_dual)
+        PackParams p1 = ps.row.pk, p2 = ps.row2.pk;
+        p1.Rp = p2.Rp = Mp; p1.Kp = p2.Kp = Kp; p1.Z = p2.Z = ps.row_zs_shared ? 1 : ps.Z; p1.C = p2.C = 1;
+        p1.dst = rowbuf; p2.dst = row2buf;
+        if (!c.dry) {
+            const long total = (long)p1.Z * Mp * (Kp / 16);
+            if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack_dual (%ld 16-element runs)", total);
+            hipLaunchKernelGGL(k_pack_dual, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 64)), dim3(256), 0, c.st, p1, p2);
+            HIPCHK(hipGetLastError());
+        }
     } else {
         if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
         if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));

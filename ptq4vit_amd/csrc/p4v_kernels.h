@@ -383,6 +383,57 @@ __global__ __launch_bounds__(256) void k_pack_twin(PackParams p) {
     }
 }
 
+
+// Both int8 planes of a twin operand from ONE read of the source: the post-GELU twin's positive / negative range
+// (linear.py:605-606: two PACK_SYM planes with clamps [0, hi] / [lo, 0]) or the split-of-softmax pair (matmul.py:595-598:
+// PACK_SOS_HI / PACK_SOS_LO).  Same arithmetic as k_pack's per-element path (pack_value: IEEE division), two fixed planes
+// (C = 1), one scale each (no blocks), row-major [Z][Rp][Kp].  Memory-bound: the source is read once instead of twice
+// (quant_forward at batch 128: 310 MB per fc2, 238 MB per attention-probability operand).
+__global__ __launch_bounds__(256) void k_pack_dual(PackParams p, PackParams p2) {
+    const unsigned kchunks = p.Kp / 16;
+    const unsigned total = (unsigned)p.Z * p.Rp * kchunks;
+    const float s1 = p.scales ? p.scales[0] : p.neg_scale, s2 = p2.scales ? p2.scales[0] : p2.neg_scale;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned row = i / kchunks;
+        const int kc = (int)(i - row * kchunks);
+        const int z = (int)(row / (unsigned)p.Rp);
+        const int r = (int)(row - (unsigned)z * p.Rp);
+        const float* zbase = p.zdiv > 0 ? p.src + (long)(z / p.zdiv) * p.s_z2 + (long)(z % p.zdiv) * p.s_z
+                                        : p.src + (long)z * p.s_z;
+        float x[16];
+        const bool vec = p.s_k == 1 && r < p.R && kc * 16 + 16 <= p.K && (p.s_r & 3) == 0 && ((((unsigned long long)zbase) & 15) == 0);
+        if (vec) {
+            const v4f* src4 = reinterpret_cast<const v4f*>(zbase + (long)r * p.s_r + kc * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = src4[q];
+                x[q * 4 + 0] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = pack_load(p, zbase, r, kc * 16 + e);
+        }
+        const bool live = r < p.R;
+        int w1[4], w2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int a1 = 0, a2 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = live && kc * 16 + q * 4 + e < p.K;
+                const float v1 = in ? pack_value(p, x[q * 4 + e], s1) : 0.0f;
+                const float v2 = in ? pack_value(p2, x[q * 4 + e], s2) : 0.0f;
+                a1 |= ((int)v1 & 0xff) << (8 * e);
+                a2 |= ((int)v2 & 0xff) << (8 * e);
+            }
+            w1[q] = a1; w2[q] = a2;
+        }
+        const long o = ((long)z * p.Rp + r) * p.Kp + (long)kc * 16;
+        __builtin_nontemporal_store(v4i{w1[0], w1[1], w1[2], w1[3]}, reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + o));
+        __builtin_nontemporal_store(v4i{w2[0], w2[1], w2[2], w2[3]}, reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p2.dst) + o));
+    }
+}
+
 // Plain 2-D helpers behind p4v_quantize_i8 / p4v_fake_quant (quant_forward building blocks).
 __global__ void k_fake_quant_rows(const float* x, long rows, long cols, const float* scales, long rows_per_scale,
                                   float lo, float hi, float* y) {
