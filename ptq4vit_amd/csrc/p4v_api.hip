@@ -1024,12 +1024,13 @@ int run_pass(Ctx& c, Pass& ps) {
 }
 
 // ---- exact candidate pruning ------------------------------------------------------------------------------------------------
-// (the argument is with the prune kernels, p4v_kernels.h)  A pass becomes: stage A = all candidates on the first ~1/8 of the
-// samples (its own small problem, scores only); B1 = the stage-A winners on all samples (the bound); B2 = the surviving range on
-// all samples with the unpruned kernels, tiles, finish and selection -- bit-identical totals for the survivors, hence the same
-// selection (tests: every parity case runs with and without it, desc.reserved bit 8 / variant 4194304 switch it off).  Everything
-// between the stages stays on the device.  Not used when the caller wants the full score tables, for the cosine metric (its
-// terms are not one-signed), for fp32 operands, or where the sample slice would not be small against the whole.
+// (the argument is with the prune kernels, p4v_kernels.h)  A pass becomes: stage A = all candidates on the HEAVIEST ~1/16 of
+// the samples (by their share of the metric weight; its own small problem, scores only); B1 = the stage-A winners on all
+// samples (the bound); B2 = the surviving range on all samples with the unpruned kernels, tiles, finish and selection --
+// bit-identical totals for the survivors, hence the same selection (tests: every parity case runs with and without it,
+// desc.reserved bit 3 / variant 4194304 switch it off).  Everything between the stages stays on the device.  Not used when the
+// caller wants the full score tables, for the cosine metric (its terms are not one-signed), for fp32 operands other than the
+// patch embedding's weight search, or where the sample slice would not be small against the whole.
 // The sample slice of a module (see SliceCache): geometry, allocation (top of the workspace when the module keeps it, the bump
 // region otherwise) and contents (ranking, share of the metric weight, gathered rows; only what changed is redone).
 struct SliceGeo {
