@@ -240,7 +240,12 @@ def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
     recv = torch.empty(per_src * world, dtype=torch.float32, device=backend_dev)
     dist.all_to_all_single(recv, send, output_split_sizes=[per_src] * world, input_split_sizes=sizes)
     del send
-    full, off = {}, 0
+    # reassembly: piece (sender, slot) of every tensor goes to its sub-batch position.  On a GPU all of them in ONE launch
+    # (p4v_multi_copy; a copy per piece is ~2000 launches for ViT-B on 8 ranks -- as long as the search of a rank's modules)
+    on_gpu = data_dev is not None and data_dev.type == "cuda"
+    if on_gpu and recv.device != data_dev:
+        recv = recv.to(data_dev)                     # (gloo with several ranks on one GPU: the collective ran on host buffers)
+    full, off, rows = {}, 0, []
     for (n, li, shp) in layouts[rank]:
         per = 1
         for d in shp:
@@ -250,10 +255,19 @@ def exchange_captures(wrapped_modules, owner, n_sub, grad_names):
             base = src * per_src + off
             for k in range(slots):
                 i = src + k * world                   # global sub-batch index of (sender, slot)
-                if i < n_sub:
+                if i >= n_sub:
+                    continue
+                if on_gpu:
+                    rows.append([recv.data_ptr() + 4 * (base + k * per), t.data_ptr() + 4 * i * per, 4 * per])
+                else:
                     t[i * shp[0]:(i + 1) * shp[0]].copy_(recv[base + k * per: base + (k + 1) * per].reshape(shp))
         off += slots * per
         full[(n, li)] = t
+    if rows:
+        from .. import engine
+        table = torch.tensor(rows, dtype=torch.int64).to(data_dev)
+        engine.multi_copy(table, len(rows), 0, max(r[2] for r in rows), data_dev)
+        torch.cuda.current_stream(data_dev).synchronize()      # `recv` and `table` are released below
     del recv
     for n in names:
         if owner[n] != rank:

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -105,7 +106,7 @@ def test_interval_exchange_world2_gloo():
 
 
 # ---- sub-batch sharded capture: the real calibrator on the mini ViT, CPU, 2 and 3 ranks ----------------------------
-def _capture_worker(rank, world, port, q, sharded=True):
+def _capture_worker(rank, world, port, q, sharded=True, device="cpu"):
     import contextlib, io, json
     import numpy as np
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -115,10 +116,10 @@ def _capture_worker(rank, world, port, q, sharded=True):
     from ptq4vit_amd.utils import models, net_wrap, quant_calib
     g = np.load("tests/golden/minivit_ptq4vit.npz", allow_pickle=False)
     kw = json.loads(str(g["model_kwargs"]))
-    net = models.get_net("vit_tiny_patch16_224", seed=0, device="cpu", **kw)
+    net = models.get_net("vit_tiny_patch16_224", seed=0, device=device, **kw)
     with contextlib.redirect_stdout(io.StringIO()):
         wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
-    images = torch.from_numpy(g["images"])
+    images = torch.from_numpy(g["images"]).to(device)
 
     class Loader:
         batch_size = images.shape[0]
@@ -132,7 +133,7 @@ def _capture_worker(rank, world, port, q, sharded=True):
             ri = _m.raw_input
             seen[_n] = ([t.clone() for t in ri] if isinstance(ri, list) else [ri.clone()]) + [_m.raw_out.clone(), _m.raw_grad.clone()]
             _m.calibrated = True
-            _m.w_interval = torch.zeros(1)
+            _m.w_interval = torch.zeros(1, device=device)
         m.calibration_step2 = rec
     cal = quant_calib.HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=2,
                                              capture_batch_size=2)   # 4 sub-batches
@@ -147,18 +148,18 @@ def _capture_worker(rank, world, port, q, sharded=True):
         want = ([g[f"{key}::A"], g[f"{key}::B"]] if f"{key}::A" in g.files else [g[f"{key}::x"]]) + [g[f"{key}::out"], g[f"{key}::grad"]]
         for t, w in zip(ts, want):
             ok &= tuple(t.shape) == tuple(w.shape)
-    q.put((rank, ok, nmine, {n: [t.numpy() for t in ts] for n, ts in seen.items()}))
+    q.put((rank, ok, nmine, {n: [t.cpu().numpy() for t in ts] for n, ts in seen.items()}))
     dist.destroy_process_group()
 
 
-def _run_capture(world, sharded=True):
+def _run_capture(world, sharded=True, device="cpu"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_capture_worker, args=(r, world, port, q, sharded)) for r in range(world)]
+    procs = [ctx.Process(target=_capture_worker, args=(r, world, port, q, sharded, device)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -184,6 +185,24 @@ def test_sharded_capture_reassembles_the_single_process_capture():
         for n, ts in merged.items():
             for a, b in zip(ts, single[3][n]):
                 np.testing.assert_array_equal(a, b, err_msg=n)
+
+
+@pytest.mark.gpu
+def test_sharded_capture_on_the_gpu_reassembles_the_single_process_capture():
+    """The same with the tensors on the GPU (two ranks sharing cuda:0, gloo moving host copies): the owners' tensors are put
+    together by ONE p4v_multi_copy launch and equal the single-process GPU capture bit for bit."""
+    import numpy as np
+    single = _run_capture(1, device="cuda:0")[0]
+    assert single[1] and single[2] == 14
+    res = _run_capture(2, True, device="cuda:0")
+    assert all(ok for _, ok, _, _ in res) and sum(nm for _, _, nm, _ in res) == 14
+    merged = {}
+    for _, _, _, d in res:
+        merged.update(d)
+    assert set(merged) == set(single[3])
+    for n, ts in merged.items():
+        for a, b in zip(ts, single[3][n]):
+            np.testing.assert_array_equal(a, b, err_msg=n)
 
 
 # ---- forward AFTER a multi-rank calibration: every rank must be able to run the quantised network ---------------------
