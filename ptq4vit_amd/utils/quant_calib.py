@@ -466,34 +466,55 @@ class HessianQuantCalibrator(QuantCalibrator):
         n_lanes = max(1, min(want, n_sub, len(lanes)))
         t_ = tick(f"graphs ready ({len(lanes)} instance(s))", t_)
         from .. import engine
+        # What does not change between calibrations of one network is kept with the graph instance (`recipe`): the layout of
+        # every cache (shape + strides: _cache_like) and which pieces are one dense block (_same_dense_block) -- ~3 ms of
+        # Python per calibration, during which the GPU had nothing to do.
         flat_dsts, plans = [], []
+        key_names = tuple(names)
+        recipe0 = lanes[0].setdefault("recipes", {}).get(key_names)
+        if recipe0 is None:
+            statics0 = lanes[0]["statics"]
+            layout, is_block = [], []
+            for n in names:
+                for t in statics0[n][0]:
+                    c = _cache_like(t, n_sub)
+                    layout.append((tuple(c.shape), tuple(c.stride()), t.dtype))
+                    is_block.append(_same_dense_block(c, t))
+                    del c
+            recipe0 = lanes[0]["recipes"][key_names] = {"n_sub": n_sub, "layout": layout, "is_block": is_block}
+        if recipe0["n_sub"] != n_sub:
+            lanes[0]["recipes"].pop(key_names)
+            return self._capture_passes_graph(names, dev, bs, raw_pred_softmax)
+        k_ = 0
+        for n in names:
+            m = self.wrapped_modules[n]
+            stat, with_g = lanes[0]["statics"][n]
+            full = []
+            for _t in stat:
+                shp, strd, dt = recipe0["layout"][k_]
+                full.append(torch.empty_strided(shp, strd, dtype=dt, device=dev))
+                k_ += 1
+            d_ = m.__dict__                        # (plain tensors: what nn.Module.__setattr__ ends up doing, without its checks)
+            if isinstance(m, MinMaxQuantMatMul):
+                d_["raw_input"], d_["raw_out"] = [full[0], full[1]], full[2]
+            else:
+                d_["raw_input"], d_["raw_out"] = full[0], full[1]
+            if hasattr(m, "metric"):
+                d_["raw_grad"] = full[-1] if with_g else None
+            flat_dsts += full
         for li in range(n_lanes):
             statics = lanes[li]["statics"]
             srcs = []
             for n in names:
                 srcs += statics[n][0]
-            if li == 0:
-                for n in names:
-                    m = self.wrapped_modules[n]
-                    stat, with_g = statics[n]
-                    # leading dim per sub-batch is t.shape[0] (= bs for ViT, bs x windows for Swin's window attention)
-                    full = [_cache_like(t, n_sub) for t in stat]
-                    if isinstance(m, MinMaxQuantMatMul):
-                        m.raw_input, m.raw_out = [full[0], full[1]], full[2]
-                    else:
-                        m.raw_input, m.raw_out = full[0], full[1]
-                    if hasattr(m, "metric"):
-                        m.raw_grad = full[-1] if with_g else None
-                    flat_dsts += full
             # every (static tensor -> slice i of its cache) whose memory is one dense block goes through ONE launch per
             # sub-batch (p4v_multi_copy); anything else (overlapping / gapped views) keeps torch's copy
-            block, other = [], []
-            for d, t in zip(flat_dsts, srcs):
-                (block if _same_dense_block(d, t) else other).append((d, t))
+            block = [(d, t) for d, t, b in zip(flat_dsts, srcs, recipe0["is_block"]) if b]
+            other = [(d, t) for d, t, b in zip(flat_dsts, srcs, recipe0["is_block"]) if not b]
             table, max_bytes = None, 0
             if block:
-                rows = [[t.data_ptr(), d.data_ptr(), t.numel() * t.element_size()] for d, t in block]
-                table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                rows = [[t.data_ptr(), d.data_ptr(), t.numel() * 4] for d, t in block]
+                table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
                 max_bytes = max(r[2] for r in rows)
             plans.append((lanes[li], table, len(block), max_bytes, other))
         t_ = tick(f"caches allocated ({sum(d.numel() * 4 for d in flat_dsts) / 2**30:.1f} GiB)", t_)
@@ -511,6 +532,8 @@ class HessianQuantCalibrator(QuantCalibrator):
                 entry["graph"].replay()
                 if table is not None:
                     engine.multi_copy(table, n_block, i, max_bytes, dev)
+                    if i < n_lanes:
+                        table.record_stream(streams[i % n_lanes])     # read on a lane's stream, released without a host sync
                 for d, t in other:
                     d[i * t.shape[0]:(i + 1) * t.shape[0]].copy_(t)
         for s_ in streams:
@@ -722,18 +745,34 @@ class HessianQuantCalibrator(QuantCalibrator):
 
         def run_group(grp):
             t1 = time.time()
+            n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "4"))
+            concurrent = batching and not self.sequential and n_streams > 1 and _dev_of(self.net).type == "cuda" and len(grp) > 1
+            # The search streams wait for the capture ON THE DEVICE (wait_stream): the host does not -- its threads prepare and
+            # enqueue the first searches while the last capture passes still run (a host synchronisation here left the GPU idle
+            # for ~2 ms per calibration: thread start, descriptors, workspace planning).  The capture / search split of the
+            # timings then comes from a device event instead of the host clock.
+            cap_done = None
             if shard_cap:
                 self._capture(names, raw_pred_softmax, with_grad, stride=(rank, world))
                 grad_names = {n for n in names if with_grad and hasattr(self.wrapped_modules[n], "metric")}
                 shard.exchange_captures(self.wrapped_modules, owner, n_sub, grad_names)
             else:
                 self._capture(grp, raw_pred_softmax, with_grad)
-            if torch.cuda.is_available():
+            if concurrent and not shard_cap and os.environ.get("P4V_CAPTURE_SYNC", "0") != "1":
+                dev_g = _dev_of(self.net)
+                cap_done = torch.cuda.Event(enable_timing=True)
+                cap_done.record(torch.cuda.current_stream(dev_g))
+            elif torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()
-            n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "4"))
-            if batching and not self.sequential and n_streams > 1 and _dev_of(self.net).type == "cuda" and len(grp) > 1:
+            if concurrent:
                 self._search_concurrent(grp, n_streams)
+                if cap_done is not None:            # (everything is synchronised now) when the capture really ended
+                    ref = torch.cuda.Event(enable_timing=True)
+                    ref.record(torch.cuda.current_stream(_dev_of(self.net)))
+                    ref.synchronize()
+                    t_end = time.time()
+                    t2 = max(t2, t_end - cap_done.elapsed_time(ref) * 1e-3)
             else:
                 for n in tqdm(grp, desc="Hessian"):
                     module = self.wrapped_modules[n]

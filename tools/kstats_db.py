@@ -34,10 +34,12 @@ def busy(db, t_from_first=None):
     union = 0
     cur_s, cur_e, last_name = rows[0][1], rows[0][2], rows[0][0]
     gaps = {}
+    big = []                # the individual gaps: (length, when, kernel before, kernel after)
     for name, s, e in rows[1:]:
         if s > cur_e:
             union += cur_e - cur_s
             gaps[last_name[:60]] = gaps.get(last_name[:60], 0) + (s - cur_e)
+            big.append((s - cur_e, cur_e - t0, last_name, name))
             cur_s, cur_e, last_name = s, e, name
         elif e > cur_e:
             cur_e, last_name = e, name
@@ -47,6 +49,18 @@ def busy(db, t_from_first=None):
           f"sum of kernel times {1e-6 * ksum:.1f} ms (x{ksum / union:.2f} overlap)")
     for k, v in sorted(gaps.items(), key=lambda kv: -kv[1])[:10]:
         print(f"   idle after {k:60s} {1e-6 * v:8.2f} ms")
+    import os
+    if os.environ.get("KSTATS_GAPS"):      # the longest single gaps of the last calibrations (KSTATS_GAPS=n)
+        tail = [g for g in big if g[1] > 0.75 * (t1 - t0)]
+        hist = {}
+        for g in tail:
+            b = 1 << max(0, int(g[0] / 1e3).bit_length())          # power-of-two buckets in us
+            hist[b] = (hist.get(b, (0, 0))[0] + 1, hist.get(b, (0, 0))[1] + g[0])
+        print("   gaps of the last quarter of the trace by length (us bucket: count, total ms): " +
+              ", ".join(f"<{b}: {c}, {1e-6 * v:.1f}" for b, (c, v) in sorted(hist.items())))
+        short = lambda n: n.replace("void ", "").replace("p4v::", "").replace("at::native::", "")[:46]
+        for g in sorted(tail, key=lambda g: -g[0])[:int(os.environ["KSTATS_GAPS"])]:
+            print(f"   {1e-3 * g[0]:8.1f} us at {1e-6 * g[1]:9.2f} ms  after {short(g[2]):46s} before {short(g[3])}")
 
 
 if len(sys.argv) > 2 and sys.argv[1] == "--busy":
