@@ -100,6 +100,7 @@ thread_local long g_memo_hits = 0, g_memo_misses = 0;
 //   4194304 no exact candidate pruning (every candidate over every sample)   8388608 prune even where the slice's bounds are loose
 //   16777216 pruned passes with several score blocks: stage B1 on the hull of the winners (no synthetic candidate)
 //   33554432 the two fixed planes of a twin row operand from two k_pack launches (not k_pack_dual)
+//   67108864 pruned Linear passes never try the half-size slice first
 //   1, 2: kernel debug flags (SweepParams::dbg)
 //   bit 30: route every int8 sweep through the generic k_sweep
 std::atomic<int> g_variant_word{0};
@@ -626,7 +627,8 @@ struct PlaneCache {
 // (the folded target of the twin activation search is rebuilt per pass).
 struct SliceCache {
     bool assigned = false;
-    int k = 0;
+    int k = 0;                        // rows per segment the buffers are sized for
+    int k_eff = 0;                    // rows per segment in use (a Linear whose 256 heaviest samples hold the weight uses those)
     int* idx = nullptr; float* mass = nullptr; float* mass_u = nullptr;
     float* Os = nullptr; float* Gs = nullptr; float* Rs = nullptr; float* Cs = nullptr;
     const void* idx_src = nullptr; int idx_wt = -1;      // what the ranking was computed from
@@ -1034,20 +1036,21 @@ int run_pass(Ctx& c, Pass& ps) {
 // The sample slice of a module (see SliceCache): geometry, allocation (top of the workspace when the module keeps it, the bump
 // region otherwise) and contents (ranking, share of the metric weight, gathered rows; only what changed is redone).
 struct SliceGeo {
-    bool lin; int segs, seg_rows, k, Ncols, K;
+    bool lin; int segs, seg_rows, k /* rows per segment */, Ncols, K;
     const float* O; const float* G; int wt_mode; long o_ms;
     const float* row_src; long s_r, s_k; int zdiv; long s_z2, s_z;
     bool conv; PackParams conv_pk;     // the row operand is the im2col view of a conv input (flat: rows = (image, pixel))
+    int k_cap;                         // rows per segment the buffers hold (>= k)
 };
 int slice_alloc(Ctx& c, SliceCache* sc, const SliceGeo& g, bool keep, bool bump) {
     if (sc->assigned) {
-        if (sc->k != g.k) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
+        if (sc->k != g.k_cap) return fail(P4V_ERR_INVALID, "slice cache reused with another geometry");
         return 0;
     }
     if (!keep && !bump) return 0;                 // a pass-local slice is allocated later, in the bump region
-    const long zrows = (long)g.segs * g.seg_rows, out_elems = (long)g.segs * g.k * g.Ncols, row_elems = (long)g.segs * g.k * g.K;
+    const long zrows = (long)g.segs * g.seg_rows, out_elems = (long)g.segs * g.k_cap * g.Ncols, row_elems = (long)g.segs * g.k_cap * g.K;
     if (keep) {
-        sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)g.segs * g.k * sizeof(int)));
+        sc->idx = reinterpret_cast<int*>(c.ws.get_top((size_t)g.segs * g.k_cap * sizeof(int)));
         sc->mass = reinterpret_cast<float*>(c.ws.get_top((size_t)zrows * sizeof(float)));
         sc->Os = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
         sc->Gs = reinterpret_cast<float*>(c.ws.get_top((size_t)out_elems * sizeof(float)));
@@ -1055,13 +1058,13 @@ int slice_alloc(Ctx& c, SliceCache* sc, const SliceGeo& g, bool keep, bool bump)
         sc->frac = reinterpret_cast<float*>(c.ws.get_top(256));
         sc->assigned = true;
     } else {
-        sc->idx = c.ws.get<int>((size_t)g.segs * g.k);
+        sc->idx = c.ws.get<int>((size_t)g.segs * g.k_cap);
         sc->mass = c.ws.get<float>((size_t)zrows);
         sc->Os = c.ws.get<float>((size_t)out_elems);
         sc->Gs = c.ws.get<float>((size_t)out_elems);
         sc->Rs = c.ws.get<float>((size_t)row_elems);
     }
-    sc->k = g.k;
+    sc->k = g.k_cap;
     return 0;
 }
 int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
@@ -1085,8 +1088,15 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
             HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
             HIPCHK(hipStreamSynchronize(c.st));
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, g.segs, g.k, g.seg_rows);
+            if (g.k < g.k_cap && !(f >= 0.97f)) {      // the small slice does not hold the weight: the full one (ranked again)
+                SliceGeo g2 = g;
+                g2.k = g.k_cap;
+                sc->idx_src = nullptr;
+                return slice_fill(c, sc, g2, host_sync_ok);
+            }
             if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : 0.5f))) { sc->loose = true; return 0; }
         }
+        sc->k_eff = g.k;
     }
     const int rows = g.segs * g.k;
     auto gather = [&](const float* src, long s0, long s3, int d3, float* dst, int seg, int zdiv, long sz2, long sz) {
@@ -1144,11 +1154,16 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         if (ps.Mrows < 64 || ps.row_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols || ps.o_ms != ps.Ncols || ps.o_ns != 1 ||
             ps.o_bs || ps.o_nbs || ps.row.pk.zdiv <= 0 || ps.row.pk.conv) return run_pass(c, ps);
     }
-    SliceGeo geo{lin, segs, seg_rows, k, ps.Ncols, ps.K, ps.O, ps.G, ps.wt_mode, ps.o_ms, ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k,
-                 ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z, lin && ps.row.pk.conv != 0, ps.row.pk};
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
     if (sc->loose) return run_pass(c, ps);
+    // A Linear first tries HALF the slice: the 256 heaviest samples (ViT: the class-token rows are 32 of them) hold > 97 % of
+    // the weight in every layer but qkv, and stage A costs in proportion to the slice (variant 67108864: always the full slice)
+    const int k_cap = k;
+    if (sc->k_eff > 0) k = sc->k_eff;
+    else if (lin && ps.scache && ps.host_sync_ok && !c.dry && k_cap >= 512 && !(g_variant & (8388608 | 67108864))) k = 256;
+    SliceGeo geo{lin, segs, seg_rows, k, ps.Ncols, ps.K, ps.O, ps.G, ps.wt_mode, ps.o_ms, ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k,
+                 ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z, lin && ps.row.pk.conv != 0, ps.row.pk, k_cap};
     CHK(slice_alloc(c, sc, geo, ps.scache != nullptr, /*bump=*/false));
     const size_t mark = c.ws.off;
     const size_t tab = (size_t)ps.eq_n * std::max(1, ps.nj);
@@ -1168,6 +1183,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     if (!c.dry) {
         CHK(slice_fill(c, sc, geo, ps.host_sync_ok));
         if (sc->loose) { c.ws.off = mark; return run_pass(c, ps); }
+        if (sc->k_eff > 0) k = sc->k_eff;
     }
     // stage A: all candidates on the slice
     a.O = Os; a.G = ps.G ? Gs : nullptr;
@@ -1335,7 +1351,7 @@ int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
     if (!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304) || kp.M < 64 || j.scache->loose)
         return run_sos_split(c, j);
     SliceGeo geo{false, kp.Z, kp.M, k, kp.N, kp.K, kp.O, (kp.wt_mode == 1 ? kp.G : nullptr), kp.wt_mode, (long)kp.N, kp.A, kp.a_r, kp.a_k,
-                 kp.zdiv, kp.a_z2, kp.a_z};
+                 kp.zdiv, kp.a_z2, kp.a_z, false, PackParams{}, k};
     SliceCache* sc = j.scache;
     CHK(slice_alloc(c, sc, geo, true, false));
     const size_t mark = c.ws.off;
