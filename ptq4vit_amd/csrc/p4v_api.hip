@@ -109,7 +109,7 @@ std::atomic<int> g_variant_word{0};
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[16];
 enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8,
-       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10 };   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11 };   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -1157,11 +1157,15 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
     if (sc->loose) return run_pass(c, ps);
-    // A Linear first tries HALF the slice: the 256 heaviest samples (ViT: the class-token rows are 32 of them) hold > 97 % of
-    // the weight in every layer but qkv, and stage A costs in proportion to the slice (variant 67108864: always the full slice)
+    // A Linear first tries a QUARTER of the slice: the M/64 (at least 128) heaviest samples -- in a ViT the class-token rows, one
+    // per image of 197+ tokens, are among them -- hold > 97 % of the weight in every layer but qkv, and stage A costs in proportion
+    // to the slice.  Measured (ViT-B/224 x 32, one box): full slice 155.4 ms per calibration, 256 rows 151.2, 128 rows 148.8,
+    // 64 rows 148.6 (variant 67108864: always the full slice; p4v_debug_set_tuning(11, rows) overrides the size)
     const int k_cap = k;
     if (sc->k_eff > 0) k = sc->k_eff;
-    else if (lin && ps.scache && ps.host_sync_ok && !c.dry && k_cap >= 512 && !(g_variant & (8388608 | 67108864))) k = 256;
+    else if (lin && ps.scache && ps.host_sync_ok && !c.dry && k_cap >= 512 && !(g_variant & (8388608 | 67108864)))
+        k = tune(TUNE_SLICE_SMALL) > 0 ? std::min(tune(TUNE_SLICE_SMALL), k_cap)
+                                       : (int)std::min<long>(std::max<long>(128, rup(ps.Mrows / 64, 64)), k_cap / 2);
     SliceGeo geo{lin, segs, seg_rows, k, ps.Ncols, ps.K, ps.O, ps.G, ps.wt_mode, ps.o_ms, ps.row.pk.src, ps.row.pk.s_r, ps.row.pk.s_k,
                  ps.row.pk.zdiv, ps.row.pk.s_z2, ps.row.pk.s_z, lin && ps.row.pk.conv != 0, ps.row.pk, k_cap};
     CHK(slice_alloc(c, sc, geo, ps.scache != nullptr, /*bump=*/false));
