@@ -457,7 +457,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         # A pass at 4 images is a chain of ~1500 kernels of a few microseconds each: the GPU is mostly idle while it runs.
         # `capture_lanes` instances of the graph (own static tensors each) replay different sub-batches on different
         # streams at the same time; every sub-batch still runs exactly the recorded kernels, so the caches do not change.
-        want = int(getattr(self, "capture_lanes", None) or os.environ.get("P4V_CAPTURE_LANES", "2"))
+        want = int(getattr(self, "capture_lanes", None) or os.environ.get("P4V_CAPTURE_LANES", "3"))
         while len(lanes) < max(1, min(want, n_sub)):
             entry = self._build_graph(dev, bs, inp, raw_pred_softmax)
             if entry is None:
