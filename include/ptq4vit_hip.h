@@ -358,6 +358,13 @@ int p4v_stats_enable(int enable);   /* 1 / 0: launch timing on the calling threa
 int p4v_stats_reset(void);
 int p4v_stats_get(p4v_kernel_stats* out);
 
+/* Exact candidate pruning (csrc/p4v_api.hip::run_pass_pruned), PROCESS-WIDE counters since the last reset -- whatever thread
+ * or stream ran the search passes: out4[0] passes run in three stages (slice / bound / survivors), out4[1] those whose
+ * survivor stage was empty, out4[2] eligible passes that kept the full sweep (slice too large, metric weight spread over the
+ * samples, unsupported layout), out4[3] passes that are never pruned (score tables requested, cosine, fp32 operand planes,
+ * desc.reserved bit 3).  Tests and bench.py use them to assert WHICH path produced a result.  `out4` may be NULL. */
+int p4v_prune_counters(int64_t* out4, int reset);
+
 /* A/B switches for measurements and kernel-vs-kernel agreement tests; never needed in production (default 0).
  * `variant` disables individual kernel paths (bit list in csrc/p4v_api.hip), `force_generic` routes every int8 sweep
  * through the generic kernel.  Process-wide, relaxed atomics: set them while no call is in flight. */

@@ -71,7 +71,20 @@ def _t(a):
 
 
 # --------------------------------------------------------------------------- #
-def gen_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bias=True, **kw):
+def _cls_heavy(grad, token_dim, g):
+    """raw_grad of a ViT under the reference's KL loss: the classifier reads the class token only, so the rows of token 0
+    carry almost all of grad^2 (measured on ViT-B: > 99 %), unevenly over the images.  Scales the class-token rows of a
+    noise gradient by 300 x a per-image factor (in place on a clone)."""
+    grad = grad.clone()
+    per_image = torch.exp(torch.randn(grad.shape[0], generator=g))
+    idx = [slice(None)] * grad.dim()
+    idx[token_dim] = 0
+    shape = [grad.shape[0]] + [1] * (grad[tuple(idx)].dim() - 1)
+    grad[tuple(idx)] = grad[tuple(idx)] * 300.0 * per_image.view(shape)
+    return grad
+
+
+def gen_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bias=True, cls_heavy=False, store_qf=True, **kw):
     from quant_layers.linear import PTQSLBatchingQuantLinear, PostGeluPTQSLBatchingQuantLinear
 
     g = torch.Generator().manual_seed(seed)
@@ -85,6 +98,8 @@ def gen_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bi
         x = F.gelu(1.5 * x)
     out = F.linear(x, w, b)
     grad = torch.randn(out.shape, generator=g) * grad_scale
+    if cls_heavy:
+        grad = _cls_heavy(grad, 1, g)
     cls = PostGeluPTQSLBatchingQuantLinear if postgelu else PTQSLBatchingQuantLinear
     m = cls(ic, oc, bias=bias, **kw)
     m.weight.data = w.clone()
@@ -100,12 +115,14 @@ def gen_linear(name, *, shape_x, oc, postgelu=False, grad_scale=1e-3, seed=0, bi
                   w_interval=m.w_interval.numpy(), a_interval=m.a_interval.numpy(),
                   quant_forward=qf.numpy(),
                   calib=np.array([m.calib_size, m.calib_batch_size, m.parallel_eq_n]))
+    if not store_qf:                                  # the larger fixtures: the output is as big as raw_out
+        arrays["quant_forward"] = qf.numpy()[:1, :8]
     if bias:
         arrays["bias"] = b.numpy()
     _save(name, dict(kind="linear", postgelu=postgelu, oc=oc, **kw), arrays, rec.tables)
 
 
-def gen_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, **kw):
+def gen_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, cls_heavy=False, store_qf=True, **kw):
     from quant_layers.matmul import PTQSLBatchingQuantMatMul, SoSPTQSLBatchingQuantMatMul
 
     g = torch.Generator().manual_seed(seed)
@@ -117,6 +134,8 @@ def gen_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, **
     Bm = (torch.randn(b, H, d3, d2, generator=g) * torch.linspace(2.0, 0.5, H).view(1, H, 1, 1)).transpose(-2, -1)
     out = A @ Bm
     grad = torch.randn(out.shape, generator=g) * grad_scale
+    if cls_heavy:
+        grad = _cls_heavy(grad, 2, g)                 # the query row of the class token
     cls = SoSPTQSLBatchingQuantMatMul if sos else PTQSLBatchingQuantMatMul
     m = cls(**kw)
     m.raw_input, m.raw_out, m.raw_grad = [A.clone(), Bm.clone()], out.clone(), grad.clone()
@@ -128,6 +147,8 @@ def gen_matmul(name, *, b, H, d1, d2, d3, sos=False, grad_scale=1e-3, seed=0, **
     arrays = dict(A=A.numpy(), B=Bm.contiguous().numpy(), out=out.numpy(), grad=grad.numpy(),
                   A_interval=np.asarray(m.A_interval), B_interval=m.B_interval.numpy(),
                   quant_forward=qf.numpy())
+    if not store_qf:
+        arrays["quant_forward"] = qf.numpy()[:1, :1, :8]
     if sos:
         arrays["split"] = np.asarray(m.split)
     _save(name, dict(kind="matmul", sos=sos, **kw), arrays, rec.tables)
@@ -240,6 +261,25 @@ def main(only=None):
              metric="hessian", eq_alpha=0.3, eq_beta=1.2, eq_n=30, search_round=2)
 
 
+
+
+def gen_prune_eligible():
+    """Layer cases the reference runs in seconds that are LARGE ENOUGH for the build's exact candidate pruning to engage
+    (csrc/p4v_api.hip::run_pass_pruned: a Linear needs >= 640 samples, a MatMul >= 64 query rows) with the gradient profile
+    of a ViT (class-token rows carry the weight, |g| ~ 1e-10 as the reference's KL loss produces): the
+    reference's own intervals and score tables pin the DEFAULT call of the engine -- no score tables requested, pruned
+    passes -- in tests/test_hip_production_path.py.  Prefix `prune_`: the generic parametrised golden tests do not load
+    these (they are ~1-2 MB each)."""
+    _install_shims()
+    os.chdir(REF)
+    gen_linear("prune_linear_qkv_hessian_w8a8", shape_x=(4, 197, 128), oc=192, n_V=3, w_bit=8, a_bit=8, seed=70,
+               grad_scale=1e-10, cls_heavy=True, store_qf=False, **PTQ4VIT)
+    gen_linear("prune_postgelu_hessian_w8a8", shape_x=(4, 197, 256), oc=64, postgelu=True, n_V=1, w_bit=8, a_bit=8, seed=71,
+               grad_scale=1e-10, cls_heavy=True, store_qf=False, **PTQ4VIT)
+    gen_matmul("prune_matmul_qk_hessian_w8a8", b=2, H=2, d1=197, d2=32, d3=197, A_bit=8, B_bit=8, seed=72,
+               grad_scale=1e-10, cls_heavy=True, store_qf=False, **PTQ4VIT)
+    gen_matmul("prune_matmul_sos_hessian_w8a8", b=2, H=2, d1=197, d2=197, d3=32, sos=True, A_bit=8, B_bit=8, seed=73,
+               grad_scale=1e-10, cls_heavy=True, store_qf=False, **PTQ4VIT)
 
 
 # --------------------------------------------------------------------------- #
@@ -656,6 +696,8 @@ if __name__ == "__main__":
         gen_f4_calibrators()
     elif len(sys.argv) > 1 and sys.argv[1] == "integer":
         gen_integer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "prune":
+        gen_prune_eligible()
     else:
         main(sys.argv[1] if len(sys.argv) > 1 else None)
         if len(sys.argv) == 1:
@@ -665,3 +707,4 @@ if __name__ == "__main__":
             gen_deit_tiny()
             gen_f4_layers()
             gen_f4_calibrators()
+            gen_prune_eligible()

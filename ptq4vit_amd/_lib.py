@@ -78,7 +78,7 @@ EXPORTS = [
     "p4v_amax_init_conv", "p4v_conv_search_w_channelwise", "p4v_conv_search_w_layerwise", "p4v_conv_search_a",
     "p4v_score_argmax_gather",
     "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize", "p4v_multi_copy",
-    "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get",
+    "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get", "p4v_prune_counters",
     "p4v_debug_set_variant", "p4v_debug_set_tuning",
 ]
 
@@ -157,6 +157,8 @@ def load():
     lib.p4v_stats_reset.restype = C.c_int
     lib.p4v_stats_get.restype = C.c_int
     lib.p4v_stats_get.argtypes = [C.POINTER(KernelStats)]
+    lib.p4v_prune_counters.restype = C.c_int
+    lib.p4v_prune_counters.argtypes = [C.POINTER(C.c_int64), C.c_int]
     _lib = lib
     return lib
 

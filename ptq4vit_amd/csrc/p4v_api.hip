@@ -85,6 +85,12 @@ thread_local bool g_stat_on = false;
 thread_local std::vector<StatRec> g_stat_recs;
 thread_local p4v_kernel_stats g_stats = {};
 thread_local long g_memo_hits = 0, g_memo_misses = 0;
+// Process-wide counters of the exact candidate pruning (p4v_prune_counters): tests and bench.py assert with them that the
+// three-stage passes -- not the full sweeps -- produced a result, whatever thread / stream the calibrator ran the module on.
+//   [0] passes run in three stages   [1] ... whose stage B2 was empty (B1's candidates were the only survivors; host knew)
+//   [2] prunable passes that ran the full sweep instead (slice too large / loose bounds / unsupported layout)
+//   [3] passes not eligible at all (score tables requested, cosine, fp32 planes, pruning switched off)
+std::atomic<long long> g_prune_cnt[4];
 // Kernel-variant switches for A/B measurements and kernel-vs-kernel agreement tests (p4v_debug_set_variant; 0 in
 // production).  One relaxed atomic word, read once per pass:
 //   4   no stationary-operand sweeps (everything on k_sweep2)      8   k_sweep4 instead of k_sweep5 (one candidate per pass)
@@ -1132,8 +1138,9 @@ int launch_pass_select(Ctx& c, const Pass& ps, const float* scores) {
     return launch_select(c, sl);
 }
 
+#define PRUNE_COUNT(i) do { if (!c.dry) g_prune_cnt[i].fetch_add(1, std::memory_order_relaxed); } while (0)
 int run_pass_pruned(Ctx& c, Pass& ps) {
-    if (!prune_ok(ps)) return run_pass(c, ps);
+    if (!prune_ok(ps)) { PRUNE_COUNT(3); return run_pass(c, ps); }
     const bool lin = ps.Z == 1;
     // geometry of the slice.  Linear: the k heaviest of its M samples (rows of x / raw_out / raw_grad).  MatMul: the 16
     // heaviest rows (queries) of EVERY batch entry (image, head) -- the column operand stays whole.  Measured on ViT-B/224 x 32
@@ -1144,19 +1151,19 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     int k;                                                           // rows taken per segment
     if (lin) {
         k = (int)std::min<long>(rup(std::max(1, ps.Mrows / (tune(TUNE_SLICE_DIV) > 0 ? tune(TUNE_SLICE_DIV) : 16)), 256), rup(ps.Mrows, 256));
-        if ((long)k * 5 > (long)ps.Mrows * 2) return run_pass(c, ps);         // slice > 40 % of the samples: not worth the stages
+        if ((long)k * 5 > (long)ps.Mrows * 2) { PRUNE_COUNT(2); return run_pass(c, ps); }   // slice > 40 % of the samples: not worth the stages
         // dense row-major operands only (or the im2col rows of a conv input, gathered element by element)
         const bool conv_rows = ps.row.pk.conv && ps.row.pk.Z == 1 && !ps.twin;
         if (ps.o_ms != ps.Ncols || ps.o_ns != 1 || ps.o_bs || ps.o_nbs || ps.row.pk.zdiv > 0 ||
-            (!conv_rows && (ps.row.pk.conv || ps.row.pk.s_k != 1 || ps.row.pk.s_r != ps.K))) return run_pass(c, ps);
+            (!conv_rows && (ps.row.pk.conv || ps.row.pk.s_k != 1 || ps.row.pk.s_r != ps.K))) { PRUNE_COUNT(2); return run_pass(c, ps); }
     } else {
         k = 16;
         if (ps.Mrows < 64 || ps.row_zs_shared || ps.o_zs != (long)ps.Mrows * ps.Ncols || ps.o_ms != ps.Ncols || ps.o_ns != 1 ||
-            ps.o_bs || ps.o_nbs || ps.row.pk.zdiv <= 0 || ps.row.pk.conv) return run_pass(c, ps);
+            ps.o_bs || ps.o_nbs || ps.row.pk.zdiv <= 0 || ps.row.pk.conv) { PRUNE_COUNT(2); return run_pass(c, ps); }
     }
     SliceCache local;
     SliceCache* sc = ps.scache ? ps.scache : &local;
-    if (sc->loose) return run_pass(c, ps);
+    if (sc->loose) { PRUNE_COUNT(2); return run_pass(c, ps); }
     // A Linear first tries a QUARTER of the slice: the M/64 (at least 128) heaviest samples -- in a ViT the class-token rows, one
     // per image of 197+ tokens, are among them -- hold > 97 % of the weight in every layer but qkv, and stage A costs in proportion
     // to the slice.  Measured (ViT-B/224 x 32, one box): full slice 155.4 ms per calibration, 256 rows 151.2, 128 rows 148.8,
@@ -1186,9 +1193,10 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     Pass a = ps;
     if (!c.dry) {
         CHK(slice_fill(c, sc, geo, ps.host_sync_ok));
-        if (sc->loose) { c.ws.off = mark; return run_pass(c, ps); }
+        if (sc->loose) { c.ws.off = mark; PRUNE_COUNT(2); return run_pass(c, ps); }
         if (sc->k_eff > 0) k = sc->k_eff;
     }
+    PRUNE_COUNT(0);
     // stage A: all candidates on the slice
     a.O = Os; a.G = ps.G ? Gs : nullptr;
     a.Mrows = k;
@@ -1236,6 +1244,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
         if (h[0] >= h[1]) {
+            PRUNE_COUNT(1);
             if (hull_selects) {}          // k_prune_hull made the selection
             else if (virt) {          // every block's only survivor is its stage-A winner: the table with those entries filled in
                 hipLaunchKernelGGL(k_fill_f32, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, -INFINITY, (int)tab);
@@ -1352,8 +1361,10 @@ int run_sos_split(Ctx& c, SosSplitJob& j) {
 int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
     const SosSplitParams& kp = j.kp;
     const int k = 16;
-    if (!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304) || kp.M < 64 || j.scache->loose)
+    if (!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304) || kp.M < 64 || j.scache->loose) {
+        PRUNE_COUNT((!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304)) ? 3 : 2);
         return run_sos_split(c, j);
+    }
     SliceGeo geo{false, kp.Z, kp.M, k, kp.N, kp.K, kp.O, (kp.wt_mode == 1 ? kp.G : nullptr), kp.wt_mode, (long)kp.N, kp.A, kp.a_r, kp.a_k,
                  kp.zdiv, kp.a_z2, kp.a_z, false, PackParams{}, k};
     SliceCache* sc = j.scache;
@@ -1367,8 +1378,9 @@ int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     if (!c.dry) {
         CHK(slice_fill(c, sc, geo, j.host_sync_ok));
-        if (sc->loose) { c.ws.off = mark; return run_sos_split(c, j); }
+        if (sc->loose) { c.ws.off = mark; PRUNE_COUNT(2); return run_sos_split(c, j); }
     }
+    PRUNE_COUNT(0);
     SosSplitParams a = kp;                       // stage A: dense slices [Z][16][K] / [Z][16][N]
     a.A = sc->Rs; a.a_k = 1; a.a_r = kp.K; a.a_z = (long)k * kp.K; a.a_z2 = (long)kp.zdiv * k * kp.K;
     a.O = sc->Os; a.G = (kp.wt_mode == 1) ? sc->Gs : sc->Os; a.M = k; a.halves = 1;
@@ -1382,7 +1394,7 @@ int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
         int h[2] = {0, 1};
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
-        if (h[0] >= h[1]) { c.ws.off = mark; return 0; }
+        if (h[0] >= h[1]) { PRUNE_COUNT(1); c.ws.off = mark; return 0; }
     }
     CHK(sos_sweep(c, j, kp, r2, S2));             // B2
     if (!c.dry) {
@@ -2369,6 +2381,12 @@ int p4v_stats_get(p4v_kernel_stats* out) {
     g_stats.memo_hits = g_memo_hits; g_stats.memo_misses = g_memo_misses;
     *out = g_stats;
     return r;
+}
+
+int p4v_prune_counters(int64_t* out4, int reset) {
+    if (out4) for (int i = 0; i < 4; ++i) out4[i] = (int64_t)g_prune_cnt[i].load(std::memory_order_relaxed);
+    if (reset) for (int i = 0; i < 4; ++i) g_prune_cnt[i].store(0, std::memory_order_relaxed);
+    return 0;
 }
 
 int p4v_debug_set_variant(int variant, int force_generic) {

@@ -535,3 +535,12 @@ def stats_get():
     s = _lib.KernelStats()
     _lib.check(_lib.load().p4v_stats_get(C.byref(s)), "p4v_stats_get")
     return {k: getattr(s, k) for k, _ in _lib.KernelStats._fields_}
+
+
+def prune_counters(reset=False):
+    """Process-wide counters of the exact candidate pruning since the last reset (p4v_prune_counters): how many search
+    passes ran in three stages, how many of those had no survivors besides the bound's candidates, how many eligible passes
+    kept the full sweep, how many were never eligible (score tables, cosine, fp32 planes, pruning switched off)."""
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.load().p4v_prune_counters(out, int(bool(reset))), "p4v_prune_counters")
+    return dict(zip(("staged", "staged_no_survivors", "kept_full_sweep", "not_eligible"), (int(v) for v in out)))

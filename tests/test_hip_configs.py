@@ -12,7 +12,8 @@ finishes in seconds (same captured tensors, same bar as the layer tests):
   * every calibrated interval is EXACTLY one entry of its candidate table: fl(mult[i] * initial interval) for some
     searched i, with the initial interval recomputed from the weights / captured inputs (linear.py:385,544-545);
   * the split of every split-of-softmax matmul is one of 2^-i, i < 20, and A_interval = split / (qmax - 1);
-  * the `head` Linear (2-D input case, linear.py:483) and one attention matmul against the oracle;
+  * the `head` Linear (2-D input case, linear.py:483) and one attention matmul, pass by pass against the torch-CPU restatement
+    of the reference on the captured tensors (tests/follow.py: hard near-tie bound on every selection);
   * the quantised network runs and stays close to the raw network.
 """
 import contextlib
@@ -22,7 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_on_candidate_grid, candidate_grid
+from tests.helpers import candidate_grid
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +45,6 @@ def _restore_bits(cfg, saved):
 
 
 def _run_config(model, bits, calib, oracle_matmul=None, logits_rel=0.35):
-    from oracle.ptq4vit_oracle import LinearOracle, MatMulOracle
     from ptq4vit_amd import engine
     from ptq4vit_amd.configs import PTQ4ViT
     from ptq4vit_amd.quant_layers.conv import MinMaxQuantConv2d
@@ -135,29 +135,37 @@ def _run_config(model, bits, calib, oracle_matmul=None, logits_rel=0.35):
                 n_iv += on_grid(m.A_interval, init_a[n][0], "A_interval")
     print(f"[config] {n_iv} intervals are exact entries of their candidate tables")
 
-    # the oracle on the layers it finishes in seconds, same captured tensors
-    npy = lambda t: None if t is None else t.detach().cpu().numpy()
+    # the reference's search (torch-CPU restatement, oracle/torch_port.py) on the layers it finishes in seconds, same captured
+    # tensors, PASS BY PASS from the engine's own pass inputs (tests/follow.py): every selection is the restatement's argmax or
+    # a near-tie by its scores (TIE_RTOL) -- a hard bound, not a printed count -- and the stand-alone default call reproduces
+    # the interval the module got inside the network bit for bit
+    from tests.follow import follow_linear, follow_matmul
+    cpu = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     for n in sorted(keep):
         m = wrapped[n]
         ri, ro, rg = caps[n]
-        hp = dict(metric=m.metric, eq_alpha=m.eq_alpha, eq_beta=m.eq_beta, eq_n=m.eq_n, search_round=m.search_round)
-        mult = candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n)
+        hp = dict(metric=m.metric, eq_alpha=m.eq_alpha, eq_beta=m.eq_beta, eq_n=m.eq_n)
+        engine.prune_counters(reset=True)
         if isinstance(m, MinMaxQuantLinear):
-            o = LinearOracle(npy(m.weight), npy(m.bias), w_bit=bits, a_bit=bits, n_V=m.n_V, **hp)
-            res = o.calibration_step2(ri, ro, rg)
+            flips, w_iv, a_iv = follow_linear(engine, weight=m.weight.detach().float().cpu(), bias=None if m.bias is None else m.bias.detach().float().cpu(),
+                                              x=cpu(ri), out=cpu(ro), grad=cpu(rg), rounds=m.search_round, what=n, expect_pruned=False,
+                                              hp=dict(w_bit=bits, a_bit=bits, n_V=m.n_V, postgelu=m._postgelu, **hp))
+            got = {"w_interval": w_iv, "a_interval": a_iv}
         else:
-            o = MatMulOracle(A_bit=bits, B_bit=bits, sos=m._sos, chunk=2, **hp)
-            res = o.calibration_step2(ri[0], ri[1], ro, rg)
-        moved = 0
-        for a, want in res.items():
-            got = torch.as_tensor(getattr(m, a)).detach().cpu().numpy()
-            if a == "split":
-                assert float(got) == float(want), f"{n}.split {float(got)} vs oracle {float(want)}"
-            elif m.__class__.__name__.startswith("SoS") and a == "A_interval":
-                assert float(got) == float(want)
-            else:
-                moved += assert_on_candidate_grid(got, want, mult, f"{n}.{a}")
-        print(f"[config] oracle on {n}: {moved} intervals on a neighbouring grid entry (near-ties), the rest bit-identical")
+            A = cpu(ri[0])
+            B = cpu(ri[1])
+            if n.endswith("matmul1"):           # q.k^T: the module saw k.transpose(-2, -1), a view (utils/models.py:16)
+                B = B.transpose(-2, -1).contiguous().transpose(-2, -1)
+            flips, A_iv, B_iv, split = follow_matmul(engine, A=A, B=B, out=cpu(ro), grad=cpu(rg), rounds=m.search_round, sos=m._sos, what=n,
+                                                     expect_pruned=False, hp=dict(A_bit=bits, B_bit=bits, **hp))
+            got = {"A_interval": A_iv, "B_interval": B_iv}
+            if m._sos:
+                got["split"] = split
+        for a, v in got.items():
+            mine = torch.as_tensor(getattr(m, a)).detach().float().cpu().reshape(-1)
+            assert torch.equal(mine, v.reshape(-1)), f"{n}.{a}: in the network {mine.tolist()[:4]} vs stand-alone {v.reshape(-1).tolist()[:4]}"
+        print(f"[config] {n}: {2 * m.search_round} search passes followed against the reference's restatement, {flips} near-tie flips "
+              f"(each within TIE_RTOL of its maximum); pruning counters {engine.prune_counters(reset=True)}")
 
     with torch.no_grad():
         ql = net(images[:8]).float().cpu()

@@ -1,0 +1,274 @@
+"""GPU: the path bench.py times -- the DEFAULT call of the engine (exact candidate pruning + pass memo, no score tables) --
+pinned directly, not by transitivity:
+
+  (a) at BASELINE shapes (ViT-B/224 x 32 images: proj / fc1 / fc2-twin / qkv at 32 x 197 rows, q.k^T and attn.v at
+      32 x 12 x 197, the patch embedding at 32 x 224^2) with the gradient profile of a ViT under the reference's KL loss
+      (class-token rows carry > 99 % of raw_grad^2, |g| ~ 1e-10): every search pass of the default call against the torch-CPU
+      restatement of the reference scored from the engine's own pass input (tests/follow.py), selection = its argmax or a
+      near-tie by ITS scores (TIE_RTOL, hard); the pruning counters assert that the three-stage passes ran;
+  (b) a whole ViT-B/224 x 32 calibration with pruning on and off: all ~1 340 interval scalars bit-identical;
+  (c) four layer cases calibrated BY THE REFERENCE ITSELF at sizes where the pruning engages (tests/golden/prune_*.npz,
+      oracle/gen_golden.py::gen_prune_eligible): default call == the reference's intervals (tie-aware by the reference's
+      own tables), and the unpruned call's score tables within SCORE_RTOL of the reference's.
+
+Reference: quant_layers/linear.py:455-555, matmul.py:483-576,600-644, conv.py:526-607.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.follow import _expect_staged, _lookup, follow_conv, follow_linear, follow_matmul
+from tests.helpers import (assert_argmax_tie_aware, assert_scores_close, candidate_grid, golden_names, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+PTQ4VIT = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ptq4vit_amd import engine
+    return engine
+
+
+def vit_like_grad(shape, token_dim, g, scale=1e-10):
+    """Noise of the magnitude the reference's KL(pred || raw_pred) gradient has with the class-token rows
+    lifted so that they hold > 99 % of grad^2, unevenly over the images (profiles/r3_row_mass.txt: max / mean row mass ~ 2000
+    on ViT-B/224 x 32)."""
+    grad = torch.randn(shape, generator=g) * scale
+    per_image = torch.exp(torch.randn(shape[0], generator=g))
+    idx = [slice(None)] * len(shape)
+    idx[token_dim] = 0
+    view = [shape[0]] + [1] * (len(shape) - 2)
+    grad[tuple(idx)] *= 300.0 * per_image.view(view)
+    return grad
+
+
+def _row_mass_stats(grad, rows_dim_end):
+    m = (grad.double() ** 2).flatten(rows_dim_end).sum(-1).flatten()
+    top = torch.topk(m, max(1, m.numel() // 64)).values.sum() / m.sum()
+    return float(m.max() / m.mean()), float(top)
+
+
+@pytest.mark.parametrize("layer,K,N,n_V,postgelu", [("proj", 768, 768, 1, False), ("fc1", 768, 3072, 1, False),
+                                                    ("fc2", 3072, 768, 1, True), ("qkv", 768, 2304, 3, False)])
+def test_default_linear_call_at_baseline_shape_follows_the_reference_pass_by_pass(eng, layer, K, N, n_V, postgelu):
+    g = torch.Generator().manual_seed({"proj": 11, "fc1": 12, "fc2": 13, "qkv": 14}[layer])
+    x = torch.randn(32, 197, K, generator=g)
+    if postgelu:
+        x = F.gelu(1.5 * x)
+    w = torch.nn.init.trunc_normal_(torch.empty(N, K), std=0.02, generator=g) * torch.linspace(0.7, 1.4, N)[:, None]
+    b = torch.randn(N, generator=g) * 0.02
+    out = F.linear(x, w, b)
+    grad = vit_like_grad(out.shape, 1, g)
+    peak, top = _row_mass_stats(grad, 2)
+    assert peak > 1000 and top > 0.99, (peak, top)
+    hp = dict(w_bit=8, a_bit=8, n_V=n_V, postgelu=postgelu, **PTQ4VIT)
+    flips, w_iv, a_iv = follow_linear(eng, weight=w, bias=b, x=x, out=out, grad=grad, hp=hp, what=f"ViT-B {layer}")
+    print(f"[production] ViT-B {layer} 32 x 197: class-token rows {top:.4f} of the weight (max / mean row mass {peak:.0f}); "
+          f"6 passes followed, {flips} near-tie flips; w_interval {w_iv.tolist()[:3]} a_interval {a_iv.tolist()}")
+
+
+@pytest.mark.parametrize("kind", ["qk", "sv"])
+def test_default_matmul_call_at_baseline_shape_follows_the_reference_pass_by_pass(eng, kind):
+    g = torch.Generator().manual_seed(21 if kind == "qk" else 22)
+    b, H, S, D = 32, 12, 197, 64
+    if kind == "qk":
+        A = torch.randn(b, H, S, D, generator=g) * torch.linspace(0.5, 2.0, H).view(1, H, 1, 1)
+        B = (torch.randn(b, H, S, D, generator=g) * torch.linspace(2.0, 0.5, H).view(1, H, 1, 1)).transpose(-2, -1)
+    else:
+        A = torch.softmax(torch.randn(b, H, S, S, generator=g) * 3.0, dim=-1)
+        B = torch.randn(b, H, S, D, generator=g) * torch.linspace(2.0, 0.5, H).view(1, H, 1, 1)
+    out = A @ B
+    grad = vit_like_grad(out.shape, 2, g)
+    hp = dict(A_bit=8, B_bit=8, **PTQ4VIT)
+    flips, A_iv, B_iv, split = follow_matmul(eng, A=A, B=B, out=out, grad=grad, hp=hp, sos=(kind == "sv"), what=f"ViT-B {kind}")
+    print(f"[production] ViT-B {'q.k^T' if kind == 'qk' else 'attn.v (split of softmax)'} 32 x 12 x 197: 6 passes followed, "
+          f"{flips} near-tie flips; split {None if split is None else float(split)}")
+
+
+def test_default_conv_call_at_baseline_shape_follows_the_reference(eng):
+    g = torch.Generator().manual_seed(23)
+    w = torch.nn.init.trunc_normal_(torch.empty(768, 3, 16, 16), std=0.02, generator=g) * torch.linspace(0.5, 2.0, 768).view(-1, 1, 1, 1)
+    b = torch.randn(768, generator=g) * 0.02
+    x = torch.randn(32, 3, 224, 224, generator=g)
+    out = F.conv2d(x, w, b, stride=16)
+    # the patch embedding's raw_grad is spread over the pixels (profiles/r3_row_mass.txt: the top 1/8 of the pixel rows hold
+    # 0.85 of it): a smooth decay over the pixel rows instead of one heavy row
+    grad = torch.randn(out.shape, generator=g) * 1e-10
+    decay = torch.exp(-torch.rand(32, 1, 14, 14, generator=g) * 9.0)
+    grad = grad * decay
+    hp = dict(w_bit=8, a_bit=32, **PTQ4VIT)
+    flips, w_iv = follow_conv(eng, weight=w, bias=b, x=x, out=out, grad=grad, stride=16, hp=hp, what="ViT-B patch embedding")
+    print(f"[production] ViT-B patch embedding 32 x 224^2: 768 channel searches, {flips} near-tie flips")
+
+
+def _intervals(wrapped):
+    out = {}
+    for n, m in wrapped.items():
+        out[n] = [torch.as_tensor(getattr(m, a)).detach().clone() for a in ("w_interval", "a_interval", "A_interval", "B_interval", "split")
+                  if getattr(m, a, None) is not None and not isinstance(getattr(m, a), (list, tuple))]
+    return out
+
+
+def test_whole_vit_base_calibration_is_bit_identical_with_and_without_pruning(eng):
+    """BASELINE headline configuration (ViT-B/224 W8A8 PTQ4ViT, 32 images, 74 modules): the calibration bench.py times, then the
+    same calibration with the exact candidate pruning switched off (variant 4194304: every candidate over every sample)."""
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    torch.cuda.empty_cache()
+    eng.release_workspace()
+    net = models.get_net("vit_base_patch16_224", seed=0, device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+
+    class Loader:
+        batch_size = 32
+
+        def __iter__(self):
+            yield images, None
+
+    def calibrate():
+        for m in wrapped.values():
+            m.mode = "raw"
+        eng.prune_counters(reset=True)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
+        torch.cuda.synchronize()
+        return _intervals(wrapped), eng.prune_counters(reset=True)
+
+    pruned, c_on = calibrate()
+    again, _ = calibrate()
+    try:
+        eng.debug_variant(4194304)
+        full, c_off = calibrate()
+    finally:
+        eng.debug_variant(0)
+    # every executed pass of the 74 modules but the `head` Linear's (32 samples: its slice would be the whole layer)
+    assert c_on["staged"] >= 200 and c_on["kept_full_sweep"] <= 6 and c_on["not_eligible"] == 0, c_on
+    assert c_off["staged"] == 0, c_off
+    n = 0
+    for name in pruned:
+        for a, b, c in zip(pruned[name], again[name], full[name]):
+            assert torch.equal(a, b), f"{name}: pruned calibration is not run-to-run deterministic"
+            assert torch.equal(a, c), f"{name}: pruned {a.flatten()[:4].tolist()} vs unpruned {c.flatten()[:4].tolist()}"
+            n += a.numel()
+    assert n >= 1334                 # 1 334 interval scalars (the 12 splits / their A_intervals counted as stored)
+    print(f"[production] ViT-B/224 x 32: {n} intervals bit-identical with pruning on ({c_on}) and off ({c_off})")
+    del net, wrapped, images
+    torch.cuda.empty_cache()
+    eng.release_workspace()
+
+
+# ---- (c) the reference's own run at pruning-eligible sizes ---------------------------------------------------------------
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _follow_reference_tables(picks, tables, what):
+    """picks[i]: candidate indices the engine selected in pass i; tables[i]: the table the REFERENCE fed to argmax in its pass i.
+    The passes are comparable as long as both followed the same trajectory: stop at the first pass where they part (which must
+    be a near-tie by the reference's own scores).  Returns the number of passes compared and whether the trajectories parted."""
+    for i, (idx, tab) in enumerate(zip(picks, tables)):
+        tab = np.asarray(tab).reshape(tab.shape[0], -1)
+        flips = assert_argmax_tie_aware(idx, tab, what=f"{what} pass {i}")
+        if flips:
+            return i + 1, True
+    return len(picks), False
+
+
+@pytest.mark.parametrize("name", golden_names("prune_linear_") + golden_names("prune_postgelu_"))
+def test_default_linear_call_reproduces_the_reference_at_a_pruning_eligible_size(eng, name):
+    from oracle.torch_port import TorchLinear
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind"); p.pop("oc")
+    R = p.pop("search_round")
+    args = dict(weight=_t(g["weight"]).cuda(), bias=_t(g["bias"]).cuda(), x=_t(g["x"]).cuda(), out=_t(g["out"]).cuda(),
+                grad=_t(g["grad"]).cuda(), n_H=1, n_a=1, **p)
+    # the unpruned call's tables against the reference's (the bar of tests/test_hip_parity.py, at this size)
+    w_f, a_f, scores, best = eng.linear_calibrate(search_round=R, want_scores=True, **args)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    parted = False
+    for r in range(R):
+        for k, (tab, idx) in enumerate(((scores[r, 0], best[r, 0]), (scores[r, 1][:, :1], best[r, 1][:1]))):
+            ref = g["scores"][2 * r + k].reshape(tab.shape[0], -1)
+            if not parted:
+                assert_scores_close(tab[:, :ref.shape[1]], ref, what=f"{name} round {r} {'wa'[k]}")
+                parted = assert_argmax_tie_aware(idx[:ref.shape[1]], ref, what=f"{name} round {r} {'wa'[k]}") > 0
+    # the default call, pass by pass against the reference's own tables
+    port = TorchLinear(g["weight"], g["bias"], **{k: v for k, v in p.items()})
+    _, _, w_c, a_c = port.initial(_t(g["x"]))
+    picks = []
+    for r in range(1, R + 1):
+        eng.prune_counters(reset=True)
+        w_iv, a_iv, sc, _ = eng.linear_calibrate(search_round=r, **args)
+        torch.cuda.synchronize()
+        assert sc is None
+        _expect_staged(eng, f"{name} R={r}")
+        picks += [_lookup(w_c.numpy(), w_iv.cpu().numpy(), name), _lookup(a_c.numpy()[:, None], a_iv.cpu().numpy(), name)]
+    done, parted2 = _follow_reference_tables(picks, g["scores"], name)
+    assert torch.equal(w_iv, w_f) and torch.equal(a_iv, a_f), f"{name}: pruned and unpruned calls differ"
+    if not parted2:
+        np.testing.assert_array_equal(w_iv.cpu().numpy(), g["w_interval"].reshape(-1))
+        np.testing.assert_array_equal(a_iv.cpu().numpy(), g["a_interval"].reshape(-1))
+    print(f"[production] {name}: {done} of {2 * R} passes on the reference's trajectory"
+          f"{' (parted at a near-tie)' if parted2 else ', intervals bit-identical to the reference run'}")
+
+
+@pytest.mark.parametrize("name", golden_names("prune_matmul_"))
+def test_default_matmul_call_reproduces_the_reference_at_a_pruning_eligible_size(eng, name):
+    from oracle.torch_port import TorchMatMul
+    g = load_golden(name)
+    p = dict(g["params"])
+    p.pop("kind")
+    sos = p.pop("sos")
+    R = p.pop("search_round")
+    A, B = _t(g["A"]), _t(g["B"])
+    Bd = B.cuda() if sos else B.transpose(-2, -1).contiguous().cuda().transpose(-2, -1)      # q.k^T: a transposed view
+    args = dict(A=A.cuda(), B=Bd, out=_t(g["out"]).cuda(), grad=_t(g["grad"]).cuda(), sos=sos, **p)
+    A_f, B_f, split_f, scores, best = eng.matmul_calibrate(search_round=R, want_scores=True, **args)
+    torch.cuda.synchronize()
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    parted = False
+    for r in range(R):
+        ta, tb = g["scores"][2 * r], g["scores"][2 * r + 1]
+        pairs = [((scores[r, 0][:20, :1], best[r, 0][:1]) if sos else (scores[r, 0], best[r, 0]), ta), ((scores[r, 1], best[r, 1]), tb)]
+        for (tab, idx), ref in pairs:
+            ref = ref.reshape(tab.shape[0], -1)
+            if not parted:
+                assert_scores_close(tab, ref, what=f"{name} round {r}")
+                parted = assert_argmax_tie_aware(idx, ref, what=f"{name} round {r}") > 0
+    port = TorchMatMul(sos=sos, **p)
+    _, _, A_c, B_c = port.initial(A, B)
+    picks = []
+    for r in range(1, R + 1):
+        eng.prune_counters(reset=True)
+        A_iv, B_iv, split, sc, _ = eng.matmul_calibrate(search_round=r, **args)
+        torch.cuda.synchronize()
+        assert sc is None
+        _expect_staged(eng, f"{name} R={r}")
+        if sos:
+            i = np.nonzero(np.asarray(port.SPLITS, dtype=np.float32) == np.float32(float(split)))[0]
+            assert i.size == 1
+            picks.append(i[:1])
+        else:
+            picks.append(_lookup(A_c.numpy(), A_iv.cpu().numpy(), name))
+        picks.append(_lookup(B_c.numpy(), B_iv.cpu().numpy(), name))
+    done, parted2 = _follow_reference_tables(picks, g["scores"], name)
+    assert torch.equal(A_iv, A_f) and torch.equal(B_iv, B_f), f"{name}: pruned and unpruned calls differ"
+    if not parted2:
+        np.testing.assert_array_equal(B_iv.cpu().numpy(), g["B_interval"].reshape(-1))
+        np.testing.assert_array_equal(A_iv.cpu().numpy(), np.asarray(g["A_interval"]).reshape(-1))
+        if sos:
+            assert float(split.cpu()) == float(g["split"])
+    print(f"[production] {name}: {done} of {2 * R} passes on the reference's trajectory"
+          f"{' (parted at a near-tie)' if parted2 else ', intervals bit-identical to the reference run'}")
