@@ -527,6 +527,23 @@ def main():
         if args.cpu_full:
             cpu["config0_full_run"] = cpu_full_deit_tiny()
 
+    # post-quant ImageNet top-1 (BASELINE.json north_star; reference example/test_vit.py:26-45): measured when the machine has
+    # the data -- P4V_IMAGENET = ImageNet root (train/ + val/), P4V_WEIGHTS = timm checkpoint of --model -- through
+    # tools/eval_top1.py (FP32 and quantised top-1 of the pretrained network, calibrated on 32 train images drawn with the
+    # reference's seed-3 rule).  Untimed, after everything else.
+    top1, top1_reason = None, ("no ImageNet and no pretrained weights in this environment (no network): set P4V_IMAGENET and P4V_WEIGHTS "
+                               "to fill this through tools/eval_top1.py; parity evidence without them is interval parity on identical "
+                               "tensors + the reference's own quantised logits (tests/golden: mini ViT, DeiT-tiny/224)")
+    if rank == 0 and world == 1 and os.environ.get("P4V_IMAGENET") and os.environ.get("P4V_WEIGHTS"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import eval_top1
+        del net, wrapped
+        torch.cuda.empty_cache()
+        max_val = int(os.environ["P4V_TOP1_MAX_VAL"]) if os.environ.get("P4V_TOP1_MAX_VAL") else None
+        top1 = eval_top1.evaluate(args.model, os.environ["P4V_IMAGENET"], os.environ["P4V_WEIGHTS"], "PTQ4ViT", args.bits, args.calib,
+                                  3, 128, max_val, int(os.environ.get("P4V_TOP1_WORKERS", "8")), quiet=True)
+        top1_reason = None
+
     if rank == 0:
         t = cals[-1].timings
         line = {
@@ -551,10 +568,8 @@ def main():
             # a NEW network object (same architecture, fresh wrap) calibrated once in this warm process: what every experiment of
             # the reference's driver is (example/test_all.py:18-46); eager capture, no cached graph
             "fresh_network_calibration_s": fresh_s,
-            # post-quant ImageNet top-1 (BASELINE.json north_star, reference example/test_vit.py:26-45): not measurable here
-            "top1": None,
-            "top1_reason": "no ImageNet, no pretrained weights and no timm in this environment (no network); parity evidence is interval "
-                           "parity on identical tensors + the reference's own quantised logits (tests/golden: mini ViT, DeiT-tiny/224)",
+            # post-quant ImageNet top-1 (BASELINE.json north_star, reference example/test_vit.py:26-45), see above
+            "top1": top1, "top1_reason": top1_reason,
             "quant_forward_img_s": qf["quant_forward_img_s"] if qf else None, "quant_forward": qf,
             "per_rank": per_rank,
             "imbalance": (max(r["search_s"] for r in per_rank) / (sum(r["search_s"] for r in per_rank) / len(per_rank))) if per_rank else None,

@@ -331,6 +331,43 @@ def get_net(name, seed=0, device=None, **overrides):
     torch.manual_seed(seed)
     net = cls(**cfg)
     torch.random.set_rng_state(g)
+    net.p4v_name = name                      # utils.datasets.data_config reads it (timm keeps this in net.default_cfg)
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     return net.to(device).eval()
+
+
+def load_pretrained(net, path):
+    """Load a timm checkpoint of the same architecture into a net built by `get_net` (the reference gets these weights from
+    `timm.create_model(name, pretrained=True)`, utils/models.py:77; the parameter names here are timm's).
+
+    `path`: a `.pth` / `.pt` / `.bin` state dict (optionally nested under "model" / "state_dict") or a `.safetensors` file.
+    Every PARAMETER of the net must be present with its shape; recomputable buffers (relative_position_index, attn_mask) and
+    checkpoint entries the net does not have are reported, not fatal -- except distillation heads (`head_dist`, `dist_token`):
+    the reference's wrapper cannot map them either (utils/net_wrap.py:42,67 raises KeyError).  Returns (missing, unexpected)."""
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(str(path))
+    else:
+        sd = torch.load(str(path), map_location="cpu", weights_only=True)
+        for k in ("model", "state_dict"):
+            if isinstance(sd, dict) and k in sd and isinstance(sd[k], dict):
+                sd = sd[k]
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    if any(k.startswith(("head_dist", "dist_token")) for k in sd):
+        raise KeyError("distilled DeiT checkpoint (head_dist / dist_token): not supported, as in the reference's wrap_modules_in_net")
+    own = net.state_dict()
+    params = {n for n, _ in net.named_parameters()}
+    missing = [k for k in own if k not in sd]
+    bad = [k for k in missing if k in params]
+    if bad:
+        raise KeyError(f"checkpoint {path} lacks parameters of {getattr(net, 'p4v_name', type(net).__name__)}: {bad[:8]}{' ...' if len(bad) > 8 else ''}")
+    for k, v in sd.items():
+        if k in own and tuple(v.shape) != tuple(own[k].shape):
+            if v.numel() == own[k].numel():
+                sd[k] = v.reshape(own[k].shape)        # e.g. a patch embedding stored as a flattened Linear
+            else:
+                raise ValueError(f"checkpoint {path}: {k} has shape {tuple(v.shape)}, the net expects {tuple(own[k].shape)}")
+    unexpected = [k for k in sd if k not in own]
+    net.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+    return missing, unexpected

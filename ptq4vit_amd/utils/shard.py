@@ -8,6 +8,8 @@ multi-GPU design BASELINE.json asks for.
 """
 import torch
 
+from .intervals import INTERVAL_ATTRS, install_intervals      # the exchange installs what load_intervals installs
+
 try:
     import torch.distributed as dist
 except Exception:  # pragma: no cover
@@ -80,9 +82,6 @@ def assign_modules(wrapped_modules, world, costs=None):
     return owner
 
 
-INTERVAL_ATTRS = ("w_interval", "a_interval", "A_interval", "B_interval", "split")
-
-
 def _pack(module):
     vals, meta = [], []
     for a in INTERVAL_ATTRS:
@@ -152,30 +151,12 @@ def exchange_intervals(wrapped_modules, owner):
             continue
         m = wrapped_modules[n]
         mdev = next((p.device for p in m.parameters()), dev) if hasattr(m, "parameters") else dev
+        vals = {}
         for a in INTERVAL_ATTRS:
-            if (n, a) not in offsets:
-                continue
-            off, numel, shp = offsets[(n, a)]
-            val = gathered[r, off:off + numel].reshape(shp).to(mdev).clone()
-            cur = getattr(m, a, None)
-            if isinstance(cur, (list, tuple)) or (a == "a_interval" and hasattr(m, "_set_a_interval") and
-                                                  getattr(m, "_postgelu", False) and not hasattr(m, "a_neg_interval")):
-                m._set_a_interval(val)        # non-batching post-GELU class: [positive tensor, fixed negative float]
-            else:
-                setattr(m, a, val)
-            # the owner's search also fixed the group count of the blocked view (head-wise: matmul.py:411-417); the
-            # block sizes / paddings themselves are recomputed from the operand shapes on the first quant_forward
-            if a in ("A_interval", "B_interval") and len(shp) == 7 and hasattr(m, f"n_G_{a[0]}"):
-                setattr(m, f"n_G_{a[0]}", int(shp[1]))
-        if hasattr(m, "n_G_A") and getattr(m, "_sos", False) and hasattr(m, "n_G_B"):
-            m.n_G_A = m.n_G_B                  # what the owner's _search_on_gpu leaves behind (quant_input_A ignores it)
-        m.calibrated = True
-        for cache in ("raw_input", "raw_out", "raw_grad"):   # every class deletes its caches at the end of step 2
-            if hasattr(m, cache):
-                try:
-                    delattr(m, cache)
-                except AttributeError:
-                    pass
+            if (n, a) in offsets:
+                off, numel, shp = offsets[(n, a)]
+                vals[a] = gathered[r, off:off + numel].reshape(shp)
+        install_intervals(m, vals, mdev)        # the state the owner's calibration_step2 left behind (utils/intervals.py)
     return total
 
 
