@@ -17,7 +17,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first GPU call (see ptq4vit_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first GPU call (what ptq4vit_amd.configure_runtime() does; the
+                                                    # package import itself no longer touches the environment)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -8,16 +8,32 @@ import importlib
 import os
 import sys
 
-# The search runs one module per host thread and HIP stream; the ROCm runtime maps streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4) and kernels of streams that share a queue serialise.  With the pruned passes a module is a chain of
-# small kernels, so more of them in flight pay (8 queues + 8 streams: +6 % on ViT-B/224 x 32).  Only effective when this
-# package is imported before the process touches the GPU; never overrides the user's setting.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+def configure_runtime(hw_queues=8):
+    """Opt-in process setting for launchers (bench.py, tools/): the search runs one module per host thread and HIP stream, and
+    the ROCm runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- kernels of streams that share a queue
+    serialise.  With the pruned passes a module is a chain of small kernels, so more of them in flight pay (8 queues:
+    +6 % on ViT-B/224 x 32; the calibrator's default of 4 search streams + 3 capture lanes was tuned with it).  The variable is
+    read when HIP initialises, so this must run BEFORE the process touches the GPU; it never overrides the user's value and
+    importing the package no longer sets it (a library import must not change the environment of other HIP users in the
+    process).  Returns the value in effect, or None (with a warning) when the GPU was already initialised without it."""
+    import warnings
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        return int(cur)
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        warnings.warn("ptq4vit_amd.configure_runtime(): the GPU is already initialised, GPU_MAX_HW_QUEUES stays at the runtime's "
+                      "default (4); call it before the first GPU use or export GPU_MAX_HW_QUEUES=8")
+        return None
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
+    return int(hw_queues)
+
 
 __version__ = "0.1.0"
 
 _SUBMODULES = ("quant_layers", "quant_layers.linear", "quant_layers.matmul", "quant_layers.conv", "utils",
-               "utils.net_wrap", "utils.quant_calib", "utils.models", "utils.shard", "utils.integer", "configs", "configs.PTQ4ViT",
+               "utils.net_wrap", "utils.quant_calib", "utils.models", "utils.shard", "utils.integer", "utils.datasets", "configs", "configs.PTQ4ViT",
                "configs.BasePTQ")
 
 

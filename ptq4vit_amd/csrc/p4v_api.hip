@@ -107,6 +107,7 @@ std::atomic<long long> g_prune_cnt[4];
 //   16777216 pruned passes with several score blocks: stage B1 on the hull of the winners (no synthetic candidate)
 //   33554432 the two fixed planes of a twin row operand from two k_pack launches (not k_pack_dual)
 //   67108864 pruned Linear passes never try the half-size slice first
+//   134217728 cross-check: every pruned pass is followed by the full sweep of the same pass, a differing selection is an error
 //   1, 2: kernel debug flags (SweepParams::dbg)
 //   bit 30: route every int8 sweep through the generic k_sweep
 std::atomic<int> g_variant_word{0};
@@ -1139,7 +1140,46 @@ int launch_pass_select(Ctx& c, const Pass& ps, const float* scores) {
 }
 
 #define PRUNE_COUNT(i) do { if (!c.dry) g_prune_cnt[i].fetch_add(1, std::memory_order_relaxed); } while (0)
+// The margin by which a stage-A (slice) score must lie below the bound L* before the candidate is dropped.  Both numbers are
+// sums of same-signed terms whose per-element values are computed by the same arithmetic in every stage; what differs is the
+// order of summation.  Every sweep sums in fp32 only INSIDE a wave -- at most PRUNE_FP32_CHAIN additions in a row: the 128
+// outputs a lane of k_sweep7 owns per candidate (the longest chain of any sweep; k_sweep6: 32, k_sweep2/8/9: 32-48, the generic
+// and k_sos_split sweeps: 64) + the 6 levels of the cross-lane reduction -- and everything across waves / tiles / slabs is
+// k_finish's fp64.  A chain of n additions of same-signed fp32 terms is off by at most (n - 1) u / (1 - (n - 1) u) relative,
+// u = 2^-24; the slice sum and the bound each carry one such error, so 2 n u = 1.6e-5 bounds their disagreement and the margin
+// is 4 x that, never below the 1e-4 of round 3 (which is therefore what is used; a kernel with a longer fp32 chain must raise
+// PRUNE_FP32_CHAIN).  Variant 134217728 cross-checks every pruned pass against the full sweep (tests).
+constexpr int PRUNE_FP32_CHAIN = 128 + 6;
+inline float prune_margin() { return std::max(1e-4f, 4.0f * 2.0f * (float)PRUNE_FP32_CHAIN * 5.9604645e-8f); }
+int prune_crosscheck_begin(Ctx& c, const float* interval, int n, std::vector<float>& keep) {
+    keep.resize(n);
+    HIPCHK(hipMemcpyAsync(keep.data(), interval, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
+    HIPCHK(hipStreamSynchronize(c.st));
+    return 0;
+}
+int prune_crosscheck_end(Ctx& c, const float* interval, int n, const std::vector<float>& pruned, const char* what) {
+    std::vector<float> full(n);
+    HIPCHK(hipMemcpyAsync(full.data(), interval, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
+    HIPCHK(hipStreamSynchronize(c.st));
+    for (int i = 0; i < n; ++i)
+        if (std::memcmp(&full[i], &pruned[i], sizeof(float)) != 0)
+            return fail(P4V_ERR_INVALID, "exact candidate pruning selected another candidate than the full sweep (%s, output %d: %.9g vs %.9g)", what, i, (double)pruned[i], (double)full[i]);
+    return 0;
+}
+int run_pass_pruned_impl(Ctx& c, Pass& ps);
 int run_pass_pruned(Ctx& c, Pass& ps) {
+    if (!(g_variant & 134217728) || c.dry || !prune_ok(ps) || !ps.interval) return run_pass_pruned_impl(c, ps);
+    // debug cross-check: the pruned pass, then the full sweep of the same pass; the selections must be bit-identical
+    const int n = ps.out_off + (std::max(1, ps.nj) - 1) * ps.out_js + 1;
+    std::vector<float> keep;
+    CHK(run_pass_pruned_impl(c, ps));
+    CHK(prune_crosscheck_begin(c, ps.interval, n, keep));
+    Pass full = ps;
+    full.prunable = false; full.scache = nullptr; full.cache = nullptr; full.ecache = nullptr;
+    CHK(run_pass(c, full));
+    return prune_crosscheck_end(c, ps.interval, n, keep, "search pass");
+}
+int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     if (!prune_ok(ps)) { PRUNE_COUNT(3); return run_pass(c, ps); }
     const bool lin = ps.Z == 1;
     // geometry of the slice.  Linear: the k heaviest of its M samples (rows of x / raw_out / raw_grad).  MatMul: the 16
@@ -1216,7 +1256,7 @@ int run_pass_pruned(Ctx& c, Pass& ps) {
     a.S1_pre = S1s; a.S2_pre = S2s; a.s_ready = false;
     // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
-    PruneParams pp{SA, SB, ps.eq_n, ps.nj, 1e-4f, r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
+    PruneParams pp{SA, SB, ps.eq_n, ps.nj, prune_margin(), r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
     CHK(run_pass(c, a));
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
@@ -1358,7 +1398,16 @@ int run_sos_split(Ctx& c, SosSplitJob& j) {
 // The split search with the exact pruning of run_pass_pruned: the 20 splits on the 16 heaviest query rows of every (image, head),
 // the winner on everything (the bound), whatever survives on everything.  Runs once per module (its result does not depend on
 // the intervals: the later rounds are memo hits), before any other pass of the module -- it is what builds the module's slice.
+int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j);
 int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
+    if (!(g_variant & 134217728) || c.dry || !j.split) return run_sos_split_pruned_impl(c, j);
+    std::vector<float> keep;                      // debug cross-check against the full split search (see run_pass_pruned)
+    CHK(run_sos_split_pruned_impl(c, j));
+    CHK(prune_crosscheck_begin(c, j.split, 1, keep));
+    CHK(run_sos_split(c, j));
+    return prune_crosscheck_end(c, j.split, 1, keep, "split search");
+}
+int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j) {
     const SosSplitParams& kp = j.kp;
     const int k = 16;
     if (!j.prunable || !j.scache || j.scores_out || j.best_out || (g_variant & 4194304) || kp.M < 64 || j.scache->loose) {
@@ -1384,7 +1433,7 @@ int run_sos_split_pruned(Ctx& c, SosSplitJob& j) {
     SosSplitParams a = kp;                       // stage A: dense slices [Z][16][K] / [Z][16][N]
     a.A = sc->Rs; a.a_k = 1; a.a_r = kp.K; a.a_z = (long)k * kp.K; a.a_z2 = (long)kp.zdiv * k * kp.K;
     a.O = sc->Os; a.G = (kp.wt_mode == 1) ? sc->Gs : sc->Os; a.M = k; a.halves = 1;
-    PruneParams pp{SA, SB, kp.C, 1, 1e-4f, r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
+    PruneParams pp{SA, SB, kp.C, 1, prune_margin(), r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
     CHK(sos_sweep(c, j, a, nullptr, SA));
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     CHK(sos_sweep(c, j, kp, r1, SB));             // B1

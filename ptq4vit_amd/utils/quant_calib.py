@@ -509,8 +509,15 @@ class HessianQuantCalibrator(QuantCalibrator):
                 srcs += statics[n][0]
             # every (static tensor -> slice i of its cache) whose memory is one dense block goes through ONE launch per
             # sub-batch (p4v_multi_copy); anything else (overlapping / gapped views) keeps torch's copy
-            block = [(d, t) for d, t, b in zip(flat_dsts, srcs, recipe0["is_block"]) if b]
-            other = [(d, t) for d, t, b in zip(flat_dsts, srcs, recipe0["is_block"]) if not b]
+            # (the recipe's flags were computed from lane 0's recorded tensors; another instance of the graph may have recorded
+            # one of them with other strides -- then the flat copy would scramble the cache: each lane's flags are checked
+            # against ITS statics once and kept with the lane)
+            lane_blocks = lanes[li].setdefault("is_block", {}).get(key_names)
+            if lane_blocks is None:
+                lane_blocks = [bool(b) and _same_dense_block(d, t) for d, t, b in zip(flat_dsts, srcs, recipe0["is_block"])]
+                lanes[li]["is_block"][key_names] = lane_blocks
+            block = [(d, t) for d, t, b in zip(flat_dsts, srcs, lane_blocks) if b]
+            other = [(d, t) for d, t, b in zip(flat_dsts, srcs, lane_blocks) if not b]
             table, max_bytes = None, 0
             if block:
                 rows = [[t.data_ptr(), d.data_ptr(), t.numel() * 4] for d, t in block]
@@ -687,9 +694,16 @@ class HessianQuantCalibrator(QuantCalibrator):
             # from the second calibration of a network on: what every module's search actually took last time (gathered from
             # all ranks at the end of that calibration, hence the same on every rank) -- the cost model does not know whether
             # the exact pruning applies to a module (it depends on where raw_grad^2 sits), the clock does
+            # Only a table that was all-gathered by a calibration of THIS world size counts (a single-process warm-up before
+            # init_process_group leaves local wall-clock times behind: tagged world 1, ignored here), and because the owner map
+            # drives the collectives of exchange_captures / exchange_intervals it must be the same on every rank whatever each
+            # rank's history is: rank 0's costs are broadcast (a few hundred floats) before the assignment.
             measured = self.net.__dict__.get("_p4v_module_ms") or {}
-            if all(n in measured for n in names):
-                costs = {n: float(measured[n]) for n in names}
+            if measured.get("world") == world and all(n in measured.get("ms", {}) for n in names):
+                costs = {n: float(measured["ms"][n]) for n in names}
+            box = [[costs[n] for n in names]]
+            shard.dist.broadcast_object_list(box, src=0)
+            costs = dict(zip(names, box[0]))
             owner = shard.assign_modules(self.wrapped_modules, world, costs)
         else:
             all_sizes = None
@@ -835,8 +849,8 @@ class HessianQuantCalibrator(QuantCalibrator):
             parts = [None] * world
             shard.dist.all_gather_object(parts, mine_ms)                 # a few hundred floats: next calibration's LPT costs
             mine_ms = {k: v for part in parts for k, v in (part or {}).items()}
-        if mine_ms:
-            self.net.__dict__.setdefault("_p4v_module_ms", {}).update(mine_ms)
+        if mine_ms:          # replaced, not merged: the table describes ONE calibration (of this world size), gathered from all ranks
+            self.net.__dict__["_p4v_module_ms"] = {"world": world, "ms": dict(mine_ms)}
         for module in self.wrapped_modules.values():
             module.mode = "quant_forward"
         self.net.__dict__["_p4v_calibrations"] = self.net.__dict__.get("_p4v_calibrations", 0) + 1

@@ -149,8 +149,16 @@ def test_whole_vit_base_calibration_is_bit_identical_with_and_without_pruning(en
     try:
         eng.debug_variant(4194304)
         full, c_off = calibrate()
+        # the engine's own cross-check (variant 134217728): every pruned pass is followed by the full sweep of the SAME pass -- same
+        # counterpart interval, same memo state -- and a differing selection is an error of the call
+        eng.debug_variant(134217728)
+        checked, c_chk = calibrate()
     finally:
         eng.debug_variant(0)
+    assert c_chk["staged"] == c_on["staged"], (c_chk, c_on)
+    for name in pruned:
+        for a, b in zip(pruned[name], checked[name]):
+            assert torch.equal(a, b), name
     # every executed pass of the 74 modules but the `head` Linear's (32 samples: its slice would be the whole layer)
     assert c_on["staged"] >= 200 and c_on["kept_full_sweep"] <= 6 and c_on["not_eligible"] == 0, c_on
     assert c_off["staged"] == 0, c_off

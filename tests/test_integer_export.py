@@ -101,3 +101,17 @@ def test_half_precision_non_dense_views_are_read_through_their_own_strides():
     got = fc1.int_input[0]
     integer.quantize_int_activation(fc1, (row.float().contiguous(),))
     assert torch.equal(got, fc1.int_input[0])
+
+
+def test_half_precision_slice_of_a_large_buffer_converts_only_its_span():
+    """A small fp16 view into a big buffer (an activation slice): the float32 image has the view's shape / strides / values and
+    its storage is the view's span, not the buffer (the whole-storage conversion allocated 4 bytes per buffer element)."""
+    big = torch.randn(1 << 20, dtype=torch.float32).half()
+    view = big[4096:4096 + 6 * 40].view(6, 40)[1:5, ::2]              # offset, gapped columns: strides (40, 2)
+    img = integer._f32_same_strides(view)
+    assert img.dtype == torch.float32 and tuple(img.shape) == (4, 20) and tuple(img.stride()) == (40, 2)
+    assert torch.equal(img, view.float())
+    assert img.untyped_storage().nbytes() <= 4 * (1 + 3 * 40 + 19 * 2)
+    assert integer._f32_same_strides(big[:0]).numel() == 0
+    f32 = torch.randn(8, 8)[:, ::2]
+    assert integer._f32_same_strides(f32).data_ptr() == f32.data_ptr()      # float32 passes through untouched

@@ -109,6 +109,8 @@ def main(argv=None):
     ap.add_argument("--save-intervals", default=None, help="write the calibrated intervals (utils/intervals.py) to this file")
     ap.add_argument("--json", default=None, help="also write the result line to this file")
     a = ap.parse_args(argv)
+    import ptq4vit_amd
+    ptq4vit_amd.configure_runtime()          # GPU_MAX_HW_QUEUES for the search streams, before the first GPU call
     res = evaluate(a.model, a.imagenet, a.weights, a.config, a.bits, a.calib, a.calib_seed, a.batch, a.max_val, a.workers,
                    a.save_intervals)
     line = json.dumps(res)
