@@ -69,34 +69,55 @@ def probe_shapes(net, wrapped, image):
     return shapes
 
 
-def pmc_traffic(kernel):
-    """Per-launch memory-side bytes of `kernel` from the NEWEST PMC pass committed under profiles/ (tools/pmc_collect.sh,
-    JSON).  FETCH_SIZE / WRITE_SIZE are KB; gfx950's FETCH_SIZE counts half of a wide streaming read
-    (MI355X_MICROARCH.md, HBM section) -> x 2.  Returns None when no pass names the kernel."""
+def production_profile():
+    """The newest offline profile of the production step committed under profiles/ (tools/prof_join.py: rocprofv3 kernel trace +
+    separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --profile`, joined launch by launch with the records of the engine).
+    rocprofv3 --pmc cannot run inside this process, so `roofline.traffic` comes from there -- for the SAME launches (kernel
+    family x stage of the pruned pass) the live numbers of this line describe."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        for name, c in d.get("kernels", {}).items():
-            if kernel in name and "FETCH_SIZE" in c:
-                launches = c["FETCH_SIZE"]["launches"]
-                fetch = c["FETCH_SIZE"]["mean"] * 1024.0 * 2.0
-                write = c.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024.0
-                busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean")
-                cand = {"source": os.path.relpath(path, ROOT), "kernel_instance": name, "layer": d.get("layer"),
-                        "launches_sampled": launches, "fetch_bytes_x2": fetch, "write_bytes": write,
-                        "traffic_bytes_per_launch": fetch + write, "mfma_busy_cycles": busy,
-                        "tcc_hit_rate": (c["TCC_HIT_sum"]["mean"] / (c["TCC_HIT_sum"]["mean"] + c["TCC_MISS_sum"]["mean"]))
-                        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c else None}
-                if best is None or path >= best["_path"]:
-                    cand["_path"] = path
-                    best = cand
-    if best:
-        best.pop("_path")
-    return best
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_production_by_stage.json")))
+    if not paths:
+        return None
+    try:
+        d = json.load(open(paths[-1]))
+    except Exception:
+        return None
+    d["source"] = os.path.relpath(paths[-1], ROOT)
+    return d
+
+
+def aggregate_launches(recs, peak_i8=5000.0, peak_f32=157.3):
+    """Per kernel family, and per stage of the pruned search pass inside it, from the engine's per-launch records (HIP events on
+    the launch stream): launches, total ms, average launch, algorithmic ops per launch, achieved / issued TOP/s, fraction of the
+    dense peak of the family's MFMA type (int8: 2 x the 2.5 PF bf16 dense spec; fp32: 157.3 TF -- MI355X_MICROARCH.md)."""
+    fams = {}
+    for r in recs:
+        f = fams.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "ops": 0.0, "alg_ops": 0.0, "alg_bytes": 0.0, "by_stage": {}})
+        st = f["by_stage"].setdefault(r["stage"], {"launches": 0, "ms": 0.0, "ops": 0.0, "alg_ops": 0.0, "alg_bytes": 0.0, "empty_launches": 0})
+        for d in (f, st):
+            d["launches"] += 1
+            d["ms"] += r["ms"]
+            d["ops"] += r["ops"]
+            d["alg_ops"] += r["alg_ops"]
+            d["alg_bytes"] += r.get("alg_bytes", 0.0)
+        st["empty_launches"] += int(r["alg_ops"] == 0.0)
+
+    def fin(d, peak):
+        secs = d["ms"] * 1e-3
+        d["avg_launch_ms"] = d["ms"] / d["launches"]
+        d["ops_per_launch"] = d["alg_ops"] / d["launches"]
+        d["algorithmic_bytes_per_launch"] = d.pop("alg_bytes") / d["launches"]
+        d["achieved"] = d["alg_ops"] / secs / 1e12 if secs > 0 else None
+        d["issued"] = d["ops"] / secs / 1e12 if secs > 0 else None
+        d["frac"] = d["achieved"] / peak if secs > 0 else None
+        d["issued_frac"] = d["issued"] / peak if secs > 0 else None
+    for name, f in fams.items():
+        peak = peak_f32 if ("float" in name or "sos" in name) else peak_i8
+        f["peak"], f["unit"] = peak, "TOP/s" if peak == peak_i8 else "TFLOP/s"
+        fin(f, peak)
+        for st in f["by_stage"].values():
+            fin(st, peak)
+    return fams
 
 
 def _cpu_info():
@@ -297,12 +318,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (fresh-network calibration, quant_forward throughput)")
     ap.add_argument("--cpu-full", action="store_true", help="also run BASELINE config 0 (DeiT-tiny/224 BasePTQ x 4 images) through the CPU oracle, in full")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--search-streams", type=int, default=0, help="host threads / HIP streams of the module searches in the timed steps "
+                    "(0 = the calibrator's default of 4; 1 = serial, the launch order of the roofline step)")
+    ap.add_argument("--profile", action="store_true",
+                    help="for runs under rocprofv3: every calibration of the process is the SAME single-stream production step (no "
+                         "single-pass / fresh-network / full-sweep / CPU extras), so that a kernel trace divides into identical calibrations")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch records of the roofline step (JSON) for tools/prof_join.py")
     ap.add_argument("--capture-batch", type=int, default=0,
                     help="images per capture pass of the timed steps (0 = batch_size = 4, the reference's passes)")
     ap.add_argument("--tune", default="", help="key=value,... engine tuning overrides (p4v_debug_set_tuning), experiments only")
     ap.add_argument("--variant", type=int, default=0, help="engine A/B switch word (p4v_debug_set_variant), experiments only: use with --no-roofline")
     args = ap.parse_args()
 
+    if args.profile:
+        args.search_streams, args.no_extras, args.no_cpu_baseline = 1, True, True
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("P4V_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0)))   # P4V_FORCE_DEVICE: testing N ranks on one GPU
@@ -344,8 +373,8 @@ def main():
             m.mode = "raw"
         cal = HessianQuantCalibrator(net, wrapped, loader, sequential=False, batch_size=4,
                                      capture_batch_size=capture_batch or args.capture_batch or None)
-        if search_streams:
-            cal.search_streams = search_streams
+        if search_streams or args.search_streams:
+            cal.search_streams = search_streams or args.search_streams
         cal.batching_quant_calib()
         return cal
 
@@ -377,13 +406,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # the same calibration with ONE capture pass over all images (opt-in `capture_batch_size`: not part of `value`)
-    with quiet:
-        one_step(capture_batch=args.calib)
-        sync()
-        t_big = time.time()
-        cal_big = one_step(capture_batch=args.calib)
-        sync()
-        big_s = time.time() - t_big
+    cal_big, big_s = None, None
+    if not args.profile:
+        with quiet:
+            one_step(capture_batch=args.calib)
+            sync()
+            t_big = time.time()
+            cal_big = one_step(capture_batch=args.calib)
+            sync()
+            big_s = time.time() - t_big
     n_mod = len(wrapped)
     value = n_mod * args.steps / elapsed
 
@@ -392,51 +423,64 @@ def main():
         # live HIP-event timing of the dominant kernels (the int8 sweeps) on their launch stream, over one more
         # step that is not part of `value` (every rank runs it: the step ends with a collective)
         engine.stats_reset()
+        engine.prune_counters(reset=True)
         engine.stats_enable(rank == 0)
         with quiet:
             cal_r = one_step(search_streams=1)   # kernels timed in isolation: no second stream sharing the CUs
         sync()
         st = engine.stats_get()
+        recs = engine.stats_launches() if rank == 0 else []
         engine.stats_enable(False)
         if rank == 0 and st["sweep_i8_launches"] > 0:
             mine = {n: m for n, m in wrapped.items() if cal_r.owner[n] == rank}
             lin, mm, conv = search_macs(mine, shapes, args.calib)
             peak = 5000.0  # TOP/s: dense int8 MFMA = 2x the 2.5 PF bf16 dense spec (MI355X_MICROARCH.md)
-
-            def cls(prefix, what):
-                n, ms = st[prefix + "_launches"], st[prefix + "_ms"]
-                if not n:
-                    return None
-                alg, iss = 2.0 * st[prefix + "_alg_macs"], 2.0 * st[prefix + "_macs"]
-                return {"kernel": what, "launches": n, "ms": ms, "avg_launch_ms": ms / n, "ops_per_launch": alg / n,
-                        "achieved": alg / (ms * 1e-3) / 1e12, "issued": iss / (ms * 1e-3) / 1e12,
-                        "frac": alg / (ms * 1e-3) / 1e12 / peak}
-            k6 = cls("sweep6", "k_sweep6 (int8 candidate sweep, register-stationary operand, K <= 768 layers)")
-            k7 = cls("sweep7", "k_sweep7 (int8 candidate sweep, both operands streaming, K >= 1024 layers; twin launches issue two planes)")
-            dom = max([k for k in (k6, k7) if k], key=lambda k: k["ms"], default=None) or cls("sweep_i8", "int8 candidate sweeps")
+            fams = aggregate_launches(recs, peak)
+            if args.dump_launches:
+                with open(args.dump_launches, "w") as fh:
+                    json.dump({"model": args.model, "bits": args.bits, "calib": args.calib, "launches": recs}, fh)
+            i8 = {k: v for k, v in fams.items() if v["peak"] == peak}
+            dom_name = max(i8, key=lambda k: i8[k]["ms"])
+            dom = i8[dom_name]
             algo_ops = 2.0 * st["sweep_i8_alg_macs"]   # ops of the reference GEMMs the EXECUTED int8 launches stand for (unpadded,
             ref_ops = 2.0 * (lin + mm)                 # one plane per candidate); memo-restored passes are not launched, not counted
             issued_ops = 2.0 * st["sweep_i8_macs"]     # incl. tile padding and the second twin plane
             secs = st["sweep_i8_ms"] * 1e-3
-            pmc = pmc_traffic("k_sweep6" if dom is k6 else "k_sweep7")
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak, "unit": "TOP/s",
-                    "frac": dom["frac"],
-                    # HBM-side bytes per launch of this kernel from the newest PMC pass under profiles/ (offline: rocprofv3
-                    # --pmc cannot run inside this process); FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE
-                    "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
-                    "pmc_offline": pmc,
+            all_alg = sum(f["alg_ops"] for f in fams.values())      # int8 + fp32 sweeps (patch embedding, split search)
+            search_s = sum(c.timings["search_s"] for c in cals) / len(cals)
+            prof = production_profile()
+            pk = (prof or {}).get("kernels", {}).get(dom_name)
+            roof = {"bound": "mfma", "kernel": dom_name + " (int8 candidate sweep; the kernel family with the most time in a calibration)",
+                    "achieved": dom["achieved"], "peak": peak, "unit": "TOP/s", "frac": dom["frac"],
+                    # HBM-side bytes per launch of THIS kernel family over THE SAME launches (the production step, one stream),
+                    # from the separate rocprofv3 --pmc passes joined by tools/prof_join.py: FETCH_SIZE x 2 (gfx950 wide-read
+                    # correction) + WRITE_SIZE; null until a profile of this code is committed
+                    "traffic": pk.get("traffic_bytes_per_launch") if pk else None,
+                    "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"], "ops_per_launch": dom["ops_per_launch"],
+                    "issued": dom["issued"],
                     # the same instruction alone (MFMA-only loop, 8 waves/CU, tools/ubench_mfma.hip) sustains 4044 TOP/s on
                     # this part at its ~2.0 GHz clock under load (profiles/r1_ubench.txt); `peak` stays the 2 x bf16 spec
                     "peak_measured_mfma_only": 4044.0, "frac_of_measured": dom["achieved"] / 4044.0,
-                    "issued": dom["issued"], "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
-                    "ops_per_launch": dom["ops_per_launch"],
-                    "by_kernel": {"k_sweep6": k6, "k_sweep7": k7},
+                    "measured": "HIP events around every sweep launch of one untimed single-stream calibration (same launches as the "
+                                "timed steps: exact pruning + memo on); per-launch records -> by_kernel / by_stage",
+                    # every sweep family of the step; by_stage: A = all candidates on the sample slice, B1 = the bound (one
+                    # candidate or the hull of the slice winners, all samples), B2 = the survivors, full = unpruned passes
+                    "by_kernel": fams,
                     "all_int8_sweeps": {"achieved": algo_ops / secs / 1e12, "issued": issued_ops / secs / 1e12,
                                         "frac": algo_ops / secs / 1e12 / peak, "launches": st["sweep_i8_launches"],
                                         "avg_launch_ms": st["sweep_i8_ms"] / st["sweep_i8_launches"]},
+                    # the whole search phase of the TIMED steps (4 streams, every kernel and gap included): executed algorithmic
+                    # ops of all sweeps / search_s
+                    "whole_search": {"executed_ops": all_alg, "search_s": search_s, "achieved": all_alg / search_s / 1e12,
+                                     "frac": all_alg / search_s / 1e12 / peak},
                     "reference_ops_fraction_executed": algo_ops / ref_ops,
                     "memo_hits": st["memo_hits"], "memo_misses": st["memo_misses"],
-                    "f32_sweep_ms": st["sweep_f32_ms"], "f32_sweep_tflops": (2.0 * st["sweep_f32_macs"] / (st["sweep_f32_ms"] * 1e-3) / 1e12) if st["sweep_f32_ms"] else None}
+                    "prune_counters": engine.prune_counters(),
+                    # offline cross-check: the same kernel family in the committed rocprofv3 profile of `bench.py --profile`
+                    "profile": None if not pk else {"source": prof["source"], "launches_per_calibration": pk.get("launches_per_calibration"),
+                                                     "avg_launch_ms": pk.get("avg_launch_ms"), "frac": pk.get("frac"),
+                                                     "traffic_bytes_per_launch": pk.get("traffic_bytes_per_launch"),
+                                                     "algorithmic_bytes_per_launch": pk.get("algorithmic_bytes_per_launch")}}
 
     # ---- untimed extras (not part of `value`) ---------------------------------------------------------------------------
     fresh_s = qf = None
@@ -488,23 +532,19 @@ def main():
 
     # the same kernels on FULL sweeps (every candidate over every sample: exact pruning and nothing else switched off, one
     # more untimed single-stream step): what the sweep kernels sustain when a launch is not a short candidate range
-    if roof is not None and world == 1:
+    if roof is not None and world == 1 and not args.profile:
         engine.debug_variant(4194304)
         engine.stats_reset()
         engine.stats_enable(True)
         with quiet:
             one_step(search_streams=1)
         sync()
-        st2 = engine.stats_get()
+        engine.stats_get()
+        full = aggregate_launches(engine.stats_launches())
         engine.stats_enable(False)
         engine.debug_variant(0)
-
-        def cls2(prefix):
-            n, ms = st2[prefix + "_launches"], st2[prefix + "_ms"]
-            return None if not n else {"launches": n, "ms": ms, "avg_launch_ms": ms / n,
-                                       "achieved": 2.0 * st2[prefix + "_alg_macs"] / (ms * 1e-3) / 1e12,
-                                       "frac": 2.0 * st2[prefix + "_alg_macs"] / (ms * 1e-3) / 1e12 / 5000.0}
-        roof["full_sweeps_without_pruning"] = {"k_sweep6": cls2("sweep6"), "k_sweep7": cls2("sweep7"), "all_int8_sweeps": cls2("sweep_i8")}
+        keep = ("launches", "ms", "avg_launch_ms", "ops_per_launch", "achieved", "issued", "frac", "issued_frac")
+        roof["full_sweeps_without_pruning"] = {k: {q: v[q] for q in keep} for k, v in full.items()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -560,9 +600,9 @@ def main():
             # images per capture pass of the timed steps (batch_size = 4: the reference's passes), and the same calibration
             # with one pass over all images (opt-in, utils/quant_calib.py: see the caveat on raw_grad there)
             "capture": {"images_per_pass": cals[-1]._capture_bs(),
-                        "opt_in_single_pass": {"images_per_pass": cal_big._capture_bs(), "calibration_wall_clock_s": big_s,
-                                               "capture_s": cal_big.timings["capture_s"],
-                                               "search_s": cal_big.timings["search_s"]}},
+                        "opt_in_single_pass": None if cal_big is None else {
+                            "images_per_pass": cal_big._capture_bs(), "calibration_wall_clock_s": big_s,
+                            "capture_s": cal_big.timings["capture_s"], "search_s": cal_big.timings["search_s"]}},
             # the timed steps re-calibrate the SAME network object: from its second calibration on the capture pass is replayed
             # from a HIP graph kept with the network (utils/quant_calib.py); the first calibration in this process, untimed:
             "first_calibration_s": cold,

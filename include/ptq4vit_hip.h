@@ -354,6 +354,24 @@ typedef struct p4v_kernel_stats {
     int64_t sweep7_twin_launches;
 } p4v_kernel_stats;
 
+/* One record per sweep launch the calling thread enqueued while timing was enabled, in launch order (= the order of the
+ * same kernels in a rocprofv3 kernel trace of a single-stream run): which kernel family, which stage of a pruned search pass,
+ * the grid, the measured duration and the work.  bench.py derives `roofline` (per kernel and per stage) from these. */
+typedef struct p4v_launch_record {
+    int32_t kind;     /* 2 k_sweep6 | 3 k_sweep7 | 4 k_sweep7 twin | 5 k_sweep4/5 | 6 k_sweep9 | 7 k_sweep8 | 8 k_sweep2g | 9 k_sweep2 |
+                         0 generic int8 k_sweep | 1 generic fp32 k_sweep | 11 k_sos_split (fp32) */
+    int32_t stage;    /* 0 full sweep (pass not pruned) | 1 stage A (all candidates, sample slice) | 2 stage B1 (the bound) |
+                         3 stage B2 (survivors) */
+    int32_t grid_x, grid_z;
+    double ms;        /* HIP events around the launch on its stream */
+    double ops;       /* 2 x integer / fp MACs issued (padded tiles, both twin planes), candidates outside a device-side range excluded */
+    double alg_ops;   /* 2 x MACs of the reference GEMMs the launch stands for (unpadded, one plane); 0: empty candidate range */
+    double alg_bytes; /* compulsory bytes of the search pass the launch belongs to (both operands in fp32 as captured +
+                         raw_out + the metric weight, each read once); a sweep split over two launches books its share of tiles */
+} p4v_launch_record;
+/* Copies min(capacity, *count) records of the calling thread since the last p4v_stats_reset; `out` may be NULL to query the count. */
+int p4v_stats_launches(p4v_launch_record* out, int64_t capacity, int64_t* count);
+
 int p4v_stats_enable(int enable);   /* 1 / 0: launch timing on the calling thread */
 int p4v_stats_reset(void);
 int p4v_stats_get(p4v_kernel_stats* out);

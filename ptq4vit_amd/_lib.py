@@ -48,6 +48,16 @@ class KernelStats(C.Structure):
                 ("sweep7_twin_ms", C.c_double), ("sweep7_twin_launches", C.c_int64)]
 
 
+class LaunchRecord(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("stage", C.c_int32), ("grid_x", C.c_int32), ("grid_z", C.c_int32),
+                ("ms", C.c_double), ("ops", C.c_double), ("alg_ops", C.c_double), ("alg_bytes", C.c_double)]
+
+
+LAUNCH_KINDS = {0: "k_sweep<int8>", 1: "k_sweep<float>", 2: "k_sweep6", 3: "k_sweep7", 4: "k_sweep7 (twin)", 5: "k_sweep4/5", 6: "k_sweep9",
+                7: "k_sweep8", 8: "k_sweep2g", 9: "k_sweep2", 11: "k_sos_split"}
+LAUNCH_STAGES = {0: "full", 1: "A", 2: "B1", 3: "B2"}
+
+
 class PlaneDesc(C.Structure):
     _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("cols_padded", C.c_int64), ("rows_per_scale", C.c_int64),
                 ("mode", C.c_int32), ("lo", C.c_int32), ("hi", C.c_int32), ("qmax", C.c_int32),
@@ -78,7 +88,7 @@ EXPORTS = [
     "p4v_amax_init_conv", "p4v_conv_search_w_channelwise", "p4v_conv_search_w_layerwise", "p4v_conv_search_a",
     "p4v_score_argmax_gather",
     "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize", "p4v_multi_copy",
-    "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get", "p4v_prune_counters",
+    "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get", "p4v_stats_launches", "p4v_prune_counters",
     "p4v_debug_set_variant", "p4v_debug_set_tuning",
 ]
 
@@ -157,6 +167,8 @@ def load():
     lib.p4v_stats_reset.restype = C.c_int
     lib.p4v_stats_get.restype = C.c_int
     lib.p4v_stats_get.argtypes = [C.POINTER(KernelStats)]
+    lib.p4v_stats_launches.restype = C.c_int
+    lib.p4v_stats_launches.argtypes = [C.POINTER(LaunchRecord), C.c_int64, C.POINTER(C.c_int64)]
     lib.p4v_prune_counters.restype = C.c_int
     lib.p4v_prune_counters.argtypes = [C.POINTER(C.c_int64), C.c_int]
     _lib = lib

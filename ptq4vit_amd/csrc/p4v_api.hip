@@ -78,11 +78,14 @@ struct Arena {
 // Per CALLING THREAD: a thread that enabled timing (p4v_stats_enable) gets an event pair around every sweep launch
 // it enqueues and reads its own totals back with p4v_stats_get.  Nothing here is shared between threads, so calls
 // on other threads / streams / devices are unaffected.
-struct StatRec { hipEvent_t a, b; int kind; double macs, alg; };
+struct StatRec { hipEvent_t a, b; int kind; double macs, alg; int stage, gx, gz; double ms, bytes; };
+thread_local double g_alg_bytes = 0;       // compulsory bytes of the pass being launched: its fp32 operands + raw_out / raw_grad, once
 thread_local double g_alg_macs_cand = 0;   // unpadded single-plane MACs of one candidate of the pass being launched
 thread_local double g_exec_frac = 1.0;     // share of a launch's candidates that a pruned pass executes (stats mode only)
 thread_local bool g_stat_on = false;
 thread_local std::vector<StatRec> g_stat_recs;
+thread_local std::vector<StatRec> g_stat_done;   // drained records, kept until p4v_stats_reset (p4v_stats_launches)
+thread_local int g_stage = 0;                   // which stage of a pruned pass is being launched: 0 full sweep, 1 A, 2 B1, 3 B2
 thread_local p4v_kernel_stats g_stats = {};
 thread_local long g_memo_hits = 0, g_memo_misses = 0;
 // Process-wide counters of the exact candidate pruning (p4v_prune_counters): tests and bench.py assert with them that the
@@ -290,12 +293,12 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
+    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
         HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 0;
+        rec.kind = 5;
         rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0);
         rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
         HIPCHK(hipEventRecord(rec.a, c.st));
@@ -328,7 +331,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = g_alg_bytes; g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -403,7 +406,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
+    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
     StatRec rec{};
     if (timed) {   // one record per kernel launch; a split sweep books its work in proportion to the tiles of each part
         const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
@@ -412,6 +415,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
         rec.kind = 2;
         rec.macs = share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
         rec.alg = share * g_alg_macs_cand * (p.c1 - p.c0);
+        rec.bytes = -share;        // (a split sweep books the pass's bytes in proportion to its tiles: resolved when the record is pushed)
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
@@ -431,7 +435,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #endif
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = -rec.bytes * g_alg_bytes; g_stat_recs.push_back(rec);
     }
     return 0;
 }
@@ -547,7 +551,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     Sweep7Params q = p;
     q.cgroups = cgroups;
     dim3 grid(p.rtiles * p.ctiles * cgroups, 1, 1);
-    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
+    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
@@ -560,14 +564,14 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     CHK(twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds) : launch_sweep7_epi<0>(c, q, epi, grid, lds));
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = g_alg_bytes; g_stat_recs.push_back(rec);
     }
     return 0;
 }
 
 int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
-    const bool timed = g_stat_on && g_exec_frac > 0.0;   // (an empty stage B2 is launched in stats mode only: not a production launch)
+    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
     StatRec rec{};
     if (timed) {
         HIPCHK(hipEventCreate(&rec.a));
@@ -587,7 +591,14 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; g_stat_recs.push_back(rec);
+        // kernel family of the record (p4v_launch_record.kind): 6 k_sweep9, 7 k_sweep8, 8 k_sweep2g, 9 k_sweep2, 0 / 1 generic int8 / fp32
+        if (fast && p.halves > 0) rec.kind = 6;
+        else if (fast && sweep8_ok(p, twin, epi)) rec.kind = 7;
+        else if (fast && sweep2g_ok(p)) rec.kind = 8;
+        else if (fast) rec.kind = 9;
+        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.bytes = g_alg_bytes;
+        rec.gx = (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles; rec.gz = cgroups;
+        g_stat_recs.push_back(rec);
     }
     return r;
 }
@@ -727,6 +738,9 @@ bool dual_pack_ok(const PackParams& a, const PackParams& b) {
 int run_pass(Ctx& c, Pass& ps) {
     const int esz = ps.i8 ? 1 : 4;
     g_alg_macs_cand = (double)ps.Mrows * ps.Ncols * ps.K * ps.Z;
+    // every cached tensor read once per search pass -- both operands in fp32 as captured, raw_out and the metric weight
+    g_alg_bytes = 4.0 * ((double)ps.Mrows * ps.K * (ps.row_zs_shared ? 1 : ps.Z) + (double)ps.Ncols * ps.K * (ps.col_zs_shared ? 1 : ps.Z)) +
+                  (ps.G ? 8.0 : 4.0) * (double)ps.Mrows * ps.Ncols * ps.Z;
     const int Kp = (int)rup(ps.K, 64 / esz);          // 64-byte k-tiles
     // stationary-operand sweep (k_sweep4): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
     const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
@@ -1257,7 +1271,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     // several score blocks whose entries of the candidate table are exactly one row: stage B1 on ONE synthetic candidate
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, prune_margin(), r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
-    CHK(run_pass(c, a));
+    g_stage = 1;
+    { const int r_ = run_pass(c, a); g_stage = 0; if (r_) return r_; }
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
@@ -1270,14 +1285,15 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         swap(b1.s1.x); swap(b1.s1.y); swap(b1.s2.x); swap(b1.s2.y);
         b1.cands = vrow;
     } else b1.crange = r1;
-    CHK(run_pass(c, b1));
+    g_stage = 2;
+    { const int r_ = run_pass(c, b1); g_stage = 0; if (r_) return r_; }
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2;
     const bool hull_selects = !ps.scores_out && ps.interval && (virt || ps.nj <= 32);   // (its non-virt selection is serial over the blocks)
     SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
                      ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl); HIPCHK(hipGetLastError()); }
-    if (ps.host_sync_ok && !c.dry && !g_stat_on) {
+    if (ps.host_sync_ok && !c.dry) {
         // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
         // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made
         int h[2] = {0, 1};
@@ -1300,7 +1316,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     Pass b2 = ps;
     b2.crange = r2; b2.scores_keep = S2; b2.no_select = true;
     b2.S1_pre = S1s; b2.S2_pre = S2s; b2.s_ready = true;
-    CHK(run_pass(c, b2));
+    g_stage = 3;
+    { const int r_ = run_pass(c, b2); g_stage = 0; if (r_) return r_; }
     if (!c.dry) {
         if (virt) hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
         else hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
@@ -1368,7 +1385,7 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
             }
             HIPCHK(hipEventCreate(&rec.a));
             HIPCHK(hipEventCreate(&rec.b));
-            rec.kind = 1;
+            rec.kind = 11;
             rec.macs = frac * (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C;
             rec.alg = frac * (double)kp.Z * kp.M * kp.K * kp.N * kp.C;
             HIPCHK(hipEventRecord(rec.a, c.st));
@@ -1378,6 +1395,8 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
         else CHK(launch_sos_split_ks<100>(c, kp, j.epi));
         if (timed) {
             HIPCHK(hipEventRecord(rec.b, c.st));
+            rec.stage = g_stage; rec.gx = kp.halves; rec.gz = kp.Z;
+            rec.bytes = 4.0 * ((double)kp.Z * kp.M * kp.K + (double)kp.Z * kp.K * kp.N) + 8.0 * (double)kp.Z * kp.M * kp.N;
             g_stat_recs.push_back(rec);
         }
     }
@@ -1434,18 +1453,21 @@ int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j) {
     a.A = sc->Rs; a.a_k = 1; a.a_r = kp.K; a.a_z = (long)k * kp.K; a.a_z2 = (long)kp.zdiv * k * kp.K;
     a.O = sc->Os; a.G = (kp.wt_mode == 1) ? sc->Gs : sc->Os; a.M = k; a.halves = 1;
     PruneParams pp{SA, SB, kp.C, 1, prune_margin(), r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
-    CHK(sos_sweep(c, j, a, nullptr, SA));
+    g_stage = 1;
+    { const int r_ = sos_sweep(c, j, a, nullptr, SA); g_stage = 0; if (r_) return r_; }
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
-    CHK(sos_sweep(c, j, kp, r1, SB));             // B1
+    g_stage = 2;
+    { const int r_ = sos_sweep(c, j, kp, r1, SB); g_stage = 0; if (r_) return r_; }   // B1
     pp.r_out = r2;                                // (+ the selection from its totals when nothing else survives)
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, sos_select_params(j, SB)); HIPCHK(hipGetLastError()); }
-    if (j.host_sync_ok && !c.dry && !g_stat_on) {
+    if (j.host_sync_ok && !c.dry) {
         int h[2] = {0, 1};
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
         if (h[0] >= h[1]) { PRUNE_COUNT(1); c.ws.off = mark; return 0; }
     }
-    CHK(sos_sweep(c, j, kp, r2, S2));             // B2
+    g_stage = 3;
+    { const int r_ = sos_sweep(c, j, kp, r2, S2); g_stage = 0; if (r_) return r_; }   // B2
     if (!c.dry) {
         hipLaunchKernelGGL(k_merge_scores, dim3(1), dim3(256), 0, c.st, S2, SB, kp.C);
         HIPCHK(hipGetLastError());
@@ -2405,13 +2427,15 @@ static int stats_drain() {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
-        if (r.kind == 0 || r.kind == 2 || r.kind == 3 || r.kind == 4) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9)) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
         if (r.kind == 3 || r.kind == 4) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
         if (r.kind == 4) { g_stats.sweep7_twin_ms += ms; g_stats.sweep7_twin_launches++; }
-        if (r.kind == 1) { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
+        if (r.kind == 1 || r.kind == 11) { g_stats.sweep_f32_ms += ms; g_stats.sweep_f32_launches++; g_stats.sweep_f32_macs += r.macs; g_stats.sweep_f32_alg_macs += r.alg; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
+        r.ms = ms;
+        g_stat_done.push_back(r);
     }
     g_stat_recs.clear();
     return 0;
@@ -2420,6 +2444,7 @@ static int stats_drain() {
 int p4v_stats_reset(void) {
     int r = stats_drain();
     g_stats = p4v_kernel_stats{};
+    g_stat_done.clear();
     g_memo_hits = 0; g_memo_misses = 0;
     return r;
 }
@@ -2430,6 +2455,18 @@ int p4v_stats_get(p4v_kernel_stats* out) {
     g_stats.memo_hits = g_memo_hits; g_stats.memo_misses = g_memo_misses;
     *out = g_stats;
     return r;
+}
+
+int p4v_stats_launches(p4v_launch_record* out, int64_t capacity, int64_t* count) {
+    int r = stats_drain();
+    if (r) return r;
+    if (count) *count = (int64_t)g_stat_done.size();
+    if (out)
+        for (int64_t i = 0; i < capacity && i < (int64_t)g_stat_done.size(); ++i) {
+            const StatRec& s = g_stat_done[(size_t)i];
+            out[i] = p4v_launch_record{s.kind, s.stage, s.gx, s.gz, (double)s.ms, 2.0 * s.macs, 2.0 * s.alg, s.bytes};
+        }
+    return 0;
 }
 
 int p4v_prune_counters(int64_t* out4, int reset) {

@@ -544,3 +544,16 @@ def prune_counters(reset=False):
     out = (C.c_int64 * 4)()
     _lib.check(_lib.load().p4v_prune_counters(out, int(bool(reset))), "p4v_prune_counters")
     return dict(zip(("staged", "staged_no_survivors", "kept_full_sweep", "not_eligible"), (int(v) for v in out)))
+
+
+def stats_launches():
+    """Every sweep launch the calling thread enqueued with timing enabled since the last stats_reset(), in launch order:
+    [{"kernel", "stage", "grid_x", "grid_z", "ms", "ops", "alg_ops", "alg_bytes"}] (p4v_stats_launches)."""
+    lib = _lib.load()
+    n = C.c_int64(0)
+    _lib.check(lib.p4v_stats_launches(None, 0, C.byref(n)), "p4v_stats_launches")
+    buf = (_lib.LaunchRecord * max(1, n.value))()
+    _lib.check(lib.p4v_stats_launches(buf, n.value, C.byref(n)), "p4v_stats_launches")
+    return [{"kernel": _lib.LAUNCH_KINDS.get(r.kind, str(r.kind)), "stage": _lib.LAUNCH_STAGES.get(r.stage, str(r.stage)),
+             "grid_x": r.grid_x, "grid_z": r.grid_z, "ms": r.ms, "ops": r.ops, "alg_ops": r.alg_ops, "alg_bytes": r.alg_bytes}
+            for r in buf[:n.value]]
