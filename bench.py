@@ -461,6 +461,7 @@ def main():
                     # the same instruction alone (MFMA-only loop, 8 waves/CU, tools/ubench_mfma.hip) sustains 4044 TOP/s on
                     # this part at its ~2.0 GHz clock under load (profiles/r1_ubench.txt); `peak` stays the 2 x bf16 spec
                     "peak_measured_mfma_only": 4044.0, "frac_of_measured": dom["achieved"] / 4044.0,
+                    "event_overhead_ms": st["event_overhead_ms"],   # an empty event pair, subtracted from every launch duration
                     "measured": "HIP events around every sweep launch of one untimed single-stream calibration (same launches as the "
                                 "timed steps: exact pruning + memo on); per-launch records -> by_kernel / by_stage",
                     # every sweep family of the step; by_stage: A = all candidates on the sample slice, B1 = the bound (one

@@ -352,6 +352,8 @@ typedef struct p4v_kernel_stats {
     double sweep7_alg_macs;
     double sweep7_twin_ms;     /* the twin (two-plane) launches of k_sweep7 alone (also included in sweep7_*) */
     int64_t sweep7_twin_launches;
+    double event_overhead_ms;  /* duration of an EMPTY event pair on an idle stream, measured by p4v_stats_enable(1) and already
+                                  subtracted from every launch duration above and in p4v_stats_launches */
 } p4v_kernel_stats;
 
 /* One record per sweep launch the calling thread enqueued while timing was enabled, in launch order (= the order of the
@@ -361,7 +363,7 @@ typedef struct p4v_launch_record {
     int32_t kind;     /* 2 k_sweep6 | 3 k_sweep7 | 4 k_sweep7 twin | 5 k_sweep4/5 | 6 k_sweep9 | 7 k_sweep8 | 8 k_sweep2g | 9 k_sweep2 |
                          0 generic int8 k_sweep | 1 generic fp32 k_sweep | 11 k_sos_split (fp32) */
     int32_t stage;    /* 0 full sweep (pass not pruned) | 1 stage A (all candidates, sample slice) | 2 stage B1 (the bound) |
-                         3 stage B2 (survivors) */
+                         3 stage B2 (survivors, all samples) | 4 stage A2 (survivors of a loose first slice on the larger second one) */
     int32_t grid_x, grid_z;
     double ms;        /* HIP events around the launch on its stream */
     double ops;       /* 2 x integer / fp MACs issued (padded tiles, both twin planes), candidates outside a device-side range excluded */

@@ -45,7 +45,7 @@ class KernelStats(C.Structure):
                 ("sweep6_ms", C.c_double), ("sweep6_launches", C.c_int64), ("sweep6_macs", C.c_double), ("sweep6_alg_macs", C.c_double),
                 ("memo_hits", C.c_int64), ("memo_misses", C.c_int64),
                 ("sweep7_ms", C.c_double), ("sweep7_launches", C.c_int64), ("sweep7_macs", C.c_double), ("sweep7_alg_macs", C.c_double),
-                ("sweep7_twin_ms", C.c_double), ("sweep7_twin_launches", C.c_int64)]
+                ("sweep7_twin_ms", C.c_double), ("sweep7_twin_launches", C.c_int64), ("event_overhead_ms", C.c_double)]
 
 
 class LaunchRecord(C.Structure):
@@ -55,7 +55,7 @@ class LaunchRecord(C.Structure):
 
 LAUNCH_KINDS = {0: "k_sweep<int8>", 1: "k_sweep<float>", 2: "k_sweep6", 3: "k_sweep7", 4: "k_sweep7 (twin)", 5: "k_sweep4/5", 6: "k_sweep9",
                 7: "k_sweep8", 8: "k_sweep2g", 9: "k_sweep2", 11: "k_sos_split"}
-LAUNCH_STAGES = {0: "full", 1: "A", 2: "B1", 3: "B2"}
+LAUNCH_STAGES = {0: "full", 1: "A", 2: "B1", 3: "B2", 4: "A2"}
 
 
 class PlaneDesc(C.Structure):

@@ -589,7 +589,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         # running: hold them until everything has been joined so that the allocator cannot hand the memory out again
         keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
         todo = list(names)
-        measured = self.net.__dict__.get("_p4v_module_ms") or {}
+        measured = (self.net.__dict__.get("_p4v_module_ms") or {}).get("ms", {})   # {"world", "ms"}: see _calibrate
         if os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt" and all(n in measured for n in names):
             todo.sort(key=lambda n: measured[n], reverse=True)        # what each search took last time on this network
         elif os.environ.get("P4V_SEARCH_ORDER", "lpt") == "lpt":

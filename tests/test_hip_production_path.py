@@ -280,3 +280,47 @@ def test_default_matmul_call_reproduces_the_reference_at_a_pruning_eligible_size
             assert float(split.cpu()) == float(g["split"])
     print(f"[production] {name}: {done} of {2 * R} passes on the reference's trajectory"
           f"{' (parted at a near-tie)' if parted2 else ', intervals bit-identical to the reference run'}")
+
+
+def test_two_tier_pruning_is_exact_and_engages_on_a_spread_weight_profile(eng):
+    """A qkv-like Linear (16 x 197 samples, 768 -> 2304, three score blocks) whose metric weight is spread over the samples --
+    per-sample log-normal raw_grad, the 256-row first slice holds between half and 0.9 of it: many candidates survive stage B1's
+    bound, the survivors are swept over the second, larger slice (stage A2) before stage B2.  Same intervals as the full sweep of
+    every candidate over every sample, and the launch records show the second tier ran."""
+    g = torch.Generator().manual_seed(31)
+    b, T, K, N = 16, 197, 768, 2304
+    x = torch.randn(b, T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.02 * torch.linspace(0.5, 2.0, N)[:, None]
+    bias = torch.randn(N, generator=g) * 0.02
+    out = F.linear(x, w, bias)
+    grad = torch.randn(out.shape, generator=g) * 1e-10 * torch.exp(1.1 * torch.randn(b, T, 1, generator=g))
+    m = (grad.double() ** 2).sum(-1).flatten()
+    share = float(torch.topk(m, 256).values.sum() / m.sum())
+    assert 0.5 < share < 0.9, share
+    args = dict(weight=w.cuda(), bias=bias.cuda(), x=x.cuda(), out=out.cuda(), grad=grad.cuda(), w_bit=8, a_bit=8, n_V=3, n_H=1, n_a=1,
+                search_round=3, **PTQ4VIT)
+    eng.stats_reset()
+    eng.stats_enable(True)
+    try:
+        two = eng.linear_calibrate(**args)
+        torch.cuda.synchronize()
+        eng.stats_get()
+        stages = [r["stage"] for r in eng.stats_launches()]
+    finally:
+        eng.stats_enable(False)
+    assert "A2" in stages, f"the second tier did not run (first slice holds {share:.2f} of the weight): {sorted(set(stages))}"
+    try:
+        eng.debug_tuning(13, 1)                      # no second tier
+        one = eng.linear_calibrate(**args)
+        eng.debug_tuning(13, 0)
+        eng.debug_variant(134217728)                 # the engine's own cross-check of every pruned pass against its full sweep
+        chk = eng.linear_calibrate(**args)
+    finally:
+        eng.debug_tuning(13, 0)
+        eng.debug_variant(0)
+    full = eng.linear_calibrate(prune=False, **args)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        assert torch.equal(two[k], full[k]) and torch.equal(one[k], full[k]) and torch.equal(chk[k], full[k])
+    print(f"[production] two-tier pruning: first slice {share:.2f} of the weight; stages of the run: "
+          f"{ {s: stages.count(s) for s in sorted(set(stages))} }")

@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Multi-GPU prediction on paper, from one-GPU measurements: what a first SCALE run (1 / 2 / 4 / 8 MI355X) should show.
+
+    python tools/predict_scale.py [--configs vitb224 swinb384 vitb384] [--out profiles/r4_scale_prediction]
+    python tools/predict_scale.py --from profiles/r4_scale_prediction.json          # recompute the table offline
+
+No multi-GPU node is available to the builder, so the scaling path (utils/shard.py: LPT assignment of the modules, replicated
+or sub-batch-sharded capture, ONE all-gather of the intervals) has only run over gloo / one rank.  This tool measures on ONE
+GPU what the model needs -- per-module search time (single stream and as the 4-stream calibrator sees it), capture time, cache
+bytes -- and predicts, per world size:
+
+  search_s(rank)  = sum of the rank's modules' single-stream times / overlap,   overlap = what 4 streams gain on one GPU
+                    (measured: sum of the single-stream module times / search_s of the 4-stream calibration); LPT on the
+                    measured times, exactly as HessianQuantCalibrator assigns from its second calibration on
+  capture_s       = replicated: the one-GPU capture (every rank runs every pass, hooks on its own modules only);
+                    sharded: ceil(n_sub / world) / n_sub of it + the all_to_all of the pieces (shard.choose_capture_mode's
+                    transfer model: 40 GB/s per xGMI peer, two HBM passes for packing / reassembly) -- the mode is the one the
+                    calibrator's rank-invariant cost model picks
+  exchange_s      = 2 small collectives + all_gather_object of the per-module times: 1.5 ms (latency-bound; RCCL init is
+                    outside the timed region)
+  step_s          = capture_s + max over ranks of search_s + exchange_s          layers/s = modules / step_s
+
+Everything measured is written next to the prediction, so that a SCALE_rNN.json can be checked against a number.
+"""
+import argparse
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {"vitb224": ("vit_base_patch16_224", 32, 8), "vits224": ("vit_small_patch16_224", 32, 8),
+           "swinb384": ("swin_base_patch4_window12_384", 128, 8), "vitb384": ("vit_base_patch16_384", 128, 6)}
+EXCHANGE_S = 1.5e-3
+
+
+def lpt(costs, world):
+    load = [0.0] * world
+    owner = {}
+    names = list(costs)
+    for n in sorted(names, key=lambda n: (-costs[n], names.index(n))):
+        r = min(range(world), key=lambda i: (load[i], i))
+        owner[n] = r
+        load[r] += costs[n]
+    return owner, load
+
+
+def predict(meas, worlds=(1, 2, 4, 8), gb_per_s_per_peer=40.0):
+    ms1 = meas["module_ms_single_stream"]
+    total1 = sum(ms1.values())
+    overlap = total1 / (meas["search_s"] * 1e3)
+    cache_total = float(sum(meas["cache_bytes"].values()))
+    n_sub = meas["n_sub"]
+    rows = []
+    for w in worlds:
+        owner, load = lpt(ms1, w)
+        search = [l / overlap * 1e-3 for l in load]
+        cap_rep = meas["capture_s"]
+        share = cache_total / w
+        moved = share * (w - 1) / w
+        t_xfer = (moved / (gb_per_s_per_peer * 1e6 * max(1, w - 1)) + 3.0 * share / 2.0e9 + 2.0) * 1e-3 if w > 1 else 0.0
+        cap_sh = cap_rep * math.ceil(n_sub / w) / n_sub + t_xfer
+        # the calibrator's own rule (shard.choose_capture_mode) with the measured capture time in place of its MAC model
+        passes_saved = 1.0 - math.ceil(n_sub / w) / n_sub
+        mode = "sharded" if (w > 1 and n_sub >= 2 and cap_rep * 1e3 * passes_saved > 1.5 * t_xfer * 1e3 + 5.0) else "replicated"
+        cap = cap_sh if mode == "sharded" else cap_rep
+        ex = EXCHANGE_S if w > 1 else 0.0
+        step = cap + max(search) + ex
+        rows.append({"world": w, "capture_mode": mode, "capture_s": cap, "search_s_max": max(search), "search_s_mean": sum(search) / w,
+                     "imbalance": max(search) / (sum(search) / w), "exchange_s": ex, "step_s": step,
+                     "layers_per_s": len(ms1) / step, "speedup": None, "modules_per_rank": [sum(1 for r in owner.values() if r == i) for i in range(w)]})
+    for r in rows:
+        r["speedup"] = rows[0]["step_s"] / r["step_s"]
+        r["efficiency"] = r["speedup"] / r["world"]
+    return {"overlap_of_4_streams": overlap, "sum_single_stream_module_ms": total1, "rows": rows}
+
+
+def measure(model, calib, bits):
+    import torch
+
+    import ptq4vit_amd
+    ptq4vit_amd.configure_runtime()
+    from ptq4vit_amd import engine
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    engine.release_workspace()
+    saved = (PTQ4ViT.bit, dict(PTQ4ViT.w_bit), dict(PTQ4ViT.a_bit), dict(PTQ4ViT.A_bit), dict(PTQ4ViT.B_bit))
+    PTQ4ViT.bit = bits
+    for tab in (PTQ4ViT.w_bit, PTQ4ViT.a_bit, PTQ4ViT.A_bit, PTQ4ViT.B_bit):
+        for k in tab:
+            tab[k] = bits
+    try:
+        net = models.get_net(model, seed=0, device=dev)
+        with contextlib.redirect_stdout(io.StringIO()):
+            wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    finally:
+        PTQ4ViT.bit = saved[0]
+        for tab, old in zip((PTQ4ViT.w_bit, PTQ4ViT.a_bit, PTQ4ViT.A_bit, PTQ4ViT.B_bit), saved[1:]):
+            tab.clear()
+            tab.update(old)
+    s = models.input_size(model)
+    images = torch.randn(calib, 3, s, s, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    class L:
+        batch_size = calib
+
+        def __iter__(self):
+            yield images, None
+
+    def run(streams=None, timed_modules=None):
+        for n, m in wrapped.items():
+            m.mode = "raw"
+            m.__dict__.pop("calibration_step2", None)
+            if timed_modules is not None:
+                orig = m.calibration_step2
+
+                def timed(_o=orig, _n=n):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    r = _o()
+                    torch.cuda.synchronize()
+                    timed_modules.setdefault(_n, []).append((time.perf_counter() - t) * 1e3)
+                    return r
+                m.calibration_step2 = timed
+        cal = HessianQuantCalibrator(net, wrapped, L(), sequential=False, batch_size=4)
+        if streams:
+            cal.search_streams = streams
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            cal.batching_quant_calib()
+            torch.cuda.synchronize()
+        for m in wrapped.values():
+            m.__dict__.pop("calibration_step2", None)
+        return cal, time.perf_counter() - t
+
+    run()                                           # first calibration: eager capture, cold kernels
+    run()
+    best = None
+    for _ in range(3):                              # the production calibration (default streams / lanes)
+        cal, wall = run()
+        if best is None or wall < best[1]:
+            best = (cal, wall)
+    cal, wall = best
+    per = {}
+    for _ in range(2):                              # per-module times, one stream, each module synchronised
+        run(streams=1, timed_modules=per)
+    sizes = cal._estimate_cache_bytes(list(wrapped))
+    n_sub = sum(-(-inp.shape[0] // cal._capture_bs()) for inp, _ in L())
+    out = {"model": model, "calib_images": calib, "bits": bits, "modules": len(wrapped), "step_s": wall,
+           "capture_s": cal.timings["capture_s"], "search_s": cal.timings["search_s"], "n_sub": n_sub,
+           "module_ms_single_stream": {n: min(v) for n, v in per.items()},
+           "cache_bytes": {n: int(sizes[n]) for n in wrapped}}
+    del net, wrapped, images, cal
+    torch.cuda.empty_cache()
+    engine.release_workspace()
+    return out
+
+
+def table(res):
+    lines = []
+    for name, r in res.items():
+        m, p = r["measured"], r["prediction"]
+        lines.append(f"{name}: {m['model']} W{m['bits']}A{m['bits']} x {m['calib_images']} images, {m['modules']} modules; measured on ONE MI355X: "
+                     f"step {m['step_s'] * 1e3:.1f} ms = capture {m['capture_s'] * 1e3:.1f} + search {m['search_s'] * 1e3:.1f}; "
+                     f"single-stream module times sum to {p['sum_single_stream_module_ms']:.1f} ms (4 streams overlap x{p['overlap_of_4_streams']:.2f}); "
+                     f"caches {sum(m['cache_bytes'].values()) / 2**30:.1f} GiB")
+        lines.append(f"  {'GPUs':>4s} {'capture':>10s} {'mode':>10s} {'search max':>11s} {'imbalance':>9s} {'exchange':>9s} {'step':>9s} {'layers/s':>9s} {'speed-up':>8s} {'eff.':>5s}  modules per rank")
+        for q in p["rows"]:
+            lines.append(f"  {q['world']:4d} {q['capture_s'] * 1e3:8.1f}ms {q['capture_mode']:>10s} {q['search_s_max'] * 1e3:9.1f}ms {q['imbalance']:9.2f} "
+                         f"{q['exchange_s'] * 1e3:7.1f}ms {q['step_s'] * 1e3:7.1f}ms {q['layers_per_s']:9.1f} {q['speedup']:8.2f} {q['efficiency']:5.2f}  {q['modules_per_rank']}")
+    return "\n".join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", nargs="*", default=["vitb224", "swinb384", "vitb384"])
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_scale_prediction"))
+    ap.add_argument("--from", dest="src", default=None)
+    a = ap.parse_args()
+    if a.src:
+        res = json.load(open(a.src))
+        for r in res.values():
+            r["prediction"] = predict(r["measured"])
+    else:
+        res = {}
+        for c in a.configs:
+            model, calib, bits = CONFIGS[c]
+            meas = measure(model, calib, bits)
+            res[c] = {"measured": meas, "prediction": predict(meas)}
+    txt = __doc__.split("\n\n")[0] + "\n" + table(res) + "\n"
+    json.dump(res, open(a.out + ".json", "w"), indent=1)
+    open(a.out + ".txt", "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()

@@ -134,7 +134,7 @@ def main():
         k = summarise(range(n))
         k["peak"], k["unit"] = peak, "TOP/s" if peak == PEAK_I8 else "TFLOP/s"
         k["by_stage"] = {}
-        for st in ("A", "B1", "B2", "full"):
+        for st in ("A", "A2", "B1", "B2", "full"):
             idx = [i for i, r in enumerate(rl) if r["stage"] == st]
             if idx:
                 k["by_stage"][st] = summarise(idx)
