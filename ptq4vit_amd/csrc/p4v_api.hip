@@ -583,6 +583,16 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         HIPCHK(hipEventRecord(rec.a, c.st));
     }
     int r;
+    if (fast && p.bound) {
+        const dim3 grid(p.mtiles * p.ntiles * 2), block(256);      // 128 x 64 workgroup tiles
+        switch (epi) {
+            case EPI_SQ_W: hipLaunchKernelGGL((k_bound<EPI_SQ_W>), grid, block, 0, c.st, p); break;
+            case EPI_SQ: hipLaunchKernelGGL((k_bound<EPI_SQ>), grid, block, 0, c.st, p); break;
+            case EPI_ABS: hipLaunchKernelGGL((k_bound<EPI_ABS>), grid, block, 0, c.st, p); break;
+            default: hipLaunchKernelGGL((k_bound<EPI_W_SQ>), grid, block, 0, c.st, p); break;
+        }
+        r = hipGetLastError() == hipSuccess ? 0 : fail(P4V_ERR_HIP, "k_bound launch failed");
+    } else
     if (fast && p.halves > 0) r = p.a_cs == 0 ? launch_sweep9_epi<true>(c, p, epi, cgroups) : launch_sweep9_epi<false>(c, p, epi, cgroups);
     else if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
     else if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
@@ -592,7 +602,8 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     if (timed) {
         HIPCHK(hipEventRecord(rec.b, c.st));
         // kernel family of the record (p4v_launch_record.kind): 6 k_sweep9, 7 k_sweep8, 8 k_sweep2g, 9 k_sweep2, 0 / 1 generic int8 / fp32
-        if (fast && p.halves > 0) rec.kind = 6;
+        if (fast && p.bound) rec.kind = 12;
+        else if (fast && p.halves > 0) rec.kind = 6;
         else if (fast && sweep8_ok(p, twin, epi)) rec.kind = 7;
         else if (fast && sweep2g_ok(p)) rec.kind = 8;
         else if (fast) rec.kind = 9;
@@ -703,6 +714,7 @@ struct Pass {
     float* S1_pre; float* S2_pre; bool s_ready;   // scale tables shared by the stages of a pruned pass (same table, same scales)
     SliceCache* scache;       // optional: the module's sample slice, shared by its pruned passes
     SliceCache* scache2;      // optional (Linear): the module's second, larger slice (two-tier pruning, run_pass_pruned)
+    bool bound_kernel;        // stage B1 of a pruned pass: ONE candidate over all samples -> k_bound where the layout allows it
     bool host_sync_ok;        // the caller synchronises the stream after the pass anyway (pass memo): the pruned pass may read
                               // the 8-byte survivor range back and skip the launches of an empty stage B2
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
@@ -747,7 +759,13 @@ int run_pass(Ctx& c, Pass& ps) {
     // stationary-operand sweep (k_sweep4): Linear layers whose invariant operand tile (128 x K int8) fits in LDS
     const bool blocks64 = (ps.s_cs == 1 || ps.sb_div % 64 == 0) &&
                           (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 64 == 0)));
-    const bool b1_generic = g_stage == 2 && tune(TUNE_B1_PATH) == 1;    // experiment: the bound pass on the 128-tile streaming sweeps
+    // stage B1 (one candidate over all samples): k_bound -- rows = samples, columns = features of a plain [M][N] layer, whole
+    // 32-column groups inside one score block (the partial-sum table of the fast sweeps)
+    const bool bound = ps.bound_kernel && ps.i8 && !ps.twin && ps.Z == 1 && !ps.store_out && ps.epi != EPI_COS && !g_force_v1 &&
+                       ps.o_bs == 0 && ps.o_nbs == 0 && ps.bias_axis == 0 && (ps.sb_mode == 0 || ps.sb_mode == 1) &&
+                       (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0))) &&
+                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) && (ps.eq_n == 1 || ps.crange);
+    const bool b1_generic = bound || (g_stage == 2 && tune(TUNE_B1_PATH) == 1);    // (tuning 12=1: experiment, the bound pass on k_sweep2)
     const bool stat_ok = !b1_generic && !ps.store_out && ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
                          ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
                          rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
@@ -861,6 +879,7 @@ int run_pass(Ctx& c, Pass& ps) {
         pk.C = op.expanded ? nc : 1;
         pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
         if (regs6 && !op.expanded) pk.c_inner = 3;                     // k_sweep6: stationary operand in MFMA-fragment order
+        if (bound) pk.c_inner = 3;                                     // k_bound: both operands (one candidate each) in fragment order
         if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
         if (op.expanded && ps.crange) {       // pruned pass: only the candidate groups in range, and not the ones already kept
             pk.crange = ps.crange; pk.c_base = c0;
@@ -999,7 +1018,10 @@ int run_pass(Ctx& c, Pass& ps) {
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
                                         : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
-        if (fast && !ps.store_out && (ps.j_mode == 0 || ps.j_mode == 2)) {
+        sp.bound = bound ? 1 : 0;
+        if (bound) sp.dbg = tune(TUNE_B1_PATH) >= 16 ? (tune(TUNE_B1_PATH) >> 4) : 0;   // (tuning 12 = 16 / 32: k_bound timing ablations)
+        if (bound) { sp.A = rowbuf; sp.B = colbuf; sp.a_cs = sp.b_cs = 0; }   // (the fragment-order image holds the ONE candidate in range)
+        if (fast && !bound && !ps.store_out && (ps.j_mode == 0 || ps.j_mode == 2)) {
             const int h9 = sweep9_halves(sp, ps.twin, ps.epi);
             if (h9 > 0 && (long)h9 * SW9_NW <= p_zs) {       // the table allocated for the 128-tile layout holds this one
                 sp.halves = h9;
@@ -1306,6 +1328,12 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         swap(b1.s1.x); swap(b1.s1.y); swap(b1.s2.x); swap(b1.s2.y);
         b1.cands = vrow;
     } else b1.crange = r1;
+    // ONE candidate per score block over all samples: the kernel built for that (k_bound; tuning 12=3 keeps the sweep kernels).
+    // Its totals are summed in another order than the sweeps', so from here on nothing may depend on stage B1's numbers but the
+    // bound: the selections below are either "the only survivor of every block" (no totals involved) or come from stage B2,
+    // which always re-evaluates stage B1's candidates together with the other survivors.  The candidate's plane is packed for
+    // this pass (one candidate: ~12 us) instead of being read from the module's plane, whose layout belongs to its sweep kernel.
+    if (lin && ps.i8 && !ps.twin && (virt || ps.nj == 1) && tune(TUNE_B1_PATH) != 3) { b1.bound_kernel = true; b1.cache = nullptr; b1.ecache = nullptr; }
     g_stage = 2;
     { const int r_ = run_pass(c, b1); g_stage = 0; if (r_) return r_; }
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
@@ -1371,6 +1399,9 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     b2.S1_pre = S1s; b2.S2_pre = S2s; b2.s_ready = true;
     g_stage = 3;
     { const int r_ = run_pass(c, b2); g_stage = 0; if (r_) return r_; }
+    // Stage B2's range is the hull of ALL survivors, stage B1's candidates among them: its table decides.  The merge only fills
+    // entries stage B2 did NOT evaluate (-inf) with stage B1's -- i.e. it matters when the device-side range was empty and this
+    // path ran without the host knowing (no pass memo): then every block's only survivor is stage B1's candidate.
     if (!c.dry) {
         if (virt) hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
         else hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
@@ -2503,7 +2534,7 @@ static int stats_drain() {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
         ms = (float)std::max(0.0, (double)ms - g_evt_overhead_ms);
-        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9)) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9) || r.kind == 12) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
         if (r.kind == 3 || r.kind == 4) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
         if (r.kind == 4) { g_stats.sweep7_twin_ms += ms; g_stats.sweep7_twin_launches++; }

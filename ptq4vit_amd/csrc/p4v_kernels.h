@@ -569,6 +569,7 @@ struct SweepParams {
     float* store;                      // EPI_STORE output [M][N]
     int halves;                        // k_sweep9: workgroups per batch entry (part layout [C][Z][halves * 8]); 0 otherwise
     int rows_p_stream;                 // k_sweep9: padded rows of the streamed operand plane
+    int bound;                         // 1: the one-candidate bound pass of a pruned search -> k_bound (no candidate loop)
 };
 
 static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
@@ -1115,6 +1116,143 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         const int cc = c_lo + i / 8, wv = i % 8;
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bound: ONE candidate over ALL samples -- stage B1 of a pruned pass (p4v_api.hip::run_pass_pruned), the bound L*
+// ------------------------------------------------------------------------------------------
+// A pruned Linear pass evaluates one candidate (per score block) on every sample to get the bound that decides which candidates
+// of the slice survive.  That is a plain int8 GEMM M x N x K with the metric epilogue and NO candidate loop to amortise
+// anything over: on the sweep kernels it costs a full workgroup prologue per tile (k_sweep6: one workgroup per CU with 512
+// registers per wave, 20 us of latency-bound prologue for 2.4 us of MFMAs; 83 us for ViT-B fc1 / qkv, the CUs blocked for every
+// other stream meanwhile) where the bytes it must read -- raw_out and the metric weight, 8 B per output: 155 MB for fc1 -- take
+// 30 us.  This kernel is built for that regime instead:
+//   * no LDS, no barrier, no ring: every wave owns a 64 x 32 tile of outputs and loads its MFMA fragments straight from L2.
+//     Both operand planes are packed for this pass in MFMA-fragment order (1 KB contiguous per fragment: 8 cache lines per
+//     load instruction; from row-major planes an instruction touches 32 rows -- measured 104 us for ViT-B fc1, the dead end of
+//     DESIGN 5.1) and the fragments of k-tile t + 2 are requested before the MFMAs of k-tile t (inline-asm loads, counted waits);
+//   * 4 waves per workgroup (2 x 2 tiles: neighbours share rows in the L1), 4 workgroups per CU next to anything else:
+//     the loads of one wave hide under the MFMAs and the epilogue of the others;
+//   * raw_out / metric weight are read in place at the end (128 contiguous bytes per half wave and row), one float per
+//     (64-row slab, 32-column group) goes to the partial-sum table k_sweep2 uses, k_finish reduces it as for any fast sweep.
+// Its totals are summed in another order than the sweeps' -- so run_pass_pruned never lets a selection depend on them: they
+// only set the bound (margin: prune_margin), and whenever more than the bound's own candidate survives, stage B2 re-evaluates
+// ALL survivors with the unpruned kernels.
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void k_bound(SweepParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    // workgroup tile 128 rows x 64 columns (2 x 2 waves of 64 x 32): p.ntiles counts 128-column tiles
+    const int ntiles = p.ntiles * 2;
+    const int nwg = p.mtiles * ntiles;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    constexpr int GM = 4;                                  // tile order as k_sweep2: GM row tiles x all column tiles per group
+    const int per_group = GM * ntiles;
+    const int first_m = (t / per_group) * GM;
+    const int gsz = min(p.mtiles - first_m, GM);
+    const int mt = first_m + (t % per_group) % gsz, nt = (t % per_group) / gsz;
+    int c = p.c0;
+    if (p.crange) {
+        const int a = __builtin_amdgcn_readfirstlane(p.crange[0]), b = __builtin_amdgcn_readfirstlane(p.crange[1]);
+        if (a >= b) return;                                // empty range: k_finish writes -inf without reading the table
+        c = max(c, a);
+    }
+    if (c >= p.c1) return;                                 // (a chunked plane: the candidate lives in another chunk's launch)
+    const int wr = wid >> 1, wc = wid & 1;
+    const int m0 = mt * 128 + wr * 64, n0 = nt * 64 + wc * 32;
+    float* slot = p.part + (long)c * p.p_cs + (long)(mt * 2 + wr) * p.Np + nt * 2 + wc;
+    if (m0 >= p.M || n0 >= p.N) {                          // a tile of pure padding
+        if (lane == 63) slot[0] = 0.0f;
+        return;
+    }
+    // Both planes are packed FOR this pass in MFMA-fragment order (k_pack layout c_inner = 3, the one k_sweep6's stationary
+    // operand uses): [64-row slab][k-tile][32-row block][MFMA of the k-tile][lane] x 16 B -- every fragment is 1 KB contiguous,
+    // a wave's load touches 8 cache lines instead of 32 rows.  Wave-uniform 64-bit bases (SGPR pairs, advanced per k-tile) +
+    // the lane's 32-bit offset: no vector address arithmetic.
+    const char* sA = (const char*)p.A + (long)(m0 >> 6) * p.ktiles * 4096;
+    const char* sB = (const char*)p.B + (long)(n0 >> 6) * p.ktiles * 4096 + ((n0 >> 5) & 1) * 2048;
+    const unsigned vo = (unsigned)lane * 16u;
+    v16i acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+    struct Fr { v4i a[2][2], b[2]; };                      // [32-row block][first / second 16 bytes of the lane's 32]
+    // Inline-asm loads with counted waits: left to itself hipcc waits vmcnt(0) before the MFMAs of k-tile t, i.e. also for the
+    // fragments of k-tile t + 1 it has just requested -- no overlap at all (seen in the ISA of the first version).
+#define P4V_BLD(dst, voff, sbase, off) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(off) : "memory")
+    auto load = [&](Fr& f) __attribute__((always_inline)) {            // 6 loads of 1 KB: the next k-tile of both operands
+        P4V_BLD(f.a[0][0], vo, sA, 0); P4V_BLD(f.a[0][1], vo, sA, 1024);
+        P4V_BLD(f.b[0], vo, sB, 0); P4V_BLD(f.b[1], vo, sB, 1024);
+        P4V_BLD(f.a[1][0], vo, sA, 2048); P4V_BLD(f.a[1][1], vo, sA, 3072);
+        sA += 4096; sB += 4096;
+    };
+    auto mma = [&](Fr& f) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.b[0]), "+v"(f.b[1]) :: "memory");   // after the wait
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[i][h], f.b[h], acc[i], 0, 0, 0);
+    };
+    Fr f0, f1, f2;
+    const int ktiles = p.ktiles;
+    // three fragment sets, two k-tiles in flight (tile t + 2 is requested before the MFMAs of tile t), four waves per SIMD
+    constexpr int LD = 6;
+    load(f0);
+    if (ktiles > 1) load(f1);
+    auto step = [&](int kt, Fr& cur, Fr& refill) __attribute__((always_inline)) {
+        const int ahead = min(ktiles - 1 - kt, 2);         // tiles after kt that are in flight once the refill is issued
+        if (kt + 2 < ktiles) load(refill);
+        if (ahead >= 2) wait_vmcnt<2 * LD>(); else if (ahead == 1) wait_vmcnt<LD>(); else wait_vmcnt<0>();
+        mma(cur);
+    };
+    for (int kt = 0; kt < ((p.dbg & 1) ? 1 : ktiles); kt += 3) {     // (dbg 1: timing-only ablation, one k-tile)
+        step(kt, f0, f2);
+        if (kt + 1 < ktiles) step(kt + 1, f1, f0);
+        if (kt + 2 < ktiles) step(kt + 2, f2, f1);
+    }
+#undef P4V_BLD
+    // ---- metric epilogue: raw_out / weight read in place, one sum per (64-row slab, 32-column group) ----
+    // The weight tensor is raw_grad (hessian) or raw_out itself (the host passes Wt = O for the raw_out-weighted metrics:
+    // square-weighted (w d)^2 with w = raw_out, linear-weighted |w| d^2) -- no run-time switch in the element loop.
+    const int n = n0 + l31;
+    const bool ncol_ok = n < p.N;
+    const int nc = min(n, p.N - 1);
+    const float bias_n = (p.bias && ncol_ok) ? p.bias[nc] : 0.0f;
+    const int sb = p.sb_mode == 1 ? min(nc / p.sb_div, p.s_cs - 1) : 0;
+    const float s1 = p.S1 ? p.S1[(long)c * p.s_cs + sb] : 1.0f;
+    const float* On = p.O + (long)nc * p.o_ns;
+    const float* Wn = p.Wt + (long)nc * p.o_ns;
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                          // one 32 x 32 block: 16 + 16 loads in flight per lane (the fragment registers are dead)
+        float u[16], w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                     // every load at a clamped (valid) address, back to back
+            const int mc = (p.dbg & 2) ? 0 : min(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.M - 1);   // (dbg 2: ablation, one row)
+            u[r] = On[(long)mc * p.o_ms];
+            if (EPI == EPI_SQ_W || EPI == EPI_W_SQ) w[r] = Wn[(long)mc * p.o_ms];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const bool ok = ncol_ok && m < p.M;
+            const float o = u[r];
+            float wv = 1.0f;
+            if (EPI == EPI_SQ_W) wv = w[r]; else if (EPI == EPI_W_SQ) wv = fabsf(w[r]);
+            const float d = (o - bias_n) - (float)acc[i][r] * s1;
+            float term;
+            if (EPI == EPI_SQ_W) { const float t2 = wv * d; term = t2 * t2; }
+            else if (EPI == EPI_SQ) term = d * d;
+            else if (EPI == EPI_ABS) term = fabsf(d);
+            else term = (wv * d) * d;
+            sum += ok ? term : 0.0f;
+        }
+        asm volatile("" ::: "memory");
+    }
+    sum = wave_sum_dpp(sum);
+    if (lane == 63) slot[0] = sum;
 }
 
 // ------------------------------------------------------------------------------------------
