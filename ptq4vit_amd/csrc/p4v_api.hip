@@ -729,10 +729,10 @@ static const long PLANE_BUDGET_DEFAULT = 6L << 30;  // bytes of candidate-expand
 // 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary
 // operand) again.  Cost model in microseconds, constants measured on MI355X (profiles/): minimise
 // rounds * (prologue + candidates_per_group * ktiles * tile_time).
-int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_us, double tile_us) {
+int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_us, double tile_us, int cg_max = 25) {
     int best = 1;
     double best_t = 1e30;
-    for (int cg = 1; cg <= std::min(ncand, 25); ++cg) {
+    for (int cg = 1; cg <= std::min(ncand, cg_max); ++cg) {
         const long rounds = (wgs * cg + slots - 1) / slots;
         const double t = (double)rounds * (prologue_us + (double)cdiv(ncand, cg) * ktiles * tile_us);
         if (t < best_t * 0.999) { best_t = t; best = cg; }
@@ -974,7 +974,9 @@ int run_pass(Ctx& c, Pass& ps) {
             q.rtiles = Np / 256; q.ctiles = Mp / (ps.twin ? 128 : 256);
             // one workgroup per CU; per k-tile ~0.62 us (16 MFMAs per wave, two waves per SIMD), ~3 k-tiles' worth of
             // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
-            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, 256, 6.0, 0.62);
+            // (up to one candidate per workgroup: stage A of a pruned pass is 3 tiles x 100 candidates -- with the 25 groups of the
+            // other sweeps 75 workgroups on 256 CUs, 140-160 us per launch)
+            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, 256, 6.0, 0.62, 100);
             if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
             q.order = tune(TUNE_ORDER7) > 0 ? tune(TUNE_ORDER7) - 1 : 1;
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);

@@ -3190,7 +3190,10 @@ __global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
         Bt[i] = (k < p.K && n < p.N) ? p.B[zoffB + (long)k * p.b_k + (long)n * p.b_n] : 0.0f;
     }
     // ---- this wave's 32 rows: the two candidate-invariant images of every element ----------------------------------
-    const int row0 = half * 128 + wid * 32;
+    // (a problem of at most 32 rows -- the 16-row sample slice of a pruned pass -- would leave three of the four waves without
+    // rows: there all four take the SAME rows and every fourth candidate each)
+    const bool share = p.M <= 32 && p.halves == 1;
+    const int row0 = share ? 0 : half * 128 + wid * 32;
     const int row = row0 + l31;
     float hv[KS], yv[KS];
     {
@@ -3224,7 +3227,7 @@ __global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
     const float* b0 = Bt + g * 64 + l31;      // B fragment of k-step ks, column block cb: b0[ks * 128 + cb * 32]
     int c_lo_ = 0, c_hi_ = p.C;
     clip_crange(p.crange, c_lo_, c_hi_);
-    for (int c = c_lo_; c < c_hi_; ++c) {
+    for (int c = c_lo_ + (share ? wid : 0); c < c_hi_; c += share ? 4 : 1) {
         const float s = p.splits[c];
         const float inv_s = 1.0f / s;                           // 2^i, exact
         const float a_int = s / p.qm1;                          // matmul.py:609
