@@ -608,7 +608,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         else if (fast && sweep2g_ok(p)) rec.kind = 8;
         else if (fast) rec.kind = 9;
         rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.bytes = g_alg_bytes;
-        rec.gx = (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles; rec.gz = cgroups;
+        rec.gx = (fast && p.bound) ? p.mtiles * p.ntiles * 2 : (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles; rec.gz = cgroups;
         g_stat_recs.push_back(rec);
     }
     return r;
