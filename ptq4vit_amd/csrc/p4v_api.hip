@@ -187,6 +187,7 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (tune(TUNE_PRINT) > 1) fprintf(stderr, "[p4v] k_pack stage %d: Z %d Rp %d Kp %d C %d crange %d done %d layout %d blocks %d\n", g_stage, p.Z, p.Rp, p.Kp, p.C, p.crange != nullptr, p.done != nullptr, p.c_inner, blocks);
     hipLaunchKernelGGL(k_pack<T>, dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;
@@ -788,9 +789,18 @@ int run_pass(Ctx& c, Pass& ps) {
     // k_sweep6 tiles the stationary operand (the one that is NOT candidate-expanded) in 256-row slabs
     const int Mp = (int)rup(ps.Mrows, big7 ? (ps.twin ? 128 : 256) : (regs6 && !ps.row.expanded) ? 256 : PADR);
     const int Np = (int)rup(ps.Ncols, big7 ? 256 : (regs6 && !ps.col.expanded) ? 256 : PADR);
-    const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * Np * Kp * esz;
+    // rows of the column operand's plane: the tile-padded count, except for the 64-column operands of the batched k_sweep2 passes
+    // (attn.v: B = V, N = head_dim = 64 -- 100 candidate planes of 384 x 128 x 256 B = 1.26 GB per ViT-B module half of which was
+    // padding: 630 us of k_pack and the stream of k_sweep2's stage A): k_sweep2 re-reads rows 0..63 for the tile's upper half
+    const bool fast_pre = !stat_ok && !(ps.store_out && (g_variant & 4096)) && ps.i8 && ps.epi != EPI_COS && !(g_force_v1) &&
+                          (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
+                          (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
+    const bool b64 = fast_pre && !big7 && !bound && ps.Z > 1 && !ps.col_zs_shared && ps.Ncols <= 64 && Kp / SW_BKB >= 2 && Kp / SW_BKB <= 15 &&
+                     !ps.store_out && tune(TUNE_B1_PATH) != 5;
+    const int NpB = b64 ? 64 : Np;
+    const long row_plane = (long)ps.Z * Mp * Kp * esz, col_plane = (long)ps.Z * NpB * Kp * esz;
     const long row_plane1 = ps.row_zs_shared ? (long)Mp * Kp * esz : row_plane;
-    const long col_plane1 = ps.col_zs_shared ? (long)Np * Kp * esz : col_plane;
+    const long col_plane1 = ps.col_zs_shared ? (long)NpB * Kp * esz : col_plane;
     const long exp_plane = ps.row.expanded ? row_plane1 : col_plane1;
     int chunk = (int)std::max<long>(1, std::min<long>(ps.eq_n, PLANE_BUDGET / std::max<long>(1, exp_plane)));
 
@@ -909,7 +919,7 @@ int run_pass(Ctx& c, Pass& ps) {
         if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
         if (ps.twin && !ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, 0, 1));
     }
-    if (!ps.col.expanded) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, 0, 1));
+    if (!ps.col.expanded) CHK(pack(ps.col, colbuf, NpB, ps.col_zs_shared, 0, 1));
 
     int nine_halves = 0;
     for (int c0 = 0; c0 < ps.eq_n; c0 += chunk) {
@@ -917,7 +927,7 @@ int run_pass(Ctx& c, Pass& ps) {
         const bool packed = pc && pc->valid;   // (a cached plane is never chunked: one iteration)
         if (ps.row.expanded && !packed) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, c0, nc));
         if (ps.twin && ps.row2.expanded) CHK(pack(ps.row2, row2buf, Mp, ps.row_zs_shared, c0, nc));
-        if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, Np, ps.col_zs_shared, c0, nc));
+        if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, NpB, ps.col_zs_shared, c0, nc));
         if (pc && !ps.crange && !packed) {   // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
             pc->valid = true;
             if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)ps.eq_n, c.st));
@@ -995,7 +1005,8 @@ int run_pass(Ctx& c, Pass& ps) {
         }
         sp.b_cs = ps.col.expanded ? col_plane1 : 0;
         sp.B = colbuf - (long)c0 * sp.b_cs;
-        sp.b_zs = ps.col_zs_shared ? 0 : (long)Np * Kp * esz;
+        sp.b_zs = ps.col_zs_shared ? 0 : (long)NpB * Kp * esz;
+        sp.b_rows = b64 ? 64 : 0;
         sp.ldk = Kp * esz; sp.ktiles = sp.ldk / SW_BKB;
         sp.S1 = S1; sp.S2 = S2; sp.s_cs = ps.s_cs; sp.sb_mode = ps.sb_mode; sp.sb_div = std::max(1, ps.sb_div);
         sp.bias = ps.bias; sp.bias_axis = ps.bias_axis; sp.bias_zs = ps.bias_zs;

@@ -570,6 +570,8 @@ struct SweepParams {
     int halves;                        // k_sweep9: workgroups per batch entry (part layout [C][Z][halves * 8]); 0 otherwise
     int rows_p_stream;                 // k_sweep9: padded rows of the streamed operand plane
     int bound;                         // 1: the one-candidate bound pass of a pruned search -> k_bound (no candidate loop)
+    int b_rows;                        // k_sweep2: rows of the B plane per batch entry when it is NOT padded to the 128-column tile
+                                       // (64: attn.v, N = head_dim); 0 = padded.  The tile's other rows re-read these (masked columns).
 };
 
 static constexpr int SW_BM = 128, SW_BN = 128, SW_BKB = 64, SW_ROW = 80;  // LDS row = 64 B + 16 B pad
@@ -960,6 +962,9 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int ld_row = wid * 16 + (lane >> 2);
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);          // logical 16-B chunk landing in physical slot lane&3
     const unsigned voffA = (unsigned)(ld_row * p.ldk + ld_chunk * 16);
+    // (a B plane of 64 rows -- attn.v: N = 64 of the 128-column tile, 100 candidate planes of V per module -- is not padded to
+    // the tile: the DMA of the tile's upper rows re-reads rows 0..63 into the LDS, their columns are masked in the epilogue)
+    const unsigned voffB = p.b_rows > 0 ? (unsigned)((ld_row & (p.b_rows - 1)) * p.ldk + ld_chunk * 16) : voffA;
     const char* curA = (const char*)p.A + (long)z * p.a_zs + (long)m0 * p.ldk + (long)c_lo * p.a_cs;
     const char* curA2 = TWIN ? (const char*)p.A2 + (long)z * p.a2_zs + (long)m0 * p.ldk + (long)c_lo * p.a2_cs : nullptr;
     const char* curB = (const char*)p.B + (long)z * p.b_zs + (long)n0 * p.ldk + (long)c_lo * p.b_cs;
@@ -975,7 +980,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         char* s = smem + stage * SW2_TILE + lds_wave;
         glds16(curA + voffA, s);
         if (TWIN) glds16(curA2 + voffA, s + PLANE);
-        glds16(curB + voffA, s + (NPL - 1) * PLANE);
+        glds16(curB + voffB, s + (NPL - 1) * PLANE);
         curA += SW_BKB; curB += SW_BKB;
         if (TWIN) curA2 += SW_BKB;
         if (++ikt == ktiles) { ikt = 0; curA += wrapA; curB += wrapB; if (TWIN) curA2 += wrapA2; }
