@@ -43,6 +43,7 @@ def search_macs(wrapped, shapes, calib, eq_n=100, rounds=3):
     lin = mm = conv = 0.0
     for name, m in wrapped.items():
         ins, out = shapes[name]
+        rounds, eq_n = getattr(m, "search_round", rounds), getattr(m, "eq_n", eq_n)      # (BasePTQ: one round)
         if isinstance(m, MinMaxQuantLinear):
             rows = calib * int(torch.tensor(ins[0][:-1]).prod())
             lin += rounds * 2 * eq_n * rows * m.in_features * m.out_features
@@ -312,6 +313,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--calib", type=int, default=32)
+    ap.add_argument("--config", default="PTQ4ViT", choices=["PTQ4ViT", "BasePTQ"],
+                    help="quantisation config module (reference configs/): PTQ4ViT = twin quantisers + hessian metric, 3 rounds (the headline); "
+                         "BasePTQ = cosine metric, 1 round, plain quantisers")
     ap.add_argument("--bits", type=int, default=8, help="W/A bit width of every wrapped module (8 = headline W8A8; 6 = the W6A6 config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-numpy", action="store_true", help="time the numpy parity oracle as the CPU baseline instead of the multi-threaded torch port")
@@ -347,7 +351,8 @@ def main():
             dist.init_process_group(backend)
 
     from ptq4vit_amd import engine
-    from ptq4vit_amd.configs import PTQ4ViT
+    import importlib
+    PTQ4ViT = importlib.import_module(f"ptq4vit_amd.configs.{args.config}")      # (the name the rest of this file uses for "the config")
     from ptq4vit_amd.utils import models, net_wrap
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
 
@@ -582,19 +587,19 @@ def main():
         del net, wrapped
         torch.cuda.empty_cache()
         max_val = int(os.environ["P4V_TOP1_MAX_VAL"]) if os.environ.get("P4V_TOP1_MAX_VAL") else None
-        top1 = eval_top1.evaluate(args.model, os.environ["P4V_IMAGENET"], os.environ["P4V_WEIGHTS"], "PTQ4ViT", args.bits, args.calib,
+        top1 = eval_top1.evaluate(args.model, os.environ["P4V_IMAGENET"], os.environ["P4V_WEIGHTS"], args.config, args.bits, args.calib,
                                   3, 128, max_val, int(os.environ.get("P4V_TOP1_WORKERS", "8")), quiet=True)
         top1_reason = None
 
     if rank == 0:
         t = cals[-1].timings
         line = {
-            "metric": "calibration throughput (wrapped modules calibrated per second), ViT-B/224 W8A8, 32 calibration images" if (args.model == "vit_base_patch16_224" and args.bits == 8 and args.calib == 32) else f"calibration throughput (wrapped modules calibrated per second), {args.model} W{args.bits}A{args.bits}, {args.calib} calibration images",
+            "metric": "calibration throughput (wrapped modules calibrated per second), ViT-B/224 W8A8, 32 calibration images" if (args.model == "vit_base_patch16_224" and args.bits == 8 and args.calib == 32 and args.config == "PTQ4ViT") else f"calibration throughput (wrapped modules calibrated per second), {args.model} {args.config} W{args.bits}A{args.bits}, {args.calib} calibration images",
             "value": value, "unit": "layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "calibration_wall_clock_s": elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8",
             "data": "synthetic (seeded N(0,1) images, trunc-normal weights)",
-            "config": {"workload": f"{args.model} PTQ4ViT W{args.bits}A{args.bits}, {args.calib} calibration images, {n_mod} wrapped modules, "
+            "config": {"workload": f"{args.model} {args.config} W{args.bits}A{args.bits}, {args.calib} calibration images, {n_mod} wrapped modules, "
                                    "HessianQuantCalibrator.batching_quant_calib (capture + search)",
                        "global_batch": args.calib, "parallelism": f"layers sharded over {world} GPU(s)"},
             "breakdown": {"capture_s": t["capture_s"], "search_s": t["search_s"]},

@@ -1220,6 +1220,97 @@ int prune_crosscheck_end(Ctx& c, const float* interval, int n, const std::vector
             return fail(P4V_ERR_INVALID, "exact candidate pruning selected another candidate than the full sweep (%s, output %d: %.9g vs %.9g)", what, i, (double)pruned[i], (double)full[i]);
     return 0;
 }
+// ---- stage A of a pruned MatMul B search in one kernel (k_slice_b: B quantised in the kernel, no candidate planes) ---------------
+// `a` is the stage-A pass run_pass_pruned built (row operand = the 16-row slices, dense [Z][16][K]; column operand = the whole B,
+// candidate-expanded); `SA` receives the scores [eq_n][nj].  Conditions: int8, head-wise scales (block = z % H on both the
+// quantiser and the output scales), K <= 256, N <= 208, no bias, a difference metric.
+bool slice_b_ok(const Pass& a) {
+    const PackParams& b = a.col.pk;
+    return a.i8 && a.col.expanded && !a.row.expanded && !(a.twin && a.row2.expanded) && a.Z > 1 && a.Mrows <= 16 && !a.store_out &&
+           a.epi != EPI_COS && a.epi != EPI_STORE && a.epi != EPI_FWD && !a.bias && a.use_s1 && a.sb_mode == 2 && a.j_mode == 2 &&
+           a.sb_div == a.j_div && a.s_cs == a.sb_div && !a.crange && a.scores_keep && a.no_select &&
+           !b.conv && b.mode == PACK_SYM && b.blk_mode == 2 && b.blk_div == a.sb_div && b.scales && !a.col_zs_shared && !a.row_zs_shared &&
+           rup(a.K, 64) <= 256 && a.Ncols <= 208 && (rup(a.K, 64) == 64 || a.Ncols <= 64) && a.o_ms == a.Ncols && a.o_ns == 1 &&
+           a.o_zs == (long)a.Mrows * a.Ncols && !a.o_bs && !a.o_nbs && !g_force_v1 && tune(TUNE_B1_PATH) != 6;
+}
+int run_slice_b(Ctx& c, Pass& a, float* SA) {
+    const int Kp = (int)rup(a.K, 64), Z = a.Z;
+    const size_t mark = c.ws.off;
+    int8_t* A1 = c.ws.get<int8_t>((size_t)Z * 16 * Kp);
+    int8_t* A2 = a.twin ? c.ws.get<int8_t>((size_t)Z * 16 * Kp) : nullptr;
+    float* part = c.ws.get<float>((size_t)a.eq_n * Z);
+    float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
+    float* S2 = !a.twin ? nullptr : a.S2_pre ? a.S2_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    if (!a.s_ready) {
+        a.s1.S = S1; a.s1.C = a.eq_n; a.s1.nblk = a.s_cs;
+        CHK(launch_scale(c, a.s1));
+        if (a.twin) { a.s2.S = S2; a.s2.C = a.eq_n; a.s2.nblk = a.s_cs; CHK(launch_scale(c, a.s2)); }
+    }
+    auto pack16 = [&](const Operand& op, int8_t* dst) -> int {     // the slice's fixed plane(s): [Z][16][Kp], row-major
+        PackParams pk = op.pk;
+        pk.Rp = 16; pk.Kp = Kp; pk.dst = dst; pk.Z = Z; pk.C = 1; pk.c_inner = 0;
+        return launch_pack<int8_t>(c, pk);
+    };
+    CHK(pack16(a.row, A1));
+    if (a.twin) CHK(pack16(a.row2, A2));
+    if (!c.dry) {
+        const PackParams& b = a.col.pk;
+        SliceBParams kp{};
+        kp.A = A1; kp.A2 = A2;
+        kp.B = b.src; kp.b_z2 = b.s_z2; kp.b_z = b.s_z; kp.b_n = b.s_r; kp.b_k = b.s_k; kp.zdiv = b.zdiv;
+        kp.bscale = b.scales; kp.bs_cs = b.sc_cs; kp.bs_div = b.blk_div; kp.lo = b.lo; kp.hi = b.hi;
+        kp.S1 = S1; kp.S2 = S2; kp.s_cs = a.s_cs; kp.s_div = a.sb_div;
+        kp.O = a.O; kp.Wt = a.G ? a.G : a.O; kp.wt_mode = a.wt_mode;
+        kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.Kp = Kp; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
+        const int nb = cdiv(a.Ncols, 16);
+        const size_t lds = (size_t)nb * 16 * (Kp + 4) * sizeof(float);
+        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));       // >= 1024 workgroups, >= 4 candidates each
+        const dim3 grid(Z, groups), block(256);
+        const bool timed = g_stat_on;
+        StatRec rec{};
+        if (timed) {
+            HIPCHK(hipEventCreate(&rec.a));
+            HIPCHK(hipEventCreate(&rec.b));
+            rec.kind = 13;
+            rec.alg = (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n;
+            rec.macs = 16.0 * nb * 16 * Kp * Z * a.eq_n * (a.twin ? 2 : 1);
+            HIPCHK(hipEventRecord(rec.a, c.st));
+        }
+#define P4V_LAUNCH_SB(TW, KTM, NBM, E)                                                                          \
+        do {                                                                                                    \
+            static bool attr_set = false;                                                                       \
+            if (!attr_set) {                                                                                    \
+                HIPCHK(hipFuncSetAttribute((const void*)k_slice_b<TW, KTM, NBM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+                attr_set = true;                                                                                \
+            }                                                                                                   \
+            hipLaunchKernelGGL((k_slice_b<TW, KTM, NBM, E>), grid, block, lds, c.st, kp);                       \
+        } while (0)
+#define P4V_LAUNCH_SB_E(TW, KTM, NBM)                                                                           \
+        switch (a.epi) {                                                                                        \
+            case EPI_SQ_W: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_SQ_W); break;                                        \
+            case EPI_SQ: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_SQ); break;                                            \
+            case EPI_ABS: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_ABS); break;                                          \
+            default: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_W_SQ); break;                                              \
+        }
+        if (Kp == 64) { if (a.twin) P4V_LAUNCH_SB_E(true, 1, 13) else P4V_LAUNCH_SB_E(false, 1, 13) }
+        else { if (a.twin) P4V_LAUNCH_SB_E(true, 4, 4) else P4V_LAUNCH_SB_E(false, 4, 4) }
+#undef P4V_LAUNCH_SB_E
+#undef P4V_LAUNCH_SB
+        HIPCHK(hipGetLastError());
+        if (timed) {
+            HIPCHK(hipEventRecord(rec.b, c.st));
+            rec.stage = g_stage; rec.gx = Z; rec.gz = groups;
+            rec.bytes = 4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z;
+            g_stat_recs.push_back(rec);
+        }
+    }
+    FinishParams fp{part, (long)Z, 1L, 1, 1, Z, 1, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
+    CHK(launch_finish(c, fp));
+    c.ws.off = mark;
+    return 0;
+}
+
 int run_pass_pruned_impl(Ctx& c, Pass& ps);
 int run_pass_pruned(Ctx& c, Pass& ps) {
     if (!(g_variant & 134217728) || !prune_ok(ps) || (!c.dry && !ps.interval)) return run_pass_pruned_impl(c, ps);
@@ -1328,7 +1419,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, prune_margin(), r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
     g_stage = 1;
-    { const int r_ = run_pass(c, a); g_stage = 0; if (r_) return r_; }
+    { const int r_ = slice_b_ok(a) ? run_slice_b(c, a, SA) : run_pass(c, a); g_stage = 0; if (r_) return r_; }
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
@@ -2547,7 +2638,7 @@ static int stats_drain() {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
         ms = (float)std::max(0.0, (double)ms - g_evt_overhead_ms);
-        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9) || r.kind == 12) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9) || r.kind == 12 || r.kind == 13) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
         if (r.kind == 3 || r.kind == 4) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
         if (r.kind == 4) { g_stats.sweep7_twin_ms += ms; g_stats.sweep7_twin_launches++; }

@@ -1668,6 +1668,144 @@ __global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_slice_b: stage A of a pruned MatMul B search -- all candidates of B on the 16-row sample slice, B quantised IN the kernel
+// ------------------------------------------------------------------------------------------
+// Stage A of the B search of an attention matmul (p4v_api.hip::run_pass_pruned) scores the 100 candidate scales of the WHOLE
+// column operand (the keys of q.k^T, the values of attn.v) against the 16 heaviest query rows of every (image, head).  On the sweep
+// kernels that meant materialising 100 int8 planes of B (629 MB per ViT-B module for the keys, 630 MB for the values: k_pack at
+// 4.6 TB/s) only to stream them once through a GEMM with 16 useful rows (k_sweep9 / k_sweep2 at the HBM rate, or below it: the
+// fixed twin planes of attn.v were re-streamed per candidate) -- both memory-bound on bytes that exist for this one read.
+// Here a workgroup owns one (image, head): B (fp32, 50 KB) is read ONCE into the LDS (transposed to [n][k], padded rows), every
+// wave takes every fourth candidate and quantises B's 16 x 64 fragments in registers with k_pack's own arithmetic
+// (quant_fast1 + the exactness check + the IEEE division for flagged elements: the same integers), feeds them to
+// mfma_i32_16x16x64_i8 against the slice's fragments, which stay in registers with raw_out / the metric weight, and writes one
+// float per (candidate, batch entry).  No candidate plane is written or read; what is left is the VALU work of the quantisation.
+// The planes stage B2 needs (the few surviving candidates, all rows) are packed on demand as before.
+struct SliceBParams {
+    const int8_t* A; const int8_t* A2;     // int8 planes [Z][16][Kp] of the fixed row operand (its slice); A2: twin second plane
+    const float* B; long b_z2, b_z, b_n, b_k; int zdiv;     // fp32 column operand: element (z, n, k) at B[(z / zdiv) b_z2 + (z % zdiv) b_z + n b_n + k b_k]
+    const float* bscale; int bs_cs, bs_div;                 // candidate scales: bscale[c * bs_cs + z % bs_div]
+    int lo, hi;                                             // grid clamp of B
+    const float* S1; const float* S2; int s_cs, s_div;      // combined output scales [C][s_cs] of plane 1 / 2, block z % s_div
+    const float* O; const float* Wt; int wt_mode;           // slice tiles [Z][16][N] fp32 (dense): raw_out, metric weight source
+    int Z, M, K, Kp, N, C;                                  // M <= 16 valid slice rows
+    float* part;                                            // [C][Z]
+};
+template <bool TWIN, int KTM, int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Bt = reinterpret_cast<float*>(smem);                         // [NB * 16][Kp + 4] fp32, zero padded
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int z = blockIdx.x;
+    const int ktn = p.Kp / 64, nb = (p.N + 15) / 16, ldb = p.Kp + 4;
+    const int per = (p.C + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * per, c_hi = min(p.C, c_lo + per);
+    // ---- B of this batch entry -> LDS as [n][k]; the faster-varying index of the copy follows the contiguous source stride --------
+    const float* Bz = p.B + (p.zdiv > 0 ? (long)(z / p.zdiv) * p.b_z2 + (long)(z % p.zdiv) * p.b_z : (long)z * p.b_z);
+    const int rows = nb * 16;
+    if (p.b_k == 1) {
+        for (int i = tid; i < rows * p.Kp; i += 256) {
+            const int n = i / p.Kp, k = i - n * p.Kp;
+            Bt[n * ldb + k] = (n < p.N && k < p.K) ? Bz[(long)n * p.b_n + k] : 0.0f;
+        }
+    } else {
+        for (int i = tid; i < rows * p.Kp; i += 256) {
+            const int k = i / rows, n = i - k * rows;
+            Bt[n * ldb + k] = (n < p.N && k < p.K) ? Bz[(long)n * p.b_n + (long)k * p.b_k] : 0.0f;
+        }
+    }
+    // ---- fixed fragments of the slice (16 rows x 64 B per k-tile: lane (l4, l15) holds bytes [16 l4, +16) of row l15) -----------
+    v4i_ fa[KTM], fa2[KTM];
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) {
+        const long off = ((long)z * 16 + l15) * p.Kp + (long)min(kt, ktn - 1) * 64 + l4 * 16;
+        fa[kt] = *reinterpret_cast<const v4i_*>(p.A + off);
+        if (TWIN) fa2[kt] = *reinterpret_cast<const v4i_*>(p.A2 + off);
+    }
+    // ---- raw_out / metric weight of the 16 x N tile in accumulator layout: lane -> column l15 of a block, rows 4 l4 + e ---------
+    float u[NBM][4], w[NBM][4];
+    const int wm = p.wt_mode;
+#pragma unroll
+    for (int j = 0; j < NBM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = j * 16 + l15, m = 4 * l4 + e;
+            const bool ok = j < nb && n < p.N && m < p.M;
+            const long idx = ((long)z * 16 + min(m, 15)) * p.N + min(n, p.N - 1);
+            const float o = p.O[idx], gw = p.Wt[idx];
+            float wv;
+            if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+            u[j][e] = ok ? o : 0.0f;
+            w[j][e] = ok ? wv : 0.0f;
+        }
+    __syncthreads();
+    const int sbz = p.bs_div > 0 ? z % p.bs_div : 0, ssz = p.s_div > 0 ? z % p.s_div : 0;
+    const float flo = (float)p.lo, fhi = (float)p.hi;
+    const bool wide = !(fmaxf(-flo, fhi) < 129.0f);
+    const float* brow = Bt + l15 * ldb + l4 * 16;                        // + (block * 16) * ldb + k-tile * 64
+    for (int c = c_lo + wid; c < c_hi; c += 4) {
+        const float s = p.bscale[(long)c * p.bs_cs + sbz];
+        const float rcp = 1.0f / s;
+        const float s1 = p.S1 ? p.S1[(long)c * p.s_cs + ssz] : 1.0f;
+        const float s2 = (TWIN && p.S2) ? p.S2[(long)c * p.s_cs + ssz] : 1.0f;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) {
+            if (j < nb) {                                            // (uniform guard, no break: the loop must unroll -- u / w are registers)
+            v4i_ acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < KTM; ++kt) {
+                if (kt < ktn) {
+                const v4f* src = reinterpret_cast<const v4f*>(brow + (j * 16) * ldb + kt * 64);
+                float x[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const v4f t = src[q]; x[q * 4] = t[0]; x[q * 4 + 1] = t[1]; x[q * 4 + 2] = t[2]; x[q * 4 + 3] = t[3]; }
+                // k_pack's hot path (symmetric grid): x * (1 / s) where provably equal to the division, the division otherwise
+                unsigned qb[16];
+                float maxdev = 0.0f, magic = PACK_MAGIC;
+                asm volatile("" : "+v"(magic));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) qb[e] = quant_fast1(x[e], rcp, flo - 0.49f, fhi + 0.49f, magic, maxdev);
+                const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || wide;
+                if (__any(bad)) {
+                    float sd = s;
+                    asm volatile("" : "+v"(sd));
+                    if (bad) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), flo), fhi) + PACK_MAGIC);
+                    }
+                }
+                v4i_ fb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
+                    const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
+                    fb[q] = (int)(lo16 | (hi16 << 16));
+                }
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[kt], fb, acc, 0, 0, 0);
+                if (TWIN) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[kt], fb, acc2, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = u[j][e] - (float)acc[e] * s1;
+                if (TWIN) d -= (float)acc2[e] * s2;
+                const float ww = w[j][e];
+                if (EPI == EPI_SQ_W) { const float t2 = ww * d; sum = fmaf(t2, t2, sum); }
+                else if (EPI == EPI_ABS) sum = fmaf(ww, fabsf(d), sum);
+                else sum = fmaf(ww * d, d, sum);                        // EPI_SQ (w = validity mask) and EPI_W_SQ
+            }
+            }
+        }
+        sum = wave_sum_dpp(sum);
+        if (lane == 63) p.part[(long)c * p.Z + z] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_sweep2g: k_sweep2 for LARGE K with two candidates per pass (weight search of fc2-like layers)
 // ------------------------------------------------------------------------------------------
 // PMC (profiles/r1_pmc_fc2_sweep2.txt): at K = 3072 k_sweep2 moves 16 KB (24 KB twin) per k-tile from L2 into LDS for
