@@ -362,7 +362,7 @@ typedef struct p4v_kernel_stats {
 typedef struct p4v_launch_record {
     int32_t kind;     /* 2 k_sweep6 | 3 k_sweep7 | 4 k_sweep7 twin | 5 k_sweep4/5 | 6 k_sweep9 | 7 k_sweep8 | 8 k_sweep2g | 9 k_sweep2 |
                          0 generic int8 k_sweep | 1 generic fp32 k_sweep | 11 k_sos_split (fp32) | 12 k_bound (stage B1) |
-                         13 k_slice_b (stage A of a MatMul B search) */
+                         13 k_slice_b / 14 k_slice_a (stage A of a MatMul B / A search) */
     int32_t stage;    /* 0 full sweep (pass not pruned) | 1 stage A (all candidates, sample slice) | 2 stage B1 (the bound) |
                          3 stage B2 (survivors, all samples) | 4 stage A2 (survivors of a loose first slice on the larger second one) */
     int32_t grid_x, grid_z;

@@ -54,7 +54,7 @@ class LaunchRecord(C.Structure):
 
 
 LAUNCH_KINDS = {0: "k_sweep<int8>", 1: "k_sweep<float>", 2: "k_sweep6", 3: "k_sweep7", 4: "k_sweep7 (twin)", 5: "k_sweep4/5", 6: "k_sweep9",
-                7: "k_sweep8", 8: "k_sweep2g", 9: "k_sweep2", 11: "k_sos_split", 12: "k_bound", 13: "k_slice_b"}
+                7: "k_sweep8", 8: "k_sweep2g", 9: "k_sweep2", 11: "k_sos_split", 12: "k_bound", 13: "k_slice_b", 14: "k_slice_a"}
 LAUNCH_STAGES = {0: "full", 1: "A", 2: "B1", 3: "B2", 4: "A2"}
 
 

@@ -1311,6 +1311,73 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
     return 0;
 }
 
+// ... and of a pruned MatMul A search with K <= 64 (k_slice_a: the slice is quantised per candidate in registers, B fixed)
+bool slice_a_ok(const Pass& a) {
+    const PackParams& r = a.row.pk;
+    return a.i8 && a.row.expanded && !a.col.expanded && !a.twin && a.Z > 1 && a.Mrows <= 16 && !a.store_out &&
+           a.epi != EPI_COS && a.epi != EPI_STORE && a.epi != EPI_FWD && !a.bias && a.use_s1 && a.sb_mode == 2 && a.j_mode == 2 &&
+           a.sb_div == a.j_div && a.s_cs == a.sb_div && !a.crange && a.scores_keep && a.no_select &&
+           !r.conv && r.mode == PACK_SYM && r.blk_mode == 2 && r.blk_div == a.sb_div && r.scales && r.s_k == 1 && r.s_r == a.K &&
+           r.zdiv > 0 && r.s_z == (long)a.Mrows * a.K && r.s_z2 == (long)r.zdiv * a.Mrows * a.K && a.Mrows == 16 &&
+           !a.col_zs_shared && !a.row_zs_shared && a.K <= 64 && a.Ncols <= 208 && a.o_ms == a.Ncols && a.o_ns == 1 &&
+           a.o_zs == (long)a.Mrows * a.Ncols && !a.o_bs && !a.o_nbs && !g_force_v1 && tune(TUNE_B1_PATH) != 6;
+}
+int run_slice_a(Ctx& c, Pass& a, float* SA) {
+    const int Z = a.Z, nb = cdiv(a.Ncols, 16);
+    const size_t mark = c.ws.off;
+    int8_t* Bp = c.ws.get<int8_t>((size_t)Z * nb * 16 * 64);
+    float* part = c.ws.get<float>((size_t)a.eq_n * Z);
+    float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
+    if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    if (!a.s_ready) {
+        a.s1.S = S1; a.s1.C = a.eq_n; a.s1.nblk = a.s_cs;
+        CHK(launch_scale(c, a.s1));
+    }
+    {
+        PackParams pk = a.col.pk;                          // the fixed column operand: [Z][nb * 16][64], row-major
+        pk.Rp = nb * 16; pk.Kp = 64; pk.dst = Bp; pk.Z = Z; pk.C = 1; pk.c_inner = 0;
+        CHK(launch_pack<int8_t>(c, pk));
+    }
+    if (!c.dry) {
+        const PackParams& r = a.row.pk;
+        SliceAParams kp{};
+        kp.A = r.src; kp.B = Bp;
+        kp.ascale = r.scales; kp.as_cs = r.sc_cs; kp.as_div = r.blk_div; kp.lo = r.lo; kp.hi = r.hi;
+        kp.S1 = S1; kp.s_cs = a.s_cs; kp.s_div = a.sb_div;
+        kp.O = a.O; kp.Wt = a.G ? a.G : a.O; kp.wt_mode = a.wt_mode;
+        kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
+        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
+        const dim3 grid(Z, groups), block(256);
+        const bool timed = g_stat_on;
+        StatRec rec{};
+        if (timed) {
+            HIPCHK(hipEventCreate(&rec.a));
+            HIPCHK(hipEventCreate(&rec.b));
+            rec.kind = 14;
+            rec.alg = (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n;
+            rec.macs = 16.0 * nb * 16 * 64 * Z * a.eq_n;
+            HIPCHK(hipEventRecord(rec.a, c.st));
+        }
+        switch (a.epi) {
+            case EPI_SQ_W: hipLaunchKernelGGL((k_slice_a<13, EPI_SQ_W>), grid, block, 0, c.st, kp); break;
+            case EPI_SQ: hipLaunchKernelGGL((k_slice_a<13, EPI_SQ>), grid, block, 0, c.st, kp); break;
+            case EPI_ABS: hipLaunchKernelGGL((k_slice_a<13, EPI_ABS>), grid, block, 0, c.st, kp); break;
+            default: hipLaunchKernelGGL((k_slice_a<13, EPI_W_SQ>), grid, block, 0, c.st, kp); break;
+        }
+        HIPCHK(hipGetLastError());
+        if (timed) {
+            HIPCHK(hipEventRecord(rec.b, c.st));
+            rec.stage = g_stage; rec.gx = Z; rec.gz = groups;
+            rec.bytes = 4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z;
+            g_stat_recs.push_back(rec);
+        }
+    }
+    FinishParams fp{part, (long)Z, 1L, 1, 1, Z, 1, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
+    CHK(launch_finish(c, fp));
+    c.ws.off = mark;
+    return 0;
+}
+
 int run_pass_pruned_impl(Ctx& c, Pass& ps);
 int run_pass_pruned(Ctx& c, Pass& ps) {
     if (!(g_variant & 134217728) || !prune_ok(ps) || (!c.dry && !ps.interval)) return run_pass_pruned_impl(c, ps);
@@ -1419,7 +1486,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     const bool virt = ps.nj > 1 && ps.cand_off == 0 && ps.cand_js * ps.nj == ps.cand_cs && ps.cand_cs <= 4096 && !(g_variant & 16777216);
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, prune_margin(), r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
     g_stage = 1;
-    { const int r_ = slice_b_ok(a) ? run_slice_b(c, a, SA) : run_pass(c, a); g_stage = 0; if (r_) return r_; }
+    { const int r_ = slice_b_ok(a) ? run_slice_b(c, a, SA) : slice_a_ok(a) ? run_slice_a(c, a, SA) : run_pass(c, a); g_stage = 0; if (r_) return r_; }
     if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
@@ -2638,7 +2705,7 @@ static int stats_drain() {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
         ms = (float)std::max(0.0, (double)ms - g_evt_overhead_ms);
-        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9) || r.kind == 12 || r.kind == 13) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
+        if (r.kind == 0 || (r.kind >= 2 && r.kind <= 9) || (r.kind >= 12 && r.kind <= 14)) { g_stats.sweep_i8_ms += ms; g_stats.sweep_i8_launches++; g_stats.sweep_i8_macs += r.macs; g_stats.sweep_i8_alg_macs += r.alg; }
         if (r.kind == 2) { g_stats.sweep6_ms += ms; g_stats.sweep6_launches++; g_stats.sweep6_macs += r.macs; g_stats.sweep6_alg_macs += r.alg; }
         if (r.kind == 3 || r.kind == 4) { g_stats.sweep7_ms += ms; g_stats.sweep7_launches++; g_stats.sweep7_macs += r.macs; g_stats.sweep7_alg_macs += r.alg; }
         if (r.kind == 4) { g_stats.sweep7_twin_ms += ms; g_stats.sweep7_twin_launches++; }

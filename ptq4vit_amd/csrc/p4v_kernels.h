@@ -1805,6 +1805,103 @@ __global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) {
     }
 }
 
+// k_slice_a: the same for a MatMul A search with K <= 64 (q.k^T): the EXPANDED operand is the 16-row slice itself -- a lane keeps
+// its 16 fp32 values of the slice in registers and re-quantises them per candidate (one fragment), the fixed operand B (int8,
+// packed once: [Z][NB * 16][64]) stays in registers as NB fragments.  One workgroup per (image, head), candidates dealt over
+// the four waves; replaces the slice's candidate planes + a k_sweep9 launch (78 -> ~30 us per pass).
+struct SliceAParams {
+    const float* A;                        // fp32 slice [Z][16][K] (dense)
+    const int8_t* B;                       // int8 plane [Z][NB * 16][64] of the fixed column operand
+    const float* ascale; int as_cs, as_div;                 // candidate scales: ascale[c * as_cs + z % as_div]
+    int lo, hi;
+    const float* S1; int s_cs, s_div;
+    const float* O; const float* Wt; int wt_mode;           // [Z][16][N]
+    int Z, M, K, N, C;
+    float* part;                                            // [C][Z]
+};
+template <int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int z = blockIdx.x;
+    const int nb = (p.N + 15) / 16;
+    const int per = (p.C + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * per, c_hi = min(p.C, c_lo + per);
+    float x[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = l4 * 16 + e;
+        x[e] = (l15 < p.M && k < p.K) ? p.A[((long)z * 16 + l15) * p.K + k] : 0.0f;
+    }
+    v4i_ fb[NBM];
+    float u[NBM][4], w[NBM][4];
+    const int wm = p.wt_mode;
+#pragma unroll
+    for (int j = 0; j < NBM; ++j) {
+        fb[j] = *reinterpret_cast<const v4i_*>(p.B + ((long)z * nb * 16 + min(j, nb - 1) * 16 + l15) * 64 + l4 * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = j * 16 + l15, m = 4 * l4 + e;
+            const bool ok = j < nb && n < p.N && m < p.M;
+            const long idx = ((long)z * 16 + min(m, 15)) * p.N + min(n, p.N - 1);
+            const float o = p.O[idx], gw = p.Wt[idx];
+            float wv;
+            if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+            u[j][e] = ok ? o : 0.0f;
+            w[j][e] = ok ? wv : 0.0f;
+        }
+    }
+    const int saz = p.as_div > 0 ? z % p.as_div : 0, ssz = p.s_div > 0 ? z % p.s_div : 0;
+    const float flo = (float)p.lo, fhi = (float)p.hi;
+    const bool wide = !(fmaxf(-flo, fhi) < 129.0f);
+    for (int c = c_lo + wid; c < c_hi; c += 4) {
+        const float s = p.ascale[(long)c * p.as_cs + saz];
+        const float rcp = 1.0f / s;
+        const float s1 = p.S1 ? p.S1[(long)c * p.s_cs + ssz] : 1.0f;
+        unsigned qb[16];
+        float maxdev = 0.0f, magic = PACK_MAGIC;
+        asm volatile("" : "+v"(magic));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qb[e] = quant_fast1(x[e], rcp, flo - 0.49f, fhi + 0.49f, magic, maxdev);
+        const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || wide;
+        if (__any(bad)) {
+            float sd = s;
+            asm volatile("" : "+v"(sd));
+            if (bad) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), flo), fhi) + PACK_MAGIC);
+            }
+        }
+        v4i_ fa;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
+            const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
+            fa[q] = (int)(lo16 | (hi16 << 16));
+        }
+        float sum = 0.0f;
+        const v4i_ zero4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) {
+            if (j < nb) {
+                const v4i_ acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb[j], zero4, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = u[j][e] - (float)acc[e] * s1;
+                    const float ww = w[j][e];
+                    if (EPI == EPI_SQ_W) { const float t2 = ww * d; sum = fmaf(t2, t2, sum); }
+                    else if (EPI == EPI_ABS) sum = fmaf(ww, fabsf(d), sum);
+                    else sum = fmaf(ww * d, d, sum);
+                }
+            }
+        }
+        sum = wave_sum_dpp(sum);
+        if (lane == 63) p.part[(long)c * p.Z + z] = sum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_sweep2g: k_sweep2 for LARGE K with two candidates per pass (weight search of fc2-like layers)
 // ------------------------------------------------------------------------------------------
