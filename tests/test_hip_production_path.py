@@ -324,3 +324,43 @@ def test_two_tier_pruning_is_exact_and_engages_on_a_spread_weight_profile(eng):
         assert torch.equal(two[k], full[k]) and torch.equal(one[k], full[k]) and torch.equal(chk[k], full[k])
     print(f"[production] two-tier pruning: first slice {share:.2f} of the weight; stages of the run: "
           f"{ {s: stages.count(s) for s in sorted(set(stages))} }")
+
+
+def test_stage_kernels_of_the_pruned_passes_are_the_ones_that_run(eng):
+    """The kernels built for the stages of a pruned pass -- k_bound (stage B1 of Linear passes), k_slice_a / k_slice_b (stage A of the
+    attention matmuls' A / B searches) -- are on the default path at ViT-B shapes (a silent fall-back to the sweep kernels would keep
+    every parity test green and only show in the bench), and the records carry their stage."""
+    g = torch.Generator().manual_seed(41)
+    b, H, S, D = 8, 12, 197, 64
+    runs = {}
+    x = torch.randn(b, S, 768, generator=g)
+    w = torch.randn(768, 768, generator=g) * 0.02
+    out = F.linear(x, w)
+    grad = vit_like_grad(out.shape, 1, g)
+    runs["linear"] = lambda: eng.linear_calibrate(weight=w.cuda(), bias=None, x=x.cuda(), out=out.cuda(), grad=grad.cuda(), w_bit=8, a_bit=8,
+                                                  n_V=1, n_H=1, n_a=1, search_round=1, **PTQ4VIT)
+    A = torch.randn(b, H, S, D, generator=g)
+    Bk = (torch.randn(b, H, S, D, generator=g)).cuda().transpose(-2, -1)
+    o1 = A.cuda() @ Bk
+    g1 = vit_like_grad(tuple(o1.shape), 2, g).cuda()
+    runs["qk"] = lambda: eng.matmul_calibrate(A=A.cuda(), B=Bk, out=o1, grad=g1, A_bit=8, B_bit=8, search_round=1, sos=False, **PTQ4VIT)
+    P = torch.softmax(torch.randn(b, H, S, S, generator=g) * 3.0, dim=-1).cuda()
+    V = torch.randn(b, H, S, D, generator=g).cuda()
+    o2 = P @ V
+    g2 = vit_like_grad(tuple(o2.shape), 2, g).cuda()
+    runs["sv"] = lambda: eng.matmul_calibrate(A=P, B=V, out=o2, grad=g2, A_bit=8, B_bit=8, search_round=1, sos=True, **PTQ4VIT)
+    seen = {}
+    for name, fn in runs.items():
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            eng.stats_get()
+            seen[name] = {(r["kernel"], r["stage"]) for r in eng.stats_launches()}
+        finally:
+            eng.stats_enable(False)
+    assert ("k_bound", "B1") in seen["linear"], seen["linear"]
+    assert ("k_slice_a", "A") in seen["qk"] and ("k_slice_b", "A") in seen["qk"], seen["qk"]
+    assert ("k_slice_b", "A") in seen["sv"], seen["sv"]
+    print(f"[production] stage kernels: {seen}")
