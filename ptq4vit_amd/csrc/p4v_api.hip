@@ -258,6 +258,7 @@ template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi
         case EPI_ABS: P4V_LAUNCH2(EPI_ABS); break;
         case EPI_FWD: P4V_LAUNCH2(EPI_FWD); break;
         case EPI_STORE: P4V_LAUNCH2(EPI_STORE); break;
+        case EPI_COS: P4V_LAUNCH2(EPI_COS); break;
         default: P4V_LAUNCH2(EPI_W_SQ); break;
     }
 #undef P4V_LAUNCH2
@@ -596,7 +597,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     } else
     if (fast && p.halves > 0) r = p.a_cs == 0 ? launch_sweep9_epi<true>(c, p, epi, cgroups) : launch_sweep9_epi<false>(c, p, epi, cgroups);
     else if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
-    else if (fast && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
+    else if (fast && epi != EPI_COS && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
     else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
     else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups);
     else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
@@ -606,7 +607,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
         if (fast && p.bound) rec.kind = 12;
         else if (fast && p.halves > 0) rec.kind = 6;
         else if (fast && sweep8_ok(p, twin, epi)) rec.kind = 7;
-        else if (fast && sweep2g_ok(p)) rec.kind = 8;
+        else if (fast && epi != EPI_COS && sweep2g_ok(p)) rec.kind = 8;
         else if (fast) rec.kind = 9;
         rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.bytes = g_alg_bytes;
         rec.gx = (fast && p.bound) ? p.mtiles * p.ntiles * 2 : (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles; rec.gz = cgroups;
@@ -828,6 +829,9 @@ int run_pass(Ctx& c, Pass& ps) {
     const bool fast = !stat_ok && !(ps.store_out && (g_variant & 4096)) && ps.i8 && !cosm && !(g_force_v1) &&
                       (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || ps.j_mode == 2 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0)));
+    // cosine on k_sweep2 (same stream and ring; three sums per sample and wave in k_sweep's table layout, k_finish_cos unchanged)
+    const bool fast_cos = cosm && !stat_ok && !big7 && ps.i8 && !ps.store_out && !g_force_v1 && tune(TUNE_B1_PATH) != 7 &&
+                          (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0);
     // k_sweep4 table: [slabs of 64 stationary rows][groups of 32 streaming rows]
     const bool a_search = ps.row.expanded;          // stationary = weights (col operand), streaming = activations
     const int s3_gw = 32;                           // streaming rows per wave (column group width of the table)
@@ -1020,13 +1024,13 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.dbg = g_variant & 3;
         sp.store = ps.store_out;
         int cgroups = 1;
-        if (!fast && !(g_variant & 8192)) {
+        if (!fast && !fast_cos && !(g_variant & 8192)) {
             // generic sweep: 2 workgroups per CU; per k-tile step ~2.6 us with fp32 operands (8 x mfma_f32_32x32x2 per
             // 32x32 block), ~1.6 us on the int8 grid (measured on the patch-embedding search)
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
             cgroups = choose_cgroups(wgs, nc, sp.ktiles, 512, 20.0, ps.i8 ? 1.6 : 2.6);
         }
-        if (fast) {
+        if (fast || fast_cos) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
                                         : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
@@ -1048,7 +1052,7 @@ int run_pass(Ctx& c, Pass& ps) {
             if (const int t_ = tune(sweep2g_ok(sp) ? TUNE_CG2G : TUNE_CG2); t_ > 0) cgroups = std::max(1, std::min(nc, t_));
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep2%s tiles %d x %d z %d ktiles %d cand %d twin %d -> cgroups %d\n", sweep2g_ok(sp) ? "g" : "", sp.mtiles, sp.ntiles, ps.Z, sp.ktiles, nc, (int)ps.twin, cgroups);
         }
-        CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast, cgroups));
+        CHK(launch_sweep(c, sp, ps.i8, ps.twin, ps.epi, fast || fast_cos, cgroups));
     }
     g_exec_frac = 1.0;
     if (ps.store_out) { c.ws.off = mark; return 0; }

@@ -892,7 +892,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     // of the operand stream and keep the barriers.  Waves w and w + 4 share a SIMD, so the parts WITH work are dealt to
     // wave ids 0, 1, 2, ... first: they spread over the four SIMDs instead of leaving whole SIMDs to the padding.
     int pos = wid;
-    constexpr bool SKIP = !(EPI == EPI_FWD || EPI == EPI_STORE);     // (the one-candidate store passes: not worth their registers)
+    // (the one-candidate store passes: not worth their registers; cosine: every part writes its three sums per sample)
+    constexpr bool SKIP = !(EPI == EPI_FWD || EPI == EPI_STORE || EPI == EPI_COS);
     if constexpr (SKIP) {
         auto useful = [&](int q) { return (n0 + (q & 3) * 32 < p.N) && (m0 + (q >> 2) * 64 < p.M); };
         int cnt = 0, found = -1;
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int n = n0 + wc * 32 + l31;
     const bool ncol_ok = n < p.N;
     const float* biasz = p.bias ? p.bias + (long)z * p.bias_zs : nullptr;
-    const float bias_n = (biasz && ncol_ok) ? biasz[n] : 0.0f;
+    const float bias_n = (biasz && ncol_ok && p.bias_axis == 0) ? biasz[n] : 0.0f;
     constexpr bool STORES = (EPI == EPI_FWD || EPI == EPI_STORE);   // no metric: the tile itself is written out
     if constexpr (EPI != EPI_FWD) {
         // Phase 1: every load of the raw_out / weight tile issued back to back at clamped (always valid) addresses.
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                 w[i][r] = p.Wt[idx];   // host passes Wt = O when the metric has no weight tensor
             }
         // Phase 2: pure ALU; the metric switch is hoisted out of the element loops
-        const int wm = p.wt_mode;
+        const int wm = EPI == EPI_COS ? 4 : p.wt_mode;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -939,11 +940,23 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                 const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 const bool ok = ncol_ok && m < p.M;
                 const float o = u[i][r], gw = w[i][r];
-                float ov = o - bias_n, wv;
+                float ov = o - (EPI == EPI_COS ? 0.0f : bias_n), wv;
                 if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
                 u[i][r] = ok ? ov : 0.0f;
                 w[i][r] = ok ? wv : 0.0f;
             }
+        if (EPI == EPI_COS) {
+            // cosine (as in k_sweep): u keeps the raw output, w carries the bias of the simulated output (0 on padding)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const bool ok = ncol_ok && m < p.M;
+                    const float braw = (biasz && p.bias_axis) ? biasz[min(m, p.M - 1)] : bias_n;
+                    w[i][r] = (ok && biasz) ? braw : 0.0f;
+                }
+        }
     }
     // wave-uniform scale block of this wave's 32 columns (host guarantees they share one block)
     const int nw0 = n0 + wc * 32;
@@ -1077,6 +1090,35 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                 ++c;
                 return;
             }
+            if constexpr (EPI == EPI_COS) {
+                // cosine: the MFMA rows are the feature axis the cosine reduces over, the columns are samples.  Per sample the
+                // partial dot(o, o_sim), |o_sim|^2, |o|^2 over this wave's 64 features, in k_sweep's order and table layout
+                // (k_finish_cos unchanged).  The three stores per candidate ride in the same vmcnt queue as the operand stream:
+                // the counted waits of the ring then wait for MORE than they need, never for less.
+                float dot = 0.0f, nn = 0.0f, oo = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o_sim = fmaf((float)acc[i][r], s1, w[i][r]);
+                        if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
+                        dot = fmaf(u[i][r], o_sim, dot);
+                        nn = fmaf(o_sim, o_sim, nn);
+                        oo = fmaf(u[i][r], u[i][r], oo);
+                        acc[i][r] = 0;
+                        if (TWIN) acc2[i][r] = 0;
+                    }
+                dot += __shfl_xor(dot, 32);
+                nn += __shfl_xor(nn, 32);
+                oo += __shfl_xor(oo, 32);
+                if (g == 0) {
+                    float* q = p.part + (long)c * p.p_cs + (long)z * p.p_zs + ((long)(mt * 2 + wr) * p.Np + n0 + wc * 32 + l31) * 3;
+                    q[0] = dot; q[1] = nn; q[2] = oo;
+                }
+                kt = 0;
+                ++c;
+                return;
+            }
             // ---- fused similarity epilogue of candidate c: one float per wave ---------------------------
             v2f sum2 = {0.0f, 0.0f};
 #pragma unroll
@@ -1115,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     }
 #undef P4V_DSR
     __syncthreads();
-    if constexpr (STORES) return;
+    if constexpr (STORES || EPI == EPI_COS) return;
     // ---- one coalesced write of this workgroup's results: part[c][z][mt*2+wr][nt*4+wc] -----------------
     for (int i = tid; i < (c_hi - c_lo) * 8; i += 512) {
         const int cc = c_lo + i / 8, wv = i % 8;
