@@ -393,6 +393,12 @@ int p4v_debug_set_variant(int variant, int force_generic);
 /* Overrides of launch heuristics: key 0 / 1 / 2 / 3 = candidate groups of k_sweep6 / k_sweep2 / k_sweep2g / k_sweep7
  * (0 = cost model), key 4 = print the launch plans to stderr, key 5 = workgroup order of k_sweep7 + 1. */
 int p4v_debug_set_tuning(int key, int value);
+/* The row selection of the exact pruning alone (k_topk_rows; csrc/p4v_api.hip::slice_fill runs it on the per-sample metric
+ * weight): for each of `segs` segments of `n` fp32 masses, d_mass [segs][n], the segment-local indices of the k heaviest
+ * entries in ASCENDING index order, d_idx [segs][k]; among equal masses the lowest indices are taken; negative masses
+ * count as the lightest.  Exposed for the tests: a repeated or missing row would make the slice's partial sums an
+ * invalid bound.  1 <= k <= n. */
+int p4v_debug_topk_rows(const float* d_mass, int segs, int n, int k, int32_t* d_idx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ EXPORTS = [
     "p4v_score_argmax_gather",
     "p4v_quantize_i8", "p4v_pack_plane_i8", "p4v_fake_quant", "p4v_export_quantize", "p4v_multi_copy",
     "p4v_stats_enable", "p4v_stats_reset", "p4v_stats_get", "p4v_stats_launches", "p4v_prune_counters",
-    "p4v_debug_set_variant", "p4v_debug_set_tuning",
+    "p4v_debug_set_variant", "p4v_debug_set_tuning", "p4v_debug_topk_rows",
 ]
 
 _lib = None
@@ -158,6 +158,8 @@ def load():
     lib.p4v_export_quantize.argtypes = [C.POINTER(ExportDesc), fp, fp, fp, vp, vp]
     lib.p4v_multi_copy.restype = C.c_int
     lib.p4v_multi_copy.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp]
+    lib.p4v_debug_topk_rows.restype = C.c_int
+    lib.p4v_debug_topk_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.p4v_debug_set_variant.restype = C.c_int
     lib.p4v_debug_set_variant.argtypes = [C.c_int, C.c_int]
     lib.p4v_debug_set_tuning.restype = C.c_int

@@ -2770,6 +2770,13 @@ int p4v_debug_set_tuning(int key, int value) {
     return 0;
 }
 
+int p4v_debug_topk_rows(const float* d_mass, int segs, int n, int k, int32_t* d_idx, void* stream) {
+    if (!d_mass || !d_idx || segs <= 0 || n <= 0 || k <= 0 || k > n) return fail(P4V_ERR_INVALID, "p4v_debug_topk_rows: bad argument");
+    hipLaunchKernelGGL(k_topk_rows, dim3(segs), dim3(1024), 0, (hipStream_t)stream, d_mass, n, k, d_idx);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_scales, int8_t* d_q, void* stream) {
     if (!d || !d_x || !d_q || d->rows <= 0 || d->cols <= 0 || d->cols_padded % 64 || d->cols_padded < d->cols)
         return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: bad argument");

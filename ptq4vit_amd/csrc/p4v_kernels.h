@@ -958,6 +958,15 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                 }
         }
     }
+    // cosine: |o|^2 of this lane's 32 outputs does not depend on the candidate (same order of additions as the per-candidate sum)
+    float oo_fix = 0.0f;
+    if constexpr (EPI == EPI_COS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oo_fix = fmaf(u[i][r], u[i][r], oo_fix);
+        oo_fix += __shfl_xor(oo_fix, 32);
+    }
     // wave-uniform scale block of this wave's 32 columns (host guarantees they share one block)
     const int nw0 = n0 + wc * 32;
     const int sb = __builtin_amdgcn_readfirstlane(p.sb_mode == 1 ? min(nw0 / p.sb_div, p.s_cs - 1) : p.sb_mode == 2 ? z % p.sb_div : 0);
@@ -1095,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                 // partial dot(o, o_sim), |o_sim|^2, |o|^2 over this wave's 64 features, in k_sweep's order and table layout
                 // (k_finish_cos unchanged).  The three stores per candidate ride in the same vmcnt queue as the operand stream:
                 // the counted waits of the ring then wait for MORE than they need, never for less.
-                float dot = 0.0f, nn = 0.0f, oo = 0.0f;
+                float dot = 0.0f, nn = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1104,13 +1113,12 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
                         if (TWIN) o_sim = fmaf((float)acc2[i][r], s2, o_sim);
                         dot = fmaf(u[i][r], o_sim, dot);
                         nn = fmaf(o_sim, o_sim, nn);
-                        oo = fmaf(u[i][r], u[i][r], oo);
                         acc[i][r] = 0;
                         if (TWIN) acc2[i][r] = 0;
                     }
                 dot += __shfl_xor(dot, 32);
                 nn += __shfl_xor(nn, 32);
-                oo += __shfl_xor(oo, 32);
+                const float oo = oo_fix;
                 if (g == 0) {
                     float* q = p.part + (long)c * p.p_cs + (long)z * p.p_zs + ((long)(mt * 2 + wr) * p.Np + n0 + wc * 32 + l31) * 3;
                     q[0] = dot; q[1] = nn; q[2] = oo;
@@ -3904,67 +3912,79 @@ __global__ void k_group_mass(const float* mass, int n_groups, int group, float* 
     out[g] = s;
 }
 __global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n, int k, int* idx_all) {
-    // one workgroup per segment (matmul: the rows of one (image, head); Linear: a single segment); indices are segment-local
+    // one workgroup per segment (matmul: the rows of one (image, head); Linear: a single segment); indices are segment-local.
+    // Radix select, one byte of the key per pass (256-bin histogram in the LDS, a wave whose keys share the digit adds its count
+    // once), then an ordered compaction with wave ballots: 4 + 1 passes over the masses and one barrier per 1024 rows
+    // (round 3: 32 one-bit passes and a 10-step scan per 1024 rows -- 50 us for the 6304 samples of a ViT-B Linear, 1-5 ms for
+    // the 1.2 M samples of a Swin stage-1 Linear).
     const float* mass = mass_all + (long)blockIdx.x * n;
     int* idx = idx_all + (long)blockIdx.x * k;
-    __shared__ int cnt[1024];
+    __shared__ int hist[256];
+    __shared__ int wtot[4];
+    __shared__ int wg[2][16], we[2][16];
     __shared__ unsigned prefix_s;
-    __shared__ int base_s, gt_s;
-    const int t = threadIdx.x;
+    __shared__ int krem_s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     auto key = [&](int i) -> unsigned { const unsigned b = __float_as_uint(mass[i]); return (b & 0x80000000u) ? 0u : b; };   // negative / -0: lightest
-    auto block_sum = [&](int v) -> int {
-        cnt[t] = v;
+    if (t == 0) { prefix_s = 0; krem_s = k; }
+    for (int shift = 24; shift >= 0; shift -= 8) {       // the k-th largest key, a byte at a time
+        if (t < 256) hist[t] = 0;
         __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) { if (t < o) cnt[t] += cnt[t + o]; __syncthreads(); }
-        const int r = cnt[0];
+        const unsigned hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        const unsigned pre = prefix_s;
+        const int kr = krem_s;
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + t;
+            const unsigned kv = i < n ? key(i) : 0u;
+            const bool in = i < n && (kv & hi_mask) == pre;
+            const int d = (int)((kv >> shift) & 255u);
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                const int d0 = __shfl(d, __ffsll((long long)m) - 1);
+                if (__ballot(in && d != d0) == 0ull) { if (lane == __ffsll((long long)m) - 1) atomicAdd(&hist[d0], __popcll(m)); }
+                else if (in) atomicAdd(&hist[d], 1);
+            }
+        }
         __syncthreads();
-        return r;
-    };
-    if (t == 0) prefix_s = 0;
-    __syncthreads();
-    for (int bit = 31; bit >= 0; --bit) {          // largest T with count(key >= T) >= k
-        const unsigned cand = prefix_s | (1u << bit);
-        int c = 0;
-        for (int i = t; i < n; i += 1024) c += key(i) >= cand;
-        const int tot = block_sum(c);
-        if (t == 0 && tot >= k) prefix_s = cand;
+        // suffix sums over the bins (threads 0..255): bin b holds the kr-th largest iff  count(bins > b) < kr <= count(bins >= b)
+        const int h = t < 256 ? hist[t] : 0;
+        int sfx = h;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(sfx, o); if (lane + o < 64) sfx += v; }
+        if (t < 256 && lane == 0) wtot[wv] = sfx;
+        __syncthreads();
+        if (t < 256) {
+            int above = 0;
+            for (int q = wv + 1; q < 4; ++q) above += wtot[q];
+            const int incl = sfx + above, excl = incl - h;
+            if (excl < kr && kr <= incl) { prefix_s = pre | ((unsigned)t << shift); krem_s = kr - excl; }
+        }
         __syncthreads();
     }
     const unsigned T = prefix_s;
-    int c = 0;
-    for (int i = t; i < n; i += 1024) c += key(i) > T;
-    const int n_gt = block_sum(c);
-    if (t == 0) { base_s = 0; gt_s = 0; }
-    __syncthreads();
+    const int eq_want = krem_s;                          // rows AT the threshold to take (the first ones by index); k - eq_want rows are above it
     // ordered compaction, 1024 rows at a time: rows above the threshold, and rows AT it until k are taken
-    for (int i0 = 0; i0 < n; i0 += 1024) {
+    int base = 0, eq_taken = 0;
+    for (int i0 = 0, it = 0; i0 < n; i0 += 1024, ++it) {
         const int i = i0 + t;
         const unsigned kv = i < n ? key(i) : 0u;
-        const int is_gt = i < n && kv > T, is_eq = i < n && kv == T;
-        // exclusive scans of the two flags
-        cnt[t] = is_gt | (is_eq << 16);
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = t >= o ? cnt[t - o] : 0;
-            __syncthreads();
-            cnt[t] += v;
-            __syncthreads();
+        const bool is_gt = i < n && kv > T, is_eq = i < n && kv == T;
+        const unsigned long long bg = __ballot(is_gt), be = __ballot(is_eq);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) { wg[it & 1][wv] = __popcll(bg); we[it & 1][wv] = __popcll(be); }
+        __syncthreads();                                 // (one barrier per chunk: the tables alternate)
+        int gt_before = __popcll(bg & below), eq_before = __popcll(be & below), gt_tot = 0, eq_tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int a_ = wg[it & 1][q], b_ = we[it & 1][q];
+            if (q < wv) { gt_before += a_; eq_before += b_; }
+            gt_tot += a_; eq_tot += b_;
         }
-        const int incl = cnt[t], tot = cnt[1023];
-        const int gt_before = (incl & 0xffff) - is_gt, eq_before = (incl >> 16) - is_eq;
-        const int eq_taken_before = gt_s;            // equal-to-threshold rows taken in earlier chunks
-        const int eq_room = (k - n_gt) - eq_taken_before;
+        const int eq_room = max(eq_want - eq_taken, 0);
         const bool take = is_gt || (is_eq && eq_before < eq_room);
-        const int eq_taken_here_before = min(eq_before, max(eq_room, 0));
-        if (take) idx[base_s + gt_before + eq_taken_here_before] = i;
-        __syncthreads();
-        if (t == 0) {
-            const int eq_tot = tot >> 16, gt_tot = tot & 0xffff;
-            const int eq_take = min(eq_tot, max(eq_room, 0));
-            base_s += gt_tot + eq_take;
-            gt_s += eq_take;
-        }
-        __syncthreads();
+        if (take) idx[base + gt_before + min(eq_before, eq_room)] = i;
+        const int eq_take = min(eq_tot, eq_room);
+        base += gt_tot + eq_take;
+        eq_taken += eq_take;
     }
 }
 // dst[r][a][b][c] = src[seg_off(r / seg) + idx[r] * s0 + a * s1 + b * s2 + c * s3]; seg = rows per segment (0: one segment),

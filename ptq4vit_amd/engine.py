@@ -527,6 +527,18 @@ def debug_tuning(key, value):
     _lib.check(_lib.load().p4v_debug_set_tuning(int(key), int(value)), "p4v_debug_set_tuning")
 
 
+def debug_topk_rows(mass, k):
+    """Row selection of the exact pruning (k_topk_rows) on `mass` [segs, n] fp32: int32 [segs, k], the segment-local indices
+    of the k heaviest entries in ascending order (ties: lowest indices).  For the tests."""
+    assert mass.is_cuda and mass.dtype == torch.float32 and mass.dim() == 2 and mass.is_contiguous()
+    segs, n = mass.shape
+    out = torch.empty(segs, int(k), dtype=torch.int32, device=mass.device)
+    with torch.cuda.device(mass.device):
+        rc = _lib.load().p4v_debug_topk_rows(ptr(mass), segs, n, int(k), ptr(out), stream_ptr(mass.device))
+    _lib.check(rc, "p4v_debug_topk_rows")
+    return out
+
+
 def stats_reset():
     _lib.load().p4v_stats_reset()
 

@@ -378,3 +378,52 @@ def test_stage_kernels_of_the_pruned_passes_are_the_ones_that_run(eng):
     assert ("k_slice_a", "A") in seen["qk"] and ("k_slice_b", "A") in seen["qk"], seen["qk"]
     assert ("k_slice_b", "A") in seen["sv"], seen["sv"]
     print(f"[production] stage kernels: {seen}")
+
+
+# ---- the row selection of the slices (k_topk_rows): exactly the k heaviest rows, each once --------------------------------------
+def _topk_reference(mass, k):
+    """indices of the k largest entries, ties to the lowest index, ascending; negative / -0.0 masses rank as the lightest"""
+    key = mass.detach().cpu().double().clone()
+    bits = mass.detach().cpu().view(torch.int32)
+    key[bits < 0] = 0.0                                   # sign bit set: lightest (key 0)
+    key[torch.isnan(mass.cpu())] = float("inf")           # (positive NaN bit patterns sort above every finite mass)
+    out = []
+    for row in key:
+        order = sorted(range(row.numel()), key=lambda i: (-row[i].item(), i))[:k]
+        out.append(sorted(order))
+    return torch.tensor(out, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("segs,n,k,kind", [(1, 6304, 512, "lognormal"), (1, 6304, 128, "ties"), (1, 1000, 999, "lognormal"), (1, 300, 1, "lognormal"),
+                                           (384, 197, 16, "cls"), (7, 1025, 256, "ties"), (1, 70000, 1280, "lognormal"), (1, 4096, 256, "zeros"),
+                                           (3, 5000, 320, "negatives"), (1, 1200000, 4864, "lognormal"), (1, 2048, 2048, "lognormal")])
+def test_row_selection_takes_exactly_the_heaviest_rows_once(eng, segs, n, k, kind):
+    g = torch.Generator().manual_seed(segs * 1000 + n + k)
+    if kind == "lognormal":
+        m = torch.exp(4.0 * torch.randn(segs, n, generator=g)) * 1e-18
+    elif kind == "ties":
+        m = torch.randint(0, 6, (segs, n), generator=g).float() * 0.37          # many equal masses around the threshold
+    elif kind == "cls":
+        m = torch.rand(segs, n, generator=g) * 1e-22
+        m[:, 0] = 3e-17                                                         # one class-token row per segment
+    elif kind == "zeros":
+        m = torch.zeros(segs, n)
+        m[0, torch.randperm(n, generator=g)[:100]] = torch.rand(100, generator=g)    # fewer non-zero rows than k
+    else:
+        m = torch.randn(segs, n, generator=g)                                    # signed: negative masses are the lightest
+        m[:, ::7] = -0.0
+    idx = eng.debug_topk_rows(m.cuda().contiguous(), k).cpu()
+    assert idx.shape == (segs, k)
+    assert bool((idx[:, 1:] > idx[:, :-1]).all()) or k == 1, "indices must be strictly ascending (no row twice)"
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    if n <= 70000:
+        ref = _topk_reference(m, k)
+        assert torch.equal(idx, ref)
+    else:                                                 # large segment: the set is checked through its threshold
+        key = m.clone()
+        key[m.view(torch.int32) < 0] = 0.0
+        sel = torch.zeros(segs, n, dtype=torch.bool)
+        sel.scatter_(1, idx.long(), True)
+        for s_ in range(segs):
+            inside, outside = key[s_][sel[s_]], key[s_][~sel[s_]]
+            assert inside.numel() == k and float(inside.min()) >= float(outside.max())
