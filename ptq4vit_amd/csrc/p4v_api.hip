@@ -626,7 +626,7 @@ int launch_finish(Ctx& c, const FinishParams& p) {
 int launch_finish_cos(Ctx& c, const FinishCosParams& p) {
     if (c.dry) return 0;
     const int gy = p.j_mode == 3 ? cdiv(p.S, 256) : p.nj;
-    hipLaunchKernelGGL(k_finish_cos, dim3(p.C, gy), dim3(256), 0, c.st, p);
+    hipLaunchKernelGGL(k_finish_cos, dim3(p.C, gy), dim3(p.j_mode == 3 ? 256 : 1024), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -3837,12 +3837,14 @@ __device__ __forceinline__ float cos_item(const FinishCosParams& p, int c, int z
     const float na = fmaxf(sqrtf(oo), 1e-8f), nb = fmaxf(sqrtf(nn), 1e-8f);
     return dot / (na * nb);
 }
-__global__ __launch_bounds__(256) void k_finish_cos(FinishCosParams p) {
-    const int c = blockIdx.x, j = blockIdx.y;
+__global__ __launch_bounds__(1024) void k_finish_cos(FinishCosParams p) {
+    // block size: 256 for j_mode 3 (thread = sample), 1024 otherwise (one workgroup per (candidate, score block) reads the
+    // candidate's whole table -- 92 MB per pass for a ViT-B proj layer, 370 MB for fc1: 16 waves keep enough loads in flight)
+    const int c = blockIdx.x, j = blockIdx.y, nt = blockDim.x;
     double acc = 0.0;
     if (p.j_mode == 3) {
-        // one workgroup per (candidate, chunk of 256 samples): thread = sample, serial over zb
-        const int smp = j * 256 + threadIdx.x;
+        // one workgroup per (candidate, chunk of samples): thread = sample, serial over zb
+        const int smp = j * nt + threadIdx.x;
         if (smp < p.S) {
             for (int zb = 0; zb < p.ZB; ++zb) acc += (double)cos_item(p, c, zb, 0, p.ZV, smp);
             p.scores[(long)c * p.nj + smp] = (float)(p.norm * acc);
@@ -3854,15 +3856,15 @@ __global__ __launch_bounds__(256) void k_finish_cos(FinishCosParams p) {
     if (p.j_mode == 2) { zlo = j; zstep = p.j_div; }
     const int nz = (p.ZB - zlo + zstep - 1) / zstep;
     const long total = (long)nz * p.S;
-    for (long i = threadIdx.x; i < total; i += 256) {
+    for (long i = threadIdx.x; i < total; i += nt) {
         const int smp = (int)(i % p.S);
         const int zb = zlo + (int)(i / p.S) * zstep;
         acc += (double)cos_item(p, c, zb, zv0, zv1, smp);
     }
-    __shared__ double red[256];
+    __shared__ double red[1024];
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = nt >> 1; o > 0; o >>= 1) {
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="p4v_debug_set_variant word (kernel A/B switches)")
     ap.add_argument("--tune", default="", help="key=value,... launch-heuristic overrides (p4v_debug_set_tuning)")
+    ap.add_argument("--metric", default="hessian", help="similarity metric (hessian, cosine, L2_norm, ...)")
     ap.add_argument("--kernel-stats", action="store_true", help="per-launch time of the sweep kernels (HIP events)")
     a = ap.parse_args()
     if "," in a.layer:
@@ -45,7 +46,7 @@ def main():
 def one(a):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
-    hp = dict(metric="hessian", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
+    hp = dict(metric=a.metric, eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=a.rounds)
     engine.debug_variant(a.variant)
     for kv in filter(None, a.tune.split(",")):
         k, v = kv.split("=")
