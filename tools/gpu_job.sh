@@ -26,7 +26,7 @@ for step in "$@"; do
                tag=$(echo $pass | cut -d' ' -f1)
                ( cd /tmp && timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $T/pmc_$tag -o p -- python $R/bench.py --profile --steps 1 --warmup 1 --no-roofline > $T/pmc_$tag.log 2>&1 )
                f=$(find $T/pmc_$tag -name "*counter_collection.csv" | head -1)
-               [ -n "$f" ] && { head -1 $f > $T/$tag.csv; grep -E "k_sweep|k_sos" $f >> $T/$tag.csv; } || echo "no counter csv for $tag: $(tail -2 $T/pmc_$tag.log)"
+               [ -n "$f" ] && { head -1 $f > $T/$tag.csv; grep -E "k_sweep|k_sos|k_bound|k_slice" $f >> $T/$tag.csv; } || echo "no counter csv for $tag: $(tail -2 $T/pmc_$tag.log)"
              done
              python tools/prof_join.py --launches $T/launches.json --trace "$T/trace/*.db" --fetch $T/FETCH_SIZE.csv --write $T/WRITE_SIZE.csv \
                     --counters $T/TCC_HIT_sum.csv $T/SQ_VALU_MFMA_BUSY_CYCLES.csv --out $O/$stem 2>&1 | cut -c1-200 | tee $O/prodprof.log
