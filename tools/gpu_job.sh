@@ -13,11 +13,11 @@ for step in "$@"; do
              else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/tests.log; fi ;;
     bench)   timeout 900 python bench.py --steps ${arg:-10} --warmup 3 > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
              tail -1 $O/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], d.get('breakdown'), d.get('first_calibration_s')); print({k:(v['launches'], round(v['ms'],1), round(v['frac'],3), {s:(q['launches'], round(q['avg_launch_ms']*1e3,1), round(q['frac'],3)) for s,q in v['by_stage'].items()}) for k,v in r.get('by_kernel',{}).items() if v}, r.get('all_int8_sweeps',{}).get('frac'), r.get('whole_search'), (d.get('cpu_baseline') or {}).get('value'))" ;;
-    kstats1|kstats3)
+    kstats1|kstats3|kstats4)
              n=${name#kstats}
              ( cd /tmp && P4V_SEARCH_STREAMS=$n timeout 600 rocprofv3 --kernel-trace -d $O/prof$n -o b -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 )
              python tools/kstats_db.py "$O/prof$n/*.db" > $O/bench_${n}stream_kernel_stats.txt
-             [ $n = 3 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
+             [ $n != 1 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
              head -24 $O/bench_${n}stream_kernel_stats.txt | cut -c1-180; rm -rf $O/prof$n ;;
     prodprof) # profile of the production step, joined with the engine's launch records (tools/prof_join.py); arg = output stem
              stem=${arg:-r4_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
