@@ -74,14 +74,24 @@ def counter_rows(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--launches", required=True)
-    ap.add_argument("--trace", required=True, help="glob of the rocpd databases of the kernel-trace run")
+    ap.add_argument("--rerender", default=None, help="an existing <out>.json: recompute the derived fields and rewrite json + txt (no inputs needed)")
+    ap.add_argument("--launches", default=None)
+    ap.add_argument("--trace", default=None, help="glob of the rocpd databases of the kernel-trace run")
     ap.add_argument("--fetch", default=None, help="counter csv of the FETCH_SIZE pass")
     ap.add_argument("--write", default=None, help="counter csv of the WRITE_SIZE pass")
     ap.add_argument("--counters", nargs="*", default=[], help="more counter csvs (any counters: per-launch means are reported)")
-    ap.add_argument("--out", required=True)
+    ap.add_argument("--out", default=None)
     ap.add_argument("--note", default="")
     a = ap.parse_args()
+    if a.rerender:
+        out = json.load(open(a.rerender))
+        derive(out)
+        json.dump(out, open(a.rerender, "w"), indent=1)
+        render(out, [], a.rerender[:-5] + ".txt")
+        print(open(a.rerender[:-5] + ".txt").read())
+        return 0
+    if not (a.launches and a.trace and a.out):
+        ap.error("--launches, --trace and --out are required (or --rerender)")
 
     L = json.load(open(a.launches))
     recs = L["launches"]
@@ -188,25 +198,51 @@ def main():
             h, m = c["TCC_HIT_sum"]["mean_per_launch"], c["TCC_MISS_sum"]["mean_per_launch"]
             k["l2_hit_rate"] = h / max(1.0, h + m)
 
+    derive(out)
     json.dump(out, open(a.out + ".json", "w"), indent=1)
-    with open(a.out + ".txt", "w") as fh:
+    render(out, lines, a.out + ".txt")
+    print(open(a.out + ".txt").read())
+
+
+SIMDS, SPEC_GHZ = 1024, 2.4
+
+
+def derive(out):
+    """Matrix-pipe occupancy from the SQ counters, where collected: SQ_VALU_MFMA_BUSY_CYCLES sums the cycles every SIMD's MFMA
+    pipe was busy (32 per v_mfma_i32_32x32x32_i8, MI355X_MICROARCH.md) -> busy cycles per SIMD / the launch's cycles at the
+    2.4 GHz spec clock (the clock `peak` is quoted at; under MFMA load the part sustains ~1.93 GHz, tools/ubench_mfma.hip:
+    4044 of 5033 TOP/s, so the pipe is busy for a larger share of the REAL cycles)."""
+    for k in out["kernels"].values():
+        for d in [k] + list(k.get("by_stage", {}).values()):
+            c = d.get("counters", {})
+            v = c.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            if v is None:
+                continue
+            busy = v["mean_per_launch"] if isinstance(v, dict) else v
+            d["mfma_busy_of_spec_cycles"] = busy / SIMDS / (d["avg_launch_ms"] * 1e6 * SPEC_GHZ)
+
+
+def render(out, lines, path):
+    with open(path, "w") as fh:
         fh.write(out["note"] + "\n")
         fh.write(f"{'kernel family / stage':28s} {'launches':>8s} {'avg us':>9s} {'(events)':>9s} {'ms/calib':>9s} {'GOP/launch':>11s} {'TOP/s':>8s} {'frac':>6s} "
-                 f"{'alg MB':>8s} {'traffic MB':>10s}\n")
+                 f"{'alg MB':>8s} {'traffic MB':>10s} {'MFMA busy':>9s}\n")
         for fam, k in out["kernels"].items():
             def row(label, d):
                 tr = d.get("traffic_bytes_per_launch")
+                mb = d.get("mfma_busy_of_spec_cycles")
                 fh.write(f"{label:28s} {d['launches_per_calibration']:8d} {d['avg_launch_ms'] * 1e3:9.1f} {d['hip_event_avg_launch_ms'] * 1e3:9.1f} "
                          f"{d['ms_per_calibration']:9.2f} {d['ops_per_launch'] / 1e9:11.1f} {d['achieved']:8.1f} {d['frac']:6.3f} "
-                         f"{d['algorithmic_bytes_per_launch'] / 1e6:8.1f} {(tr / 1e6 if tr is not None else float('nan')):10.1f}\n")
+                         f"{d['algorithmic_bytes_per_launch'] / 1e6:8.1f} {(tr / 1e6 if tr is not None else float('nan')):10.1f} "
+                         f"{(f'{mb:9.3f}' if mb is not None else '        -')}\n")
             row(fam, k)
             for st, sd in k["by_stage"].items():
                 row(f"    stage {st}", sd)
+        fh.write("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (launch duration x 2.4 GHz spec clock): occupancy of the matrix pipes, any dtype; '-' = counter not collected\n")
         for fam, j in out["join"].items():
             fh.write(f"join {fam}: {j}\n")
         for ln in lines:
             fh.write(ln + "\n")
-    print(open(a.out + ".txt").read())
 
 
 if __name__ == "__main__":
