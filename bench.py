@@ -486,7 +486,9 @@ def main():
                     "profile": None if not pk else {"source": prof["source"], "launches_per_calibration": pk.get("launches_per_calibration"),
                                                      "avg_launch_ms": pk.get("avg_launch_ms"), "frac": pk.get("frac"),
                                                      "traffic_bytes_per_launch": pk.get("traffic_bytes_per_launch"),
-                                                     "algorithmic_bytes_per_launch": pk.get("algorithmic_bytes_per_launch")}}
+                                                     "algorithmic_bytes_per_launch": pk.get("algorithmic_bytes_per_launch"),
+                                                     # SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / launch cycles at 2.4 GHz (PMC pass)
+                                                     "mfma_busy_of_spec_cycles": pk.get("mfma_busy_of_spec_cycles")}}
 
     # ---- untimed extras (not part of `value`) ---------------------------------------------------------------------------
     fresh_s = qf = None
