@@ -726,3 +726,49 @@ def test_candidate_pruning_is_exact_matmul(eng, kind, b, H, S, D, bit, metric):
             if pruned[k] is not None:
                 assert torch.equal(pruned[k], full[k]), f"pruned search selected another {what}"
                 assert torch.equal(auto[k], full[k]), f"adaptive search selected another {what}"
+
+
+# ------------------------------------------------------------------------------------------------
+# cosine on the LDS-DMA sweep (k_sweep2<., EPI_COS>) == cosine on the generic kernel, bit for bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(kind="linear", b=5, T=61, K=200, N=390, n_V=3, bit=8),
+    dict(kind="linear", b=2, T=197, K=768, N=3072, n_V=1, bit=8),       # ViT-B fc1 at 2 images
+    dict(kind="linear", b=2, T=197, K=3072, N=768, n_V=1, bit=6),       # ViT-B fc2 geometry (BasePTQ: no twin)
+    dict(kind="qk", b=2, H=6, S=197, D=64, bit=8),
+], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_cosine_on_the_fast_sweep_is_bit_identical_to_the_generic_kernel(eng, cfg):
+    """The same three sums per sample and 64-feature slab, accumulated in the same order, reduced by the same k_finish_cos: the
+    score tables of every pass and the intervals must agree exactly (p4v_debug_set_tuning(12, 7) keeps the generic kernel)."""
+    hp = dict(metric="cosine", eq_alpha=0.01, eq_beta=1.2, eq_n=100, search_round=2)
+    if cfg["kind"] == "linear":
+        w, bias, x, out, grad = _mk_linear(11, cfg["b"], cfg["T"], cfg["K"], cfg["N"])
+        run = lambda: eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), postgelu=False, n_H=1, n_a=1,
+                                           n_V=cfg["n_V"], w_bit=cfg["bit"], a_bit=cfg["bit"], want_scores=True, **hp)
+    else:
+        rng = np.random.default_rng(5)
+        A = rng.standard_normal((cfg["b"], cfg["H"], cfg["S"], cfg["D"])).astype(np.float32)
+        B = rng.standard_normal((cfg["b"], cfg["H"], cfg["D"], cfg["S"])).astype(np.float32)
+        out = A @ B
+        grad = (rng.standard_normal(out.shape) * 1e-3).astype(np.float32)
+        run = lambda: eng.matmul_calibrate(A=_t(A), B=_t(B), out=_t(out), grad=_t(grad), sos=False, A_bit=cfg["bit"], B_bit=cfg["bit"],
+                                           want_scores=True, **hp)
+    def kinds(fn):
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+            return res, {r["kernel"] for r in eng.stats_launches()}
+        finally:
+            eng.stats_enable(False)
+    fast, k_fast = kinds(run)
+    try:
+        eng.debug_tuning(12, 7)
+        generic, k_gen = kinds(run)
+    finally:
+        eng.debug_tuning(12, 0)
+    assert k_fast == {"k_sweep2"} and k_gen == {"k_sweep<int8>"}, (k_fast, k_gen)
+    for a, g_ in zip(fast, generic):
+        if a is not None:
+            assert torch.equal(a, g_)
