@@ -58,6 +58,17 @@ def test_prof_join_joins_trace_and_counters_with_the_launch_records(tmp_path):
     assert abs(k6["by_stage"]["B2"]["traffic_bytes_per_launch"] - (2 * 70e6 + 10 * 1024)) < 1.0
     assert abs(kb["traffic_bytes_per_launch"] - (2 * 150e6 + 10 * 1024)) < 1.0 and abs(kb["algorithmic_bytes_per_launch"] - 150e6) < 1.0
     assert "k_sweep6" in open(str(out) + ".txt").read()
+    # matrix-pipe occupancy from an SQ counter pass, added to a committed profile without its inputs (--rerender): one MFMA =
+    # 32 busy cycles of one SIMD; 100 % of the 1024 SIMDs for the whole launch at the 2.4 GHz spec clock = 1.0
+    for d_ in [k6] + list(k6["by_stage"].values()):
+        busy = 0.5 * 1024 * d_["avg_launch_ms"] * 1e6 * 2.4
+        d_.setdefault("counters", {})["SQ_VALU_MFMA_BUSY_CYCLES"] = {"mean_per_launch": busy, "dispatches": 12} if d_ is k6 else busy
+    json.dump(d, open(str(out) + ".json", "w"))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_join.py"), "--rerender", str(out) + ".json"], check=True, capture_output=True)
+    d2 = json.load(open(str(out) + ".json"))
+    assert abs(d2["kernels"]["k_sweep6"]["mfma_busy_of_spec_cycles"] - 0.5) < 1e-9
+    assert abs(d2["kernels"]["k_sweep6"]["by_stage"]["A2"]["mfma_busy_of_spec_cycles"] - 0.5) < 1e-9
+    assert "mfma_busy_of_spec_cycles" not in d2["kernels"]["k_bound"] and "MFMA busy" in open(str(out) + ".txt").read()
     # a trace whose launch count is not a multiple of the records is refused, not silently mis-joined
     con = sqlite3.connect(db)
     con.execute("insert into kernels values (?,?,?,?,?,?,?)", ("void p4v::k_bound<0>(p4v::SweepParams)", t, t + 10, 600 * 256, 1, 1, 256))
