@@ -43,18 +43,18 @@ def search_macs(wrapped, shapes, calib, eq_n=100, rounds=3):
     lin = mm = conv = 0.0
     for name, m in wrapped.items():
         ins, out = shapes[name]
-        rounds, eq_n = getattr(m, "search_round", rounds), getattr(m, "eq_n", eq_n)      # (BasePTQ: one round)
+        r_, n_ = getattr(m, "search_round", rounds), getattr(m, "eq_n", eq_n)      # per module (BasePTQ: one round)
         if isinstance(m, MinMaxQuantLinear):
             rows = calib * int(torch.tensor(ins[0][:-1]).prod())
-            lin += rounds * 2 * eq_n * rows * m.in_features * m.out_features
+            lin += r_ * 2 * n_ * rows * m.in_features * m.out_features
         elif isinstance(m, MinMaxQuantConv2d):
             k = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-            conv += rounds * eq_n * calib * out[2] * out[3] * k * m.out_channels
+            conv += r_ * n_ * calib * out[2] * out[3] * k * m.out_channels
         else:
             sos = type(m).__name__.startswith("SoS")
             A, B = ins
             per = calib * A[0] * A[1] * A[2] * A[3] * B[3]          # (windows x) heads x M x K x N per image
-            mm += rounds * ((20 + eq_n) if sos else 2 * eq_n) * per
+            mm += r_ * ((20 + n_) if sos else 2 * n_) * per
     return lin, mm, conv
 
 

@@ -13,7 +13,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <type_traits>
 #include <vector>
 
@@ -127,6 +129,43 @@ struct Ctx {
     Arena ws;
     bool dry;
 };
+
+// Small device -> host results (the survivor range of a pruned pass, the slice's weight share, the intervals a pass selected)
+// are written by their kernel into mapped host memory as well and read after the stream synchronisation the host does anyway:
+// no copy command (a pageable hipMemcpyAsync is a blit kernel into a staging buffer between two waits: ~410 range read-backs
+// and ~270 interval read-backs per ViT-B calibration).  One block per stream, allocated at the stream's first use (the
+// calibrator's streams are persistent), never freed: 16 ints (ranges, weight share) + MIR_SLOTS interval vectors of MIR_SLOT floats.
+// p4v_debug_set_tuning(12, 8): the copy path (A/B).
+constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
+int* host_mirror(hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<void*, int*> tab;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tab.find((void*)st);
+    if (it != tab.end()) return it->second;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64 + sizeof(float) * MIR_SLOT * MIR_SLOTS, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    tab[(void*)st] = (int*)p;
+    return (int*)p;
+}
+// The interval vectors of the *_impl call running on this thread that are mirrored (MirrorScope binds them, launch_select /
+// k_prune_hull write through attach_mirror, read_dev reads).  `valid`: the last writer of the whole device vector was a
+// mirrored selection (not the min-max initialisation, not a memo restore).
+struct IvMirror { const float* dev; float* host; bool valid; int count; };
+thread_local IvMirror g_mir[MIR_SLOTS] = {};
+IvMirror* mirror_of(const float* dev) {
+    if (!dev) return nullptr;
+    for (auto& m : g_mir) if (m.dev == dev) return &m;
+    return nullptr;
+}
+void attach_mirror(SelectParams& sl) {
+    sl.iv_host = nullptr; sl.aux_host = nullptr;
+    if (!sl.interval) return;
+    if (IvMirror* m = mirror_of(sl.interval); m && sl.nj <= MIR_SLOT && sl.out_off == 0 && (sl.nj == 1 || sl.out_js == 1)) {
+        sl.iv_host = m->host; m->valid = true; m->count = sl.nj;
+    } else if (m) m->valid = false;
+    if (IvMirror* m = mirror_of(sl.aux_out); m && sl.nj <= MIR_SLOT) { sl.aux_host = m->host; m->valid = true; m->count = sl.nj; }
+}
 
 void metric_epi(int metric, int* epi, int* wt_mode) {
     switch (metric) {
@@ -631,8 +670,10 @@ int launch_finish_cos(Ctx& c, const FinishCosParams& p) {
     return 0;
 }
 
-int launch_select(Ctx& c, const SelectParams& p) {
+int launch_select(Ctx& c, const SelectParams& p_) {
     if (c.dry) return 0;
+    SelectParams p = p_;
+    attach_mirror(p);
     hipLaunchKernelGGL(k_select, dim3(p.nj), dim3(128), 0, c.st, p);
     HIPCHK(hipGetLastError());
     return 0;
@@ -709,6 +750,8 @@ struct Pass {
     bool twin_disjoint;       // twin whose two ranges never overlap (post-GELU): k_sweep7 may stream them as one merged plane
     // exact candidate pruning (run_pass_pruned): device-side candidate range, scores kept for the next stage, no selection
     const int* crange;
+    const int* crange_blk;    // ... and per score block [2 * nj] (k_prune_hull's rblk): honoured where the sweep kernel's tiles lie inside
+                              // one score block (run_pass decides; otherwise every block sweeps `crange`, a superset)
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
@@ -774,6 +817,14 @@ int run_pass(Ctx& c, Pass& ps) {
     const bool b1_lds = g_stage == 2 && tune(TUNE_B1_PATH) == 2;        // experiment: the bound pass on k_sweep4 (stationary operand in LDS)
     const bool regs6 = stat_ok && sweep6_supported(Kp / SW_BKB) && !(g_variant & 16) && !b1_lds;   // k_sweep6: stationary operand in registers
     const bool pairs = stat_ok && !regs6 && !(g_variant & 8) && !b1_lds;                // k_sweep5: two candidates per pass
+    // per-score-block candidate ranges: the weight search on k_sweep6 (a streaming 64-row tile lies in one scale block = one score
+    // block: blocks64); tuning 12 = 9 switches them off (A/B)
+    const int* rblk = (ps.crange && ps.crange_blk && regs6 && !ps.row.expanded && ps.j_mode == 1 && ps.nj == ps.s_cs &&
+                       ps.j_div == ps.sb_div && tune(TUNE_B1_PATH) != 9) ? ps.crange_blk : nullptr;
+    // ... and the head-wise searches of the attention matmuls (score block = z % heads: a workgroup works on one z)
+    const bool rblk_z_ok = ps.crange && ps.crange_blk && !stat_ok && ps.j_mode == 2 && ps.nj == ps.j_div && ps.Z > 1 && ps.epi != EPI_COS &&
+                           !ps.store_out && !bound && rup(ps.K, 64) < 1024 && tune(TUNE_B1_PATH) != 9;
+    const int* rblk_z = rblk_z_ok ? ps.crange_blk : nullptr;
     const int PADR = SW_BM;
     // k_sweep7 (large K): rows = samples, columns = output features of a plain [M][N] layer; features contiguous in
     // raw_out / raw_grad and a multiple of 32 (dwordx4 epilogue loads, whole 32-feature blocks), every 32-feature block
@@ -942,6 +993,14 @@ int run_pass(Ctx& c, Pass& ps) {
             HIPCHK(hipStreamSynchronize(c.st));
             const int lo = std::max(h[0], c0), hi = std::min(h[1], c0 + nc);
             g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
+            if ((rblk || rblk_z) && ps.nj <= 64) {               // equal-sized score blocks, each on its own range
+                int hb[128];
+                HIPCHK(hipMemcpyAsync(hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj, hipMemcpyDeviceToHost, c.st));
+                HIPCHK(hipStreamSynchronize(c.st));
+                double sum = 0;
+                for (int j = 0; j < ps.nj; ++j) sum += std::max(0, std::min(std::min(hb[2 * j + 1], h[1]), c0 + nc) - std::max(std::max(hb[2 * j], h[0]), c0));
+                g_exec_frac = sum / ((double)nc * ps.nj);
+            }
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] pruned stage: candidates [%d, %d) of %d  (M %d N %d K %d Z %d nj %d)\n", h[0], h[1], ps.eq_n, ps.Mrows, ps.Ncols, ps.K, ps.Z, ps.nj);
         } else g_exec_frac = 1.0;
         if (stat_ok) {
@@ -961,7 +1020,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.dbg = g_variant & 3;
             if (regs6) {
                 // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
-                q.stiles = s6_stiles; q.ttiles = s6_ttiles; q.E = epi6;
+                q.stiles = s6_stiles; q.ttiles = s6_ttiles; q.E = epi6; q.crange_blk = rblk;
                 int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, tune(TUNE_P6) > 0 ? 0.125 * tune(TUNE_P6) : 25.0, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
@@ -1019,6 +1078,7 @@ int run_pass(Ctx& c, Pass& ps) {
         sp.o_inner = ps.o_inner > 0 ? ps.o_inner : INT_MAX;
         sp.o_ninner = ps.o_ninner > 0 ? ps.o_ninner : INT_MAX;
         sp.M = ps.Mrows; sp.N = ps.Ncols; sp.Z = ps.Z; sp.c0 = c0; sp.c1 = c0 + nc; sp.crange = ps.crange;
+        sp.crange_blk = rblk_z; sp.cb_div = std::max(1, ps.j_div);
         sp.part = part; sp.p_cs = p_cs; sp.p_zs = p_zs; sp.Np = NpP;
         sp.mtiles = Mp / SW_BM; sp.ntiles = Np / SW_BN;
         sp.dbg = g_variant & 3;
@@ -1058,6 +1118,7 @@ int run_pass(Ctx& c, Pass& ps) {
     if (ps.store_out) { c.ws.off = mark; return 0; }
     auto with_marks = [&](FinishParams& fp) {     // a pruned pass flags the candidates it packed into the module's plane
         if (ps.crange && pc && pc->done) { fp.mark_done = pc->done; fp.mark_n = ps.eq_n; }
+        fp.crange_blk = rblk ? rblk : rblk_z;
     };
     if (nine_halves > 0) {      // k_sweep9 wrote [C][Z][halves * 8]
         const int slots = nine_halves * SW9_NW;
@@ -1148,9 +1209,12 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
             // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
             // (variant 8388608: always prune)
             float f = 1.0f;
-            hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, g.segs, g.seg_rows, g.k, sc->frac);
-            HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
+            int* hm = tune(TUNE_B1_PATH) == 8 ? nullptr : host_mirror(c.st);
+            hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, g.segs, g.seg_rows, g.k, sc->frac,
+                               hm ? reinterpret_cast<float*>(hm + 4) : nullptr);
+            if (!hm) HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
             HIPCHK(hipStreamSynchronize(c.st));
+            if (hm) f = *reinterpret_cast<volatile float*>(hm + 4);
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, g.segs, g.k, g.seg_rows);
             sc->frac_host = f;
             if (g.k < g.k_cap && !(f >= 0.97f)) {      // the small slice does not hold the weight: the full one (ranked again)
@@ -1456,6 +1520,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     int* r2 = r1 + 2;
     int* r3 = r1 + 4;
     int* best_idx = c.ws.get<int>((size_t)std::max(1, ps.nj));
+    int* rblk2 = c.ws.get<int>((size_t)4 * std::max(1, ps.nj));      // per-score-block survivor ranges of the hull (r2) ...
+    int* rblk3 = rblk2 + 2 * std::max(1, ps.nj);                       // ... and of the second tier's (r3)
     float* vrow = c.ws.get<float>((size_t)std::max(1, ps.cand_cs));
     float* S1s = ps.use_s1 ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;             // one scale table for all stages
     float* S2s = (ps.use_s1 && ps.twin) ? c.ws.get<float>((size_t)ps.eq_n * ps.s_cs) : nullptr;
@@ -1512,10 +1578,13 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     g_stage = 2;
     { const int r_ = run_pass(c, b1); g_stage = 0; if (r_) return r_; }
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
-    pp.r_out = r2;
+    pp.r_out = r2; pp.rblk = rblk2;
+    int* hm = (ps.host_sync_ok && !c.dry && tune(TUNE_B1_PATH) != 8) ? host_mirror(c.st) : nullptr;
+    pp.r_host = hm;
     const bool hull_selects = !ps.scores_out && ps.interval && (virt || ps.nj <= 32);   // (its non-virt selection is serial over the blocks)
     SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
                      ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
+    attach_mirror(hsl);
     if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl); HIPCHK(hipGetLastError()); }
     // nothing survives besides stage B1's candidates: the pass's selection without another sweep
     auto select_without_b2 = [&]() -> int {
@@ -1535,13 +1604,15 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
         // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made
         int h[2] = {0, 1};
-        HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
+        if (!hm) HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
+        if (hm) { h[0] = reinterpret_cast<volatile int*>(hm)[0]; h[1] = reinterpret_cast<volatile int*>(hm)[1]; }
         if (h[0] >= h[1]) return select_without_b2();
         nsurv = h[1] - h[0];
     }
     // second tier: many survivors of a slice that holds well under all of the weight -> sweep THEM over the larger slice first
     const int* rB = r2;
+    const int* rBblk = rblk2;
     const int t2min = tune(TUNE_TIER2) >= 2 ? tune(TUNE_TIER2) : 8;
     if (sc2 && (c.dry || (ps.host_sync_ok && nsurv >= t2min && sc->frac_host < 0.9f))) {
         if (!c.dry) CHK(slice_fill(c, sc2, geo2, /*host_sync_ok=*/false));
@@ -1551,26 +1622,27 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         sliced2(a2.row.pk);
         if (ps.twin) sliced2(a2.row2.pk);
         a2.cache = ps.col.expanded ? ps.cache : ps.cache ? &sc2->aplane : nullptr;
-        a2.ecache = nullptr; a2.scores_keep = SA2; a2.no_select = true; a2.crange = r2;
+        a2.ecache = nullptr; a2.scores_keep = SA2; a2.no_select = true; a2.crange = r2; a2.crange_blk = rblk2;
         a2.S1_pre = S1s; a2.S2_pre = S2s; a2.s_ready = true;
         g_stage = 4;
         { const int r_ = run_pass(c, a2); g_stage = 0; if (r_) return r_; }
         if (!c.dry) {
             PruneParams pp2 = pp;                 // same bound L* (stage B1's totals), the tighter partial sums, hull into r3
-            pp2.SA = SA2; pp2.r_out = r3;
+            pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3;
             hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp2, hsl);
             HIPCHK(hipGetLastError());
             int h[2] = {0, 1};
-            HIPCHK(hipMemcpyAsync(h, r3, sizeof h, hipMemcpyDeviceToHost, c.st));
+            if (!hm) HIPCHK(hipMemcpyAsync(h, r3, sizeof h, hipMemcpyDeviceToHost, c.st));
             HIPCHK(hipStreamSynchronize(c.st));
+            if (hm) { h[0] = reinterpret_cast<volatile int*>(hm)[2]; h[1] = reinterpret_cast<volatile int*>(hm)[3]; }
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] second tier: %d survivors of the %d-row slice -> %d of the %d-row slice (M %d N %d K %d)\n", nsurv, k, std::max(0, h[1] - h[0]), k2, ps.Mrows, ps.Ncols, ps.K);
             if (h[0] >= h[1]) return select_without_b2();
-            rB = r3;
+            rB = r3; rBblk = rblk3;
         }
     }
     // stage B2: whatever else survives, on all samples (an empty range when stage B1 already covers the survivors)
     Pass b2 = ps;
-    b2.crange = rB; b2.scores_keep = S2; b2.no_select = true;
+    b2.crange = rB; b2.crange_blk = rBblk; b2.scores_keep = S2; b2.no_select = true;
     b2.S1_pre = S1s; b2.S2_pre = S2s; b2.s_ready = true;
     g_stage = 3;
     { const int r_ = run_pass(c, b2); g_stage = 0; if (r_) return r_; }
@@ -1718,7 +1790,12 @@ int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j) {
     g_stage = 2;
     { const int r_ = sos_sweep(c, j, kp, r1, SB); g_stage = 0; if (r_) return r_; }   // B1
     pp.r_out = r2;                                // (+ the selection from its totals when nothing else survives)
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, sos_select_params(j, SB)); HIPCHK(hipGetLastError()); }
+    if (!c.dry) {
+        SelectParams hsl = sos_select_params(j, SB);
+        attach_mirror(hsl);
+        hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl);
+        HIPCHK(hipGetLastError());
+    }
     if (j.host_sync_ok && !c.dry) {
         int h[2] = {0, 1};
         HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
@@ -1754,17 +1831,36 @@ struct PassMemo {
 
 int read_dev(Ctx& c, const float* d, int n, std::vector<float>& h) {
     h.resize(n);
+    if (IvMirror* m = mirror_of(d); m && m->valid && m->count == n) {      // the selection that wrote `d` also wrote the mirror
+        HIPCHK(hipStreamSynchronize(c.st));
+        const volatile float* src = m->host;
+        for (int i = 0; i < n; ++i) h[i] = src[i];
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(h.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
     HIPCHK(hipStreamSynchronize(c.st));
     return 0;
 }
 
 int write_dev(Ctx& c, float* d, const std::vector<float>& h) {
+    if (IvMirror* m = mirror_of(d)) m->valid = false;
     HIPCHK(hipMemcpyAsync(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, c.st));
     HIPCHK(hipStreamSynchronize(c.st));   // h may go out of scope
     return 0;
 }
 
+// binds the interval vectors of one *_impl call (the ones its pass memo reads back) to the stream's mapped block
+struct MirrorScope {
+    MirrorScope(Ctx& c, bool on, const float* a, const float* b = nullptr, const float* d3 = nullptr) {
+        float* base = (on && !c.dry && tune(TUNE_B1_PATH) != 8) ? reinterpret_cast<float*>(host_mirror(c.st)) : nullptr;
+        const float* devs[MIR_SLOTS] = {a, b, d3};
+        for (int i = 0; i < MIR_SLOTS; ++i)
+            g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + 16 + i * MIR_SLOT : nullptr, false, 0};
+    }
+    ~MirrorScope() { for (auto& m : g_mir) m = IvMirror{}; }
+    MirrorScope(const MirrorScope&) = delete;
+    MirrorScope& operator=(const MirrorScope&) = delete;
+};
 
 // Which parts of calibration_step2 one call runs.  The fused entry points run everything (ST_ALL: initialisation, then
 // search_round x {first operand, second operand} with memoisation); the granular entry points of the C ABI
@@ -1893,6 +1989,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     }
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
+    MirrorScope mirrors(c, memo_on, w_iv, a_iv);
     PlaneCache plane_w, plane_a;
     EpiCache epi_w, epi_a;
     SliceCache slice, slice2;
@@ -2025,6 +2122,8 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     // fragment-order image of k_sweep6's epilogue operands (built from ps.O) must be rebuilt with it
                     ps.ecache = nullptr;
                     slice.o_src = nullptr;          // ... and so are the gathered rows of the target in the sample slice
+                    slice2.o_src = nullptr;         // (both tiers: the second one compares the same pointer and would otherwise keep
+                                                    // the previous pass's target rows when two tier-2 activation passes follow each other)
                 }
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -2149,6 +2248,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     }
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_A, memo_B;
+    MirrorScope mirrors(c, memo_on, A_iv, B_iv, d->sos ? split : nullptr);
     PlaneCache plane_A, plane_B;
     SliceCache slice;
     const bool keep_planes = sg.full() && d->search_round > 1;
@@ -2372,6 +2472,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
 
     const bool memo_on = sg.full() && !c.dry && !scores_out && !best_out && !(d->reserved & 2) && !(g_variant & 512);
     PassMemo memo_w, memo_a;
+    MirrorScope mirrors(c, memo_on, w_iv, a_iv);
     PlaneCache plane_w, plane_a;
     SliceCache slice;
     const bool keep_planes = sg.full() && d->search_round > 1;

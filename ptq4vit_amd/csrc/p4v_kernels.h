@@ -541,8 +541,17 @@ __device__ __forceinline__ void clip_crange(const int* crange, int& lo, int& hi,
     lo = max(lo, a); hi = min(hi, b);
 }
 
+// ... and per score block (prune_hull's rblk: 2 ints per block): the kernel's tile lies inside ONE score block `blk`
+__device__ __forceinline__ void clip_crange_blk(const int* rblk, int blk, int& lo, int& hi) {
+    if (!rblk) return;
+    const int a = __builtin_amdgcn_readfirstlane(rblk[2 * blk]), b = __builtin_amdgcn_readfirstlane(rblk[2 * blk + 1]);
+    lo = max(lo, a); hi = min(hi, b);
+}
+
 struct SweepParams {
     const int* crange;                 // optional device-side candidate range (see clip_crange)
+    const int* crange_blk; int cb_div; // optional per-score-block ranges, block = z % cb_div (head-wise MatMul searches); k_sweep, k_sweep2,
+                                       // k_sweep8, k_sweep9 honour them (k_sweep2g / k_bound never get them: run_pass)
     const void* A;  long a_cs, a_zs;   // byte strides between candidates / batch entries (0 = shared)
     const void* A2; long a2_cs, a2_zs; // twin second plane (post-GELU negative range / SoS low range)
     const void* B;  long b_cs, b_zs;
@@ -608,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
     clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, z % p.cb_div, c_lo_, c_hi_);
     const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
@@ -884,6 +894,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
     clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, z % p.cb_div, c_lo_, c_hi_);
     const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
 
@@ -1212,6 +1223,8 @@ __global__ __launch_bounds__(256, 4) void k_bound(SweepParams p) {
         const int a = __builtin_amdgcn_readfirstlane(p.crange[0]), b = __builtin_amdgcn_readfirstlane(p.crange[1]);
         if (a >= b) return;                                // empty range: k_finish writes -inf without reading the table
         c = max(c, a);
+        if (c >= b) return;                                // (a chunked plane: the candidate sits in an earlier chunk -- nothing of this
+                                                           // launch's chunk is in range, and its fragment image holds another candidate)
     }
     if (c >= p.c1) return;                                 // (a chunked plane: the candidate lives in another chunk's launch)
     const int wr = wid >> 1, wc = wid & 1;
@@ -1341,6 +1354,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
     clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, z % p.cb_div, c_lo_, c_hi_);
     const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
@@ -1567,6 +1581,7 @@ __global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
     clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, z % p.cb_div, c_lo_, c_hi_);
     const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
@@ -2191,6 +2206,7 @@ struct Sweep3Params {
     int dbg;
     int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them)
     const float* E;                     // k_sweep6: epilogue operands in fragment order (k_prep_epi6); S is in fragment order too
+    const int* crange_blk;              // k_sweep6: optional per-score-block candidate ranges (block = scale block of the tile)
 #ifdef P4V_TRACE
     unsigned long long* trace;          // tuning builds only: [workgroup][8] timestamps (100 MHz) + hw id
 #endif
@@ -2683,6 +2699,7 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
     int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
     clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, min((p.sb_on_t ? tt * 64 : st * 256) / p.sb_div, p.s_cs - 1), c_lo_, c_hi_);
     const int c_lo = c_lo_, c_hi = c_hi_;
     if (c_lo >= c_hi) return;
     const int ncand = c_hi - c_lo;
@@ -3602,6 +3619,8 @@ struct SelectParams {
     float* scores_out;  // optional copy [C][scores_out_ld]
     int scores_out_ld;
     int32_t* best_out;  // optional [nj]
+    float* iv_host; float* aux_host;   // optional mirrors of `interval` / `aux_out` in mapped host memory (same indexing): the pass
+                                       // memo reads them after the stream synchronisation it does anyway -- no copy command
 };
 // the selection of score block j over the candidates [c_lo, c_hi) (all threads of the workgroup; sv / si: blockDim.x entries)
 __device__ __forceinline__ void select_block(const SelectParams& p, int j, int c_lo, int c_hi, float* sv, int* si) {
@@ -3616,7 +3635,9 @@ __device__ __forceinline__ void select_block(const SelectParams& p, int j, int c
     if (threadIdx.x == 0) {
         const float sel = p.cands[(long)best * p.cand_cs + (long)j * p.cand_js + p.cand_off];
         p.interval[(long)j * p.out_js + p.out_off] = sel;
+        if (p.iv_host) p.iv_host[(long)j * p.out_js + p.out_off] = sel;
         if (p.aux_out) p.aux_out[j] = sel / p.aux_div;
+        if (p.aux_out && p.aux_host) p.aux_host[j] = sel / p.aux_div;
         if (p.best_out) p.best_out[j] = best;
     }
 }
@@ -3632,7 +3653,9 @@ __global__ __launch_bounds__(128) void k_select(SelectParams p) {          // on
 // that winner's total) instead of the hull of the winners (a dozen heads: 20-30 candidates).  vrow = that candidate's row of the
 // candidate table, best[j] = the winners.
 struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out;
-                     int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow; };
+                     int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow;
+                     int* r_host;         // optional mirror of r_out in mapped host memory (read by the host after its stream sync)
+                     int* rblk; };        // optional per-score-block survivor ranges [2 * nj] (see prune_hull)
 // (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
 // r_out = hull over the blocks of stage A's first maxima
 #define PRUNE_WIDE_NJ 64        // from this many score blocks on: one THREAD per block (channel-wise weights: hundreds of blocks)
@@ -3684,17 +3707,25 @@ __global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {
 }
 // r_out = what stage B2 has to evaluate: the hull of the candidates whose stage-A bound reaches the best complete score, or the
 // empty range when stage B1 already evaluated all of them.  Returns (to every thread) whether the range is empty.
-__device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int* sh) {
+// rblk (optional, 2 ints per score block): the same PER BLOCK -- the blocks of a pass are scored independently, so block j only
+// needs ITS survivors [rblk[2j], rblk[2j+1]) re-evaluated; a block whose only survivor is its own stage-A winner (virt) is closed:
+// empty range, the winner stands without any total (the q block of every ViT qkv layer, whose class-token rows hold its whole
+// weight: one survivor, while the flat optima of the k / v blocks keep 10-20 -- a third of stages A2 / B2 of the largest sweep
+// family).  r_out is then the hull of the OPEN blocks' ranges (what k_pack has to provide); kernels that cannot take per-block
+// ranges sweep r_out for every block, a superset.  sblk: 3 * 64 ints of shared memory (narrow path).
+__device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int* sh, int* sblk) {
     int &lo_s = sh[0], &hi_s = sh[1], &bad_s = sh[2], &more_s = sh[3], &empty_s = sh[4];
     const int a = p.r_in[0], b = p.r_in[1];
-    if (threadIdx.x == 0) { lo_s = a; hi_s = b; bad_s = 0; more_s = 0; }
+    if (threadIdx.x == 0) { lo_s = p.C; hi_s = 0; bad_s = 0; more_s = 0; }
+    const bool narrow = p.nj < PRUNE_WIDE_NJ;
+    if (narrow && (int)threadIdx.x < p.nj) { sblk[3 * threadIdx.x] = p.C; sblk[3 * threadIdx.x + 1] = 0; sblk[3 * threadIdx.x + 2] = 0; }
     __syncthreads();
-    if (p.nj >= PRUNE_WIDE_NJ) {          // one thread per score block
-        int l = p.C, h = 0;
-        bool bad = false, more = false;
+    if (!narrow) {          // one thread per score block
+        bool bad = false;
         for (int j = threadIdx.x; j < p.nj; j += 256) {
             float L = -__builtin_inff();
-            bool nan = false;
+            bool nan = false, more = false;
+            int l = p.C, h = 0;
             if (p.virt) { L = p.SB[j]; nan = L != L; }
             else for (int c = a; c < b; ++c) { const float v = p.SB[(long)c * p.nj + j]; nan |= v != v; L = fmaxf(L, v); }
             const float thr = L - p.margin * fabsf(L);
@@ -3705,10 +3736,11 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
                 if (!(v < thr)) { l = min(l, c); h = max(h, c + 1); more |= p.virt && c != bj; }
             }
             bad |= nan || !(L > -__builtin_inff());
+            const bool open = p.virt ? more : h > 0;
+            if (open) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); atomicOr(&more_s, more ? 1 : 0); }
+            if (p.rblk) { p.rblk[2 * j] = open ? l : 0; p.rblk[2 * j + 1] = open ? h : 0; }
         }
         if (bad) atomicOr(&bad_s, 1);
-        if (more) atomicOr(&more_s, 1);
-        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
     } else
     for (int j = 0; j < p.nj; ++j) {
         // L* = the best complete score among stage B1's candidates (virt: the one synthetic candidate's score in this block)
@@ -3723,26 +3755,45 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
         __syncthreads();
         const float thr = L - p.margin * fabsf(L);
         int l = p.C, h = 0;
+        bool more = false;
         for (int c = threadIdx.x; c < p.C; c += 256) {
             const float v = p.SA[(long)c * p.nj + j];
             nan |= v != v;
             if (!(v < thr)) {
                 l = min(l, c); h = max(h, c + 1);
-                if (p.virt && c != p.best[j]) atomicOr(&more_s, 1);     // a survivor besides the block's winner: stage B2 decides
+                more |= p.virt && c != p.best[j];     // a survivor besides the block's winner: stage B2 decides
             }
         }
         if (nan || !(L > -__builtin_inff())) atomicOr(&bad_s, 1);
-        if (h > 0) { atomicMin(&lo_s, l); atomicMax(&hi_s, h); }
+        if (h > 0) { atomicMin(&sblk[3 * j], l); atomicMax(&sblk[3 * j + 1], h); }
+        if (more) atomicOr(&sblk[3 * j + 2], 1);
+    }
+    __syncthreads();
+    if (narrow && threadIdx.x == 0) {
+        for (int j = 0; j < p.nj; ++j) {
+            const bool open = p.virt ? sblk[3 * j + 2] != 0 : sblk[3 * j + 1] > 0;
+            if (open) { lo_s = min(lo_s, sblk[3 * j]); hi_s = max(hi_s, sblk[3 * j + 1]); more_s |= sblk[3 * j + 2]; }
+            else { sblk[3 * j] = 0; sblk[3 * j + 1] = 0; }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int l = bad_s ? 0 : lo_s, h = bad_s ? p.C : hi_s;
+        int l = bad_s ? 0 : min(lo_s, hi_s), h = bad_s ? p.C : hi_s;
         // nothing survives outside what stage B1 evaluated: its totals decide
-        if (p.virt ? (!bad_s && !more_s) : (l == a && h == b)) l = h = 0;
+        if (p.virt ? (!bad_s && !more_s) : (!bad_s && l >= a && h <= b && h > l)) l = h = 0;
+        if (!p.virt && !bad_s && h > l) { l = min(l, a); h = max(h, b); }     // stage B2 re-evaluates stage B1's candidates with the other survivors
         p.r_out[0] = l; p.r_out[1] = h;
+        if (p.r_host) { p.r_host[0] = l; p.r_host[1] = h; }
+        lo_s = l; hi_s = h;
         empty_s = l >= h;
     }
     __syncthreads();
+    if (p.rblk) {
+        // per-block ranges: the block's own hull (virt, healthy); the global range otherwise (NaN anywhere: everything)
+        const bool per_blk = p.virt && !bad_s && !empty_s;
+        if (narrow) { for (int j = threadIdx.x; j < p.nj; j += 256) { p.rblk[2 * j] = per_blk ? sblk[3 * j] : lo_s; p.rblk[2 * j + 1] = per_blk ? sblk[3 * j + 1] : hi_s; } }
+        else if (!per_blk) { for (int j = threadIdx.x; j < p.nj; j += 256) { p.rblk[2 * j] = lo_s; p.rblk[2 * j + 1] = hi_s; } }
+    }
     return empty_s != 0;
 }
 // ... and, when the range is empty, the pass's selection (sl.interval != nullptr) from stage B1's totals: what k_select would pick
@@ -3753,14 +3804,17 @@ __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p, SelectParams 
     __shared__ float sv[256];
     __shared__ int si[256];
     __shared__ int sh[8];
-    const bool empty = prune_hull(p, sv, sh);
+    __shared__ int sblk[3 * PRUNE_WIDE_NJ];
+    const bool empty = prune_hull(p, sv, sh, sblk);
     if (!empty || !sl.interval) return;
     if (p.virt) {                                  // every block's only survivor is its stage-A winner
         for (int j = threadIdx.x; j < sl.nj; j += 256) {
             const int best = p.best[j];
             const float sel = sl.cands[(long)best * sl.cand_cs + (long)j * sl.cand_js + sl.cand_off];
             sl.interval[(long)j * sl.out_js + sl.out_off] = sel;
+            if (sl.iv_host) sl.iv_host[(long)j * sl.out_js + sl.out_off] = sel;
             if (sl.aux_out) sl.aux_out[j] = sel / sl.aux_div;
+            if (sl.aux_out && sl.aux_host) sl.aux_host[j] = sel / sl.aux_div;
             if (sl.best_out) sl.best_out[j] = best;
         }
     } else {                                       // (the caller leaves many-block non-virt selections to k_select)
@@ -3777,6 +3831,7 @@ struct FinishParams {
     float* scores;         // [C][nj]
     const int* crange;     // optional: candidates outside [crange[0], crange[1]) were not evaluated -> score -inf
     unsigned char* mark_done; int mark_n;        // optional, with crange: the candidates this pass packed into the module's plane (flags, count)
+    const int* crange_blk;                       // optional, with crange: per-score-block ranges [2 * nj] (the sweep evaluated block j on those only)
 };
 
 // One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
@@ -3789,7 +3844,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishParams p) {
         const int a = p.crange[0], b = p.crange[1];
         for (int cc = max(a, 0) + (int)threadIdx.x; cc < min(b, p.mark_n); cc += 256) p.mark_done[cc] = 1;
     }
-    if (p.crange && (c < p.crange[0] || c >= p.crange[1])) {
+    if (p.crange && (c < p.crange[0] || c >= p.crange[1] || (p.crange_blk && (c < p.crange_blk[2 * j] || c >= p.crange_blk[2 * j + 1])))) {
         if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = -__builtin_inff();
     } else {
         int nlo = 0, nhi = p.N, zstep = 1, zlo = 0;
@@ -3992,7 +4047,7 @@ __global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n
 // dst[r][a][b][c] = src[seg_off(r / seg) + idx[r] * s0 + a * s1 + b * s2 + c * s3]; seg = rows per segment (0: one segment),
 // seg_off(z) = (z / zdiv) * sz2 + (z % zdiv) * sz (two-level batch stride: image, head)
 // frac[0] = (weight of the selected rows) / (weight of all rows): how tight the slice's bounds are
-__global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long n, const int* idx, int segs, int seg_rows, int k, float* frac) {
+__global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long n, const int* idx, int segs, int seg_rows, int k, float* frac, float* frac_host) {
     __shared__ double red[1024];
     double tot = 0.0, sel = 0.0;
     for (long i = threadIdx.x; i < n; i += 1024) tot += (double)mass[i];
@@ -4004,7 +4059,11 @@ __global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long 
         if (threadIdx.x == 0) { if (pass) sel = red[0]; else tot = red[0]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) frac[0] = tot > 0.0 ? (float)(sel / tot) : 0.0f;
+    if (threadIdx.x == 0) {
+        const float f = tot > 0.0 ? (float)(sel / tot) : 0.0f;
+        frac[0] = f;
+        if (frac_host) frac_host[0] = f;               // mapped host memory: read after the stream sync, no copy command
+    }
 }
 
 struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; int seg, zdiv; long sz2, sz; };

@@ -69,9 +69,21 @@ def save_intervals(wrapped_modules, path, meta=None):
     torch.save({"format": FORMAT, "meta": dict(meta or {}), "modules": intervals_state_dict(wrapped_modules)}, str(path))
 
 
-def load_intervals(wrapped_modules, path, strict=True, mode="quant_forward"):
+def _net_device(wrapped_modules):
+    """The device the wrapped network lives on: that of any parameter / buffer of any wrapped module (MatMul wrappers have
+    none of their own -- their intervals must follow the Linear / Conv modules of the same network)."""
+    for m in wrapped_modules.values():
+        for t in list(m.parameters()) + list(m.buffers()):
+            return t.device
+    return torch.device("cpu")
+
+
+def load_intervals(wrapped_modules, path, strict=True, mode="quant_forward", device=None):
     """Install the intervals stored by `save_intervals` into freshly wrapped modules; `strict`: the module names and classes
-    must match exactly.  Sets `mode` on every module it touched (None: leave the modes).  Returns the stored `meta`."""
+    must match exactly.  Sets `mode` on every module it touched (None: leave the modes).  `device`: where the interval tensors
+    go (default: the device of the network's parameters -- also for the parameter-less MatMul wrappers).  Returns the stored `meta`."""
+    if device is None:
+        device = _net_device(wrapped_modules)
     blob = torch.load(str(path), map_location="cpu", weights_only=True)
     if not isinstance(blob, dict) or blob.get("format") != FORMAT:
         raise ValueError(f"{path}: not an interval checkpoint ({FORMAT})")
@@ -88,7 +100,7 @@ def load_intervals(wrapped_modules, path, strict=True, mode="quant_forward"):
         cls = vals.pop("__class__", None)
         if strict and cls is not None and cls != type(m).__name__:
             raise TypeError(f"load_intervals: {name} is a {type(m).__name__}, the file holds a {cls}")
-        install_intervals(m, vals)
+        install_intervals(m, vals, device=device)
         if mode is not None:
             m.mode = mode
     return blob.get("meta", {})

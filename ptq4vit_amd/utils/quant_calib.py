@@ -29,6 +29,23 @@ except Exception:  # pragma: no cover
         return x
 
 
+_HWQ_WARNED = False
+
+
+def _warn_hw_queues(n_streams):
+    """Once per process: the default of 4 search streams + 3 capture lanes was tuned with GPU_MAX_HW_QUEUES=8
+    (ptq4vit_amd.configure_runtime(), before the first GPU use); with the runtime's 4 hardware queues streams share queues
+    and their kernels serialise (~6 % on ViT-B/224 x 32).  Nothing is changed here -- a library must not touch the
+    environment of other HIP users in the process -- the caller is told."""
+    global _HWQ_WARNED
+    if _HWQ_WARNED or n_streams <= 1 or os.environ.get("GPU_MAX_HW_QUEUES"):
+        return
+    _HWQ_WARNED = True
+    import warnings
+    warnings.warn(f"ptq4vit_amd: {n_streams} search streams but GPU_MAX_HW_QUEUES is unset (runtime default: 4 hardware queues); "
+                  "call ptq4vit_amd.configure_runtime() before the first GPU use, or export GPU_MAX_HW_QUEUES=8", stacklevel=3)
+
+
 def _dev_of(net):
     for p in net.parameters():
         return p.device
@@ -580,6 +597,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         dev = _dev_of(self.net)
         main = torch.cuda.current_stream(dev)
         from .. import engine
+        _warn_hw_queues(n_streams)
         streams = engine.side_streams(dev, n_streams)
         if not hasattr(self, "_module_ms"):
             self._module_ms = {}

@@ -340,6 +340,92 @@ def test_two_tier_pruning_is_exact_and_engages_on_a_spread_weight_profile(eng):
           f"{ {s: stages.count(s) for s in sorted(set(stages))} }")
 
 
+def test_per_score_block_candidate_ranges_are_exact_and_skip_the_closed_blocks(eng):
+    """A ViT-qkv-like Linear (n_V = 3): the q block's metric weight sits in the class-token rows (one survivor: the block is closed
+    after the bound), the k / v blocks' weight is spread over every token (flat optima: many survivors).  With per-score-block
+    candidate ranges (k_prune_hull's rblk) stages A2 / B2 sweep each block over ITS survivors only.  Same intervals as with the
+    ranges switched off (tuning 12 = 9: every block sweeps the hull), as the engine's own cross-check against the full sweep of
+    every pass, and as the unpruned call; and the launch records show less executed work in stages A2 / B2."""
+    g = torch.Generator().manual_seed(37)
+    b, T, K, N = 16, 197, 768, 2304
+    x = torch.randn(b, T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.02 * torch.linspace(0.5, 2.0, N)[:, None]
+    bias = torch.randn(N, generator=g) * 0.02
+    out = F.linear(x, w, bias)
+    grad = torch.randn(out.shape, generator=g) * 1e-10 * torch.exp(0.9 * torch.randn(b, T, 1, generator=g))
+    grad[:, 1:, :768] *= 1e-3                        # q block: only the class-token queries reach the classifier
+    grad[:, 0, :768] *= 30.0
+    args = dict(weight=w.cuda(), bias=bias.cuda(), x=x.cuda(), out=out.cuda(), grad=grad.cuda(), w_bit=8, a_bit=8, n_V=3, n_H=1, n_a=1,
+                search_round=3, **PTQ4VIT)
+
+    def staged_ops():
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            res = eng.linear_calibrate(**args)
+            torch.cuda.synchronize()
+            eng.stats_get()
+            recs = eng.stats_launches()
+        finally:
+            eng.stats_enable(False)
+        return res, sum(r["alg_ops"] for r in recs if r["stage"] in ("A2", "B2")), sorted({r["stage"] for r in recs})
+
+    blk, ops_blk, stages = staged_ops()
+    assert "B2" in stages, f"no stage B2 ran -- the case does not exercise the ranges: {stages}"
+    try:
+        eng.debug_tuning(12, 9)                      # per-block ranges off: every block sweeps the hull of all survivors
+        hull, ops_hull, _ = staged_ops()
+        eng.debug_tuning(12, 0)
+        eng.debug_variant(134217728)
+        chk = eng.linear_calibrate(**args)
+    finally:
+        eng.debug_tuning(12, 0)
+        eng.debug_variant(0)
+    full = eng.linear_calibrate(prune=False, **args)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        assert torch.equal(blk[k], full[k]) and torch.equal(hull[k], full[k]) and torch.equal(chk[k], full[k])
+    assert ops_blk < 0.9 * ops_hull, (ops_blk, ops_hull)
+    print(f"[production] per-block ranges: stages A2 + B2 execute {ops_blk / 1e9:.1f} GOP instead of {ops_hull / 1e9:.1f} GOP; stages {stages}")
+
+
+def test_second_tier_on_a_twin_layer_under_the_cross_check(eng):
+    """Advisor finding of round 4: the twin (post-GELU) activation search rebuilds its folded target in place for every pass; both
+    slice tiers must re-gather its rows.  A fc2-like twin layer with a spread metric weight and the second tier forced on from two
+    survivors (tuning 13 = 2), three rounds, under the engine's cross-check of every pruned pass against its full sweep; and the
+    same intervals as the unpruned call."""
+    g = torch.Generator().manual_seed(43)
+    b, T, K, N = 16, 197, 1024, 768
+    x = F.gelu(1.5 * torch.randn(b, T, K, generator=g))
+    w = torch.randn(N, K, generator=g) * 0.02
+    bias = torch.randn(N, generator=g) * 0.02
+    out = F.linear(x, w, bias)
+    grad = torch.randn(out.shape, generator=g) * 1e-10 * torch.exp(1.1 * torch.randn(b, T, 1, generator=g))
+    args = dict(weight=w.cuda(), bias=bias.cuda(), x=x.cuda(), out=out.cuda(), grad=grad.cuda(), w_bit=8, a_bit=8, n_V=1, n_H=1, n_a=1,
+                search_round=3, postgelu=True, **PTQ4VIT)
+    try:
+        eng.debug_tuning(13, 2)
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            two = eng.linear_calibrate(**args)
+            torch.cuda.synchronize()
+            eng.stats_get()
+            stages = [r["stage"] for r in eng.stats_launches()]
+        finally:
+            eng.stats_enable(False)
+        eng.debug_variant(134217728)
+        chk = eng.linear_calibrate(**args)
+    finally:
+        eng.debug_tuning(13, 0)
+        eng.debug_variant(0)
+    full = eng.linear_calibrate(prune=False, **args)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        assert torch.equal(two[k], full[k]) and torch.equal(chk[k], full[k])
+    print(f"[production] twin layer, forced second tier: stages { {s_: stages.count(s_) for s_ in sorted(set(stages))} }")
+
+
 def test_stage_kernels_of_the_pruned_passes_are_the_ones_that_run(eng):
     """The kernels built for the stages of a pruned pass -- k_bound (stage B1 of Linear passes), k_slice_a / k_slice_b (stage A of the
     attention matmuls' A / B searches) -- are on the default path at ViT-B shapes (a silent fall-back to the sweep kernels would keep
