@@ -454,6 +454,39 @@ def gen_deit_tiny(name="deit_tiny_224_baseptq_4img"):
     print(f"wrote {name}.npz ({len(wrapped)} modules)")
 
 
+def gen_deit_tiny_eval(name="deit_tiny_224_baseptq_eval1000", n_eval=1000, eval_seed=7):
+    """The evaluation loop of the reference (example/test_vit.py:26-45: argmax of the quantised network's logits per image) on
+    the network of `gen_deit_tiny` -- DeiT-tiny/224, BasePTQ, calibrated BY THE REFERENCE on the 4 seeded images -- over 1000
+    seeded evaluation images: the reference's top-1 prediction of every image, its top-1 / top-2 logit margin, and the raw
+    network's prediction (the "label" a data-free top-1 uses).  ImageNet does not exist offline; this pins the inference path
+    and the top-1 bookkeeping on what does.  The calibration must reproduce the intervals of deit_tiny_224_baseptq_4img.npz."""
+    ref_models, ref_wrap, ref_calib, cfg, my_models = _reference_harness("BasePTQ")
+    net = _reference_net(my_models, ref_models, "deit_tiny_patch16_224")
+    images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    ev = torch.randn(n_eval, 3, 224, 224, generator=torch.Generator().manual_seed(eval_seed))
+    with torch.no_grad():
+        raw = torch.cat([net(ev[i:i + 50]) for i in range(0, n_eval, 50)])
+    wrapped = ref_wrap.wrap_modules_in_net(net, cfg)
+    ref_calib.HessianQuantCalibrator(net, wrapped, _Loader(images), sequential=False, batch_size=4).batching_quant_calib()
+    stored = np.load(os.path.join(OUT, "deit_tiny_224_baseptq_4img.npz"), allow_pickle=False)
+    for k, v in _interval_payload(wrapped).items():
+        if "::" in k:
+            assert np.array_equal(np.asarray(v), stored[k]), f"{k}: not the calibration of deit_tiny_224_baseptq_4img.npz"
+    with torch.no_grad():
+        q = torch.cat([net(ev[i:i + 50]) for i in range(0, n_eval, 50)])
+    top2 = q.topk(2, dim=1).values
+    rng = float(q.max() - q.min())
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        quant_argmax=q.argmax(1).numpy().astype(np.int16), quant_margin=(top2[:, 0] - top2[:, 1]).numpy().astype(np.float32),
+                        raw_argmax=raw.argmax(1).numpy().astype(np.int16), quant_logits_head=q[:16].numpy(), logit_range=np.array(rng),
+                        eval_sum=np.array(ev.double().sum().item()), eval_abs_sum=np.array(ev.double().abs().sum().item()),
+                        config=np.array(json.dumps(dict(model="deit_tiny_patch16_224", cfg="BasePTQ", calib_images=4, image_seed=0,
+                                                        net_seed=0, eval_images=n_eval, eval_seed=eval_seed))))
+    agree = int((q.argmax(1) == raw.argmax(1)).sum())
+    print(f"wrote {name}.npz: reference top-1 == raw network's top-1 on {agree}/{n_eval} images, logit range {rng:.3f}")
+
+
 # --------------------------------------------------------------------------- #
 # SURVEY.md s8 row f-4: the non-batching classes and the other calibrator entry points
 # --------------------------------------------------------------------------- #
@@ -689,6 +722,8 @@ if __name__ == "__main__":
         gen_swin_attention()
     elif len(sys.argv) > 1 and sys.argv[1] == "deit":
         gen_deit_tiny()
+    elif len(sys.argv) > 1 and sys.argv[1] == "deit_eval":
+        gen_deit_tiny_eval()
     elif len(sys.argv) > 1 and sys.argv[1] == "f4":
         _install_shims()
         os.chdir(REF)
@@ -705,6 +740,7 @@ if __name__ == "__main__":
             gen_integer()
             gen_swin_attention()
             gen_deit_tiny()
+            gen_deit_tiny_eval()
             gen_f4_layers()
             gen_f4_calibrators()
             gen_prune_eligible()

@@ -183,3 +183,15 @@ def check(rc, what):
         if rc == -2:
             raise NotImplementedError(f"{what}: {msg}")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def source_hash():
+    """Short hash of the engine's sources (kernels, host side of the C ABI, the header): profiles committed under profiles/ carry
+    it, and bench.py only quotes a profile's PMC traffic when it was measured on THIS code."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for rel in ("csrc/p4v_kernels.h", "csrc/p4v_api.hip", "../include/ptq4vit_hip.h"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]

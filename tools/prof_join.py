@@ -72,6 +72,17 @@ def counter_rows(path):
     return [(k, v["name"], v["c"]) for k, v in sorted(per.items())]
 
 
+def _source_hash():
+    """hash of the engine sources the profile was taken on (bench.py quotes `traffic` only from a profile of the running code)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from ptq4vit_amd import _lib
+        return _lib.source_hash()
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rerender", default=None, help="an existing <out>.json: recompute the derived fields and rewrite json + txt (no inputs needed)")
@@ -106,7 +117,8 @@ def main():
 
     out = {"note": ("rocprofv3 kernel trace + separate --pmc passes of `bench.py --profile` (every calibration = the single-stream "
                     "production step), joined launch by launch with the engine's records (tools/prof_join.py). " + a.note).strip(),
-           "model": L.get("model"), "bits": L.get("bits"), "calib": L.get("calib"), "kernels": {}, "join": {}}
+           "model": L.get("model"), "bits": L.get("bits"), "calib": L.get("calib"), "kernels": {}, "join": {},
+           "source_hash": _source_hash()}
     lines = []
     for fam, rl in sorted(by_fam.items(), key=lambda kv: -sum(r["ms"] for r in kv[1])):
         tl = t_fam.get(fam, [])
