@@ -213,8 +213,30 @@ int launch_scale(Ctx& c, ScaleParams p) {
     return 0;
 }
 
-template <typename T> int launch_pack(Ctx& c, const PackParams& p) {
+// The rounding of v_cvt_pk_u8_f32 (k_probe_cvt, once per process) -> the bias of quant16_sat8: 128.5 where the conversion
+// truncates, 128 where it rounds to nearest; 0 = not usable (the kernels keep quant_fast1).  `scratch`: 8 device words.
+float cvt_bias(Ctx& c, unsigned* scratch) {
+    static std::atomic<int> state{0};      // 0 unknown, 1 truncates, 2 rounds to nearest, 3 unusable
+    int st = state.load(std::memory_order_relaxed);
+    if (st == 0 && !c.dry && scratch) {
+        unsigned h[5] = {9, 9, 9, 9, 9};
+        hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(64), 0, c.st, scratch);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c.st) == hipSuccess &&
+            hipStreamSynchronize(c.st) == hipSuccess) {
+            const bool sat = h[3] == 0 && h[4] == 255;
+            st = (sat && h[0] == 0 && h[1] == 1 && h[2] == 2) ? 1 : (sat && h[0] == 1 && h[1] == 2 && (h[2] == 2 || h[2] == 3)) ? 2 : 3;
+        } else { (void)hipGetLastError(); st = 3; }
+        if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] v_cvt_pk_u8_f32(0.7, 1.5, 2.5, -3, 300) = %u %u %u %u %u -> mode %d\n", h[0], h[1], h[2], h[3], h[4], st);
+        state.store(st, std::memory_order_relaxed);
+    }
+    return st == 1 ? 128.5f : st == 2 ? 128.0f : 0.0f;
+}
+template <typename T> int launch_pack(Ctx& c, const PackParams& p_) {
     if (c.dry) return 0;
+    PackParams p = p_;
+    // the full symmetric 8-bit grid: quant16_sat8 once the conversion has been probed (the *_impl entry points do that first);
+    // tuning 12 = 11 keeps quant_fast1 (A/B)
+    p.qbias = (sizeof(T) == 1 && p.mode == PACK_SYM && p.lo == -128 && p.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, nullptr) : 0.0f;
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
     if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack (%ld 16-element runs)", total);
     // (a pruned launch lets most candidate groups exit at once: fewer, longer-running workgroups)
@@ -1306,7 +1328,9 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
     const size_t mark = c.ws.off;
     int8_t* A1 = c.ws.get<int8_t>((size_t)Z * 16 * Kp);
     int8_t* A2 = a.twin ? c.ws.get<int8_t>((size_t)Z * 16 * Kp) : nullptr;
-    float* part = c.ws.get<float>((size_t)a.eq_n * Z);
+    const bool v2 = tune(TUNE_B1_PATH) != 10;           // k_slice_b2 (B in registers, waves deal the column blocks); 12 = 10: k_slice_b (A/B)
+    float* part = c.ws.get<float>((size_t)a.eq_n * Z * (v2 ? 4 : 1));
+    unsigned* probe = c.ws.get<unsigned>(8);
     float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     float* S2 = !a.twin ? nullptr : a.S2_pre ? a.S2_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
@@ -1333,8 +1357,11 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
         kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.Kp = Kp; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
         const int nb = cdiv(a.Ncols, 16);
         const size_t lds = (size_t)nb * 16 * (Kp + 4) * sizeof(float);
-        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));       // >= 1024 workgroups, >= 4 candidates each
+        // k_slice_b: >= 1024 workgroups, >= 4 candidates each (one per wave); k_slice_b2: every wave runs every candidate of its
+        // workgroup, the prologue (B -> registers) is paid per workgroup: >= 512 workgroups of >= 10 candidates
+        const int groups = v2 ? std::max(1, std::min(a.eq_n / 10, cdiv(512, Z))) : std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
         const dim3 grid(Z, groups), block(256);
+        const float qbias = (v2 && b.lo == -128 && b.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, probe) : 0.0f;   // 12 = 11: quant_fast1 in k_slice_b2 (A/B)
         const bool timed = g_stat_on;
         StatRec rec{};
         if (timed) {
@@ -1361,6 +1388,25 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
             case EPI_ABS: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_ABS); break;                                          \
             default: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_W_SQ); break;                                              \
         }
+        if (v2) {
+            SliceB2Params kp2{kp, qbias};
+#define P4V_LAUNCH_SB2(TW, KTM, NBW, E)                                                                          \
+            do {                                                                                                 \
+                if (qbias != 0.0f) hipLaunchKernelGGL((k_slice_b2<TW, KTM, NBW, E, true>), grid, block, 0, c.st, kp2);   \
+                else hipLaunchKernelGGL((k_slice_b2<TW, KTM, NBW, E, false>), grid, block, 0, c.st, kp2);        \
+            } while (0)
+#define P4V_LAUNCH_SB2_E(TW, KTM, NBW)                                                                           \
+            switch (a.epi) {                                                                                     \
+                case EPI_SQ_W: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_SQ_W); break;                                    \
+                case EPI_SQ: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_SQ); break;                                        \
+                case EPI_ABS: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_ABS); break;                                      \
+                default: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_W_SQ); break;                                          \
+            }
+            if (Kp == 64) { if (a.twin) P4V_LAUNCH_SB2_E(true, 1, 4) else P4V_LAUNCH_SB2_E(false, 1, 4) }
+            else { if (a.twin) P4V_LAUNCH_SB2_E(true, 4, 1) else P4V_LAUNCH_SB2_E(false, 4, 1) }
+#undef P4V_LAUNCH_SB2_E
+#undef P4V_LAUNCH_SB2
+        } else
         if (Kp == 64) { if (a.twin) P4V_LAUNCH_SB_E(true, 1, 13) else P4V_LAUNCH_SB_E(false, 1, 13) }
         else { if (a.twin) P4V_LAUNCH_SB_E(true, 4, 4) else P4V_LAUNCH_SB_E(false, 4, 4) }
 #undef P4V_LAUNCH_SB_E
@@ -1373,7 +1419,8 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
             g_stat_recs.push_back(rec);
         }
     }
-    FinishParams fp{part, (long)Z, 1L, 1, 1, Z, 1, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
+    const int pw = v2 ? 4 : 1;                          // floats per (candidate, batch entry): one per wave of k_slice_b2
+    FinishParams fp{part, (long)Z * pw, (long)pw, pw, 1, Z, pw, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
     CHK(launch_finish(c, fp));
     c.ws.off = mark;
     return 0;
@@ -1395,6 +1442,7 @@ int run_slice_a(Ctx& c, Pass& a, float* SA) {
     const size_t mark = c.ws.off;
     int8_t* Bp = c.ws.get<int8_t>((size_t)Z * nb * 16 * 64);
     float* part = c.ws.get<float>((size_t)a.eq_n * Z);
+    unsigned* probe = c.ws.get<unsigned>(8);
     float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     if (!a.s_ready) {
@@ -1414,6 +1462,7 @@ int run_slice_a(Ctx& c, Pass& a, float* SA) {
         kp.S1 = S1; kp.s_cs = a.s_cs; kp.s_div = a.sb_div;
         kp.O = a.O; kp.Wt = a.G ? a.G : a.O; kp.wt_mode = a.wt_mode;
         kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
+        kp.qbias = (r.lo == -128 && r.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, probe) : 0.0f;
         const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
         const dim3 grid(Z, groups), block(256);
         const bool timed = g_stat_on;
@@ -1908,6 +1957,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     if (cosm && !fwd_out && (nH > 1 || nA > 1)) return fail(P4V_ERR_UNSUPPORTED, "linear: cosine with n_H>1 / n_a>1 is not implemented on the GPU");
     const int ncand = d->eq_n + 1;
 
+    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
     // ---- interval initialisation (linear.py:380-397 / 576-599) ---------------------------------------
     unsigned* enc_w = c.ws.get<unsigned>((size_t)nV * nH);
     unsigned* enc_a = c.ws.get<unsigned>((size_t)nA);
@@ -2161,6 +2211,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     const bool cosm = epi == EPI_COS;
     if (wt_mode == 1 && !G && !fwd_out && sg.searches()) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
     if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
+    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
     const int ncand = d->eq_n + 1;
     const int NSPLIT = 20;  // matmul.py:636
 
@@ -2380,6 +2431,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     const bool aquant = d->a_bit < 32;
     const int aq = aquant ? (1 << (d->a_bit - 1)) : 0;
     if (aquant && !d->channelwise) return fail(P4V_ERR_UNSUPPORTED, "conv: the layer-wise class cannot search activations (reference conv.py:420 raises IndexError); use a_bit=32");
+    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
@@ -2889,6 +2941,9 @@ int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_
     if (d->mode == P4V_PLANE_SYM && d_scales && d->rows_per_scale <= 0) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: rows_per_scale");
     if (d->lo < -128 || d->hi > 127 || d->qmax < 2 || d->qmax > 128) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: grid wider than int8");
     Ctx c{(hipStream_t)stream, Arena(nullptr, 0), false};
+    // (first use of the process: the conversion quant16_sat8 relies on is probed into the head of the destination plane -- at
+    // least 64 bytes, overwritten by the pack below on the same stream)
+    cvt_bias(c, (d->rows * d->cols_padded >= 32) ? reinterpret_cast<unsigned*>(d_q) : nullptr);
     PackParams p = pack2d(d_x, d->rows, d->cols, d->cols);
     p.Rp = (int)d->rows; p.Kp = (int)d->cols_padded; p.dst = d_q; p.C = 1;
     p.scales = d_scales; p.sc_cs = 0; p.neg_scale = d->const_scale;

@@ -154,6 +154,7 @@ struct PackParams {
     const int* crange; int c_base; const unsigned char* done;
     // optional im2col gather (conv): logical r = (b, oy, ox), k = (ci, ki, kj)
     int conv, ic, H, W, kh, kw, sh, sw, ph, pw, dh, dw, fw, L;
+    float qbias;          // != 0 (set by launch_pack for PACK_SYM on the full symmetric 8-bit grid): quant16_sat8 with this bias
 };
 
 __device__ __forceinline__ float pack_value(const PackParams& p, float x, float s) {
@@ -226,6 +227,83 @@ __device__ __forceinline__ unsigned quant_fast1(float x, float r, float lo49, fl
     return __builtin_bit_cast(unsigned, biased);
 }
 
+// ---- exact 8-bit quantisation of 16 values at 4.5 VALU operations per element (round 5) --------------------------------------
+// clamp(rint(x / s), -128, 127) needs, per element, a product, a rounding, a clamp and a byte insert -- and the proof that
+// x * fl(1/s) rounds like the IEEE quotient the reference divides (linear.py:167).  quant_fast1 spends 6.75 operations on it
+// (mul, med3, add magic, sub, sub, max-abs, 3/4 perm).  v_cvt_pk_u8_f32 converts, SATURATES to [0, 255] and inserts the byte in
+// ONE operation, so with u = fma(x, r, bias) (one rounding of the exact product + bias; bias = 128.5 where the conversion
+// truncates, 128 where it rounds to nearest -- probed once per process, k_probe_cvt) the grid index + 128 is two operations,
+// and the proof is the same two operations again with the bias moved: lo = cvt(fma(x, r, bias - d)), hi = cvt(fma(x, r, bias + d)),
+// d = 2^-14.  With q = fl(x / s): |x r - q| <= 3 * 2^-24 |x / s| <= 2.3e-5 inside the unsaturated range and the fma's own rounding
+// is <= 2^-16 below 512, so u_lo < q + bias < u_hi strictly, by more than 2e-5 on either side; the conversion is monotone, hence
+// lo <= cvt(q + bias) <= hi, and where q is an exact tie (q + bias lands on the conversion's own breakpoint) lo != hi.  So
+// lo == hi  =>  that byte is clamp(rint(q), -128, 127) + 128; a dword whose four bytes do not all agree (1.2e-4 of the elements sit
+// within d of a breakpoint: 0.05 % of the dwords) is redone with the IEEE division, as is everything when 1/s overflowed.  One
+// xor turns the four biased bytes into two's complement.  Only for the full symmetric 8-bit grid (the saturation IS the clamp);
+// other grids keep quant_fast1.
+__global__ void k_probe_cvt(unsigned* out) {
+    const float v[5] = {0.7f, 1.5f, 2.5f, -3.0f, 300.0f};
+    if (threadIdx.x < 5) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(v[threadIdx.x], 0u, 0u);
+}
+static constexpr float QUANT_D = 6.103515625e-05f;                 // 2^-14
+__device__ __forceinline__ void quant16_sat8(const float (&x)[16], float s, float rcp, float qbias, v4i& out) {
+    const float b1 = qbias - QUANT_D, b2 = qbias + QUANT_D;
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lo[q] = 0u; hi[q] = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[q] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x[q * 4 + e], rcp, b1), (unsigned)e, lo[q]);
+            hi[q] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x[q * 4 + e], rcp, b2), (unsigned)e, hi[q]);
+        }
+    }
+    const bool inf = !(rcp < 3.0e38f);
+    const bool bad = inf || lo[0] != hi[0] || lo[1] != hi[1] || lo[2] != hi[2] || lo[3] != hi[3];
+    if (__any(bad)) {
+        float sd = s;
+        asm volatile("" : "+v"(sd));       // the divisions depend on this: they cannot be hoisted out of the rare branch
+        if (bad) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (inf || lo[q] != hi[q]) {
+                    unsigned w = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fminf(fmaxf(rintf(x[q * 4 + e] / sd), -128.0f), 127.0f);
+                        w |= (unsigned)(((int)v + 128) & 0xff) << (8 * e);
+                    }
+                    lo[q] = w;
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = (int)(lo[q] ^ 0x80808080u);
+}
+// ... and the general grid (any clamp, <= 8 bit): quant_fast1 + its exactness check (k_pack's hot path)
+__device__ __forceinline__ void quant16_any(const float (&x)[16], float s, float rcp, float flo, float fhi, bool wide, v4i& out) {
+    unsigned qb[16];
+    float maxdev = 0.0f, magic = PACK_MAGIC;
+    asm volatile("" : "+v"(magic));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) qb[e] = quant_fast1(x[e], rcp, flo - 0.49f, fhi + 0.49f, magic, maxdev);
+    const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || wide;
+    if (__any(bad)) {
+        float sd = s;
+        asm volatile("" : "+v"(sd));
+        if (bad) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), flo), fhi) + PACK_MAGIC);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
+        const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
+        out[q] = (int)(lo16 | (hi16 << 16));
+    }
+}
+
 // One thread owns 16 consecutive k of one (z, r) for a group of PACK_CG candidates (blockIdx.y): the source
 // (L2 / Infinity-Cache resident: it is re-read once per candidate group) is loaded once per group, the scales
 // are loaded up front, and every plane is written as one contiguous stream of full 16-byte (int8) /
@@ -292,7 +370,12 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
             if constexpr (sizeof(T) == 1) {
                 const float s = sc[j];
                 int w[4];
-                if (p.mode == PACK_SYM && live && kc * 16 + 16 <= p.K) {
+                if (p.mode == PACK_SYM && live && kc * 16 + 16 <= p.K && p.qbias != 0.0f) {
+                    // hot path on the full symmetric 8-bit grid: 4.5 operations per element (quant16_sat8)
+                    v4i o4;
+                    quant16_sat8(x, s, 1.0f / s, p.qbias, o4);
+                    w[0] = o4[0]; w[1] = o4[1]; w[2] = o4[2]; w[3] = o4[3];
+                } else if (p.mode == PACK_SYM && live && kc * 16 + 16 <= p.K) {
                     // hot path: symmetric grid, no padding inside this 16-element run
                     const float rcp = 1.0f / s, flo = (float)p.lo, fhi = (float)p.hi;
                     unsigned qb[16];
@@ -1870,6 +1953,105 @@ __global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) {
     }
 }
 
+// k_slice_b2 (round 5): k_slice_b with B in REGISTERS.  k_slice_b dealt the candidates over the four waves: every wave
+// re-read all of B (fp32) from the LDS for each of its candidates -- 4 KB of ds_read_b128 and the address arithmetic per 1 KB
+// fragment, ~200 instructions per fragment, VALU-bound at 0.015 of the matrix peak.  Here the waves deal the 16-COLUMN BLOCKS
+// of B instead (q.k^T: 13 blocks of one k-tile -> 4 / 3 / 3 / 3; attn.v: 4 blocks of 4 k-tiles -> one each): a lane keeps its
+// 16 fp32 values of each of its (at most 4) fragments for the whole kernel, every wave works on EVERY candidate and quantises
+// only its own fragments (quant16_sat8 on the symmetric 8-bit grid: 4.5 operations per element), and writes one float per
+// (candidate, batch entry, wave); k_finish adds the four.  No LDS, no candidate planes.
+struct SliceB2Params {
+    SliceBParams b;
+    float qbias;            // bias of quant16_sat8's conversion (k_probe_cvt); 0: the conversion is not usable -> SAT8 must be false
+};
+template <bool TWIN, int KTM, int NBW, int EPI, bool SAT8>
+__global__ __launch_bounds__(256, 2) void k_slice_b2(SliceB2Params pp) {
+    const SliceBParams& p = pp.b;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int z = blockIdx.x;
+    const int ktn = p.Kp / 64, nb = (p.N + 15) / 16;
+    const int per = (p.C + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * per, c_hi = min(p.C, c_lo + per);
+    const float* Bz = p.B + (p.zdiv > 0 ? (long)(z / p.zdiv) * p.b_z2 + (long)(z % p.zdiv) * p.b_z : (long)z * p.b_z);
+    // ---- this wave's fragments of B (fp32): block j = wid + 4 i, k-tile kt; lane (l4, l15) holds k = 64 kt + 16 l4 + e of column 16 j + l15
+    float xb[NBW][KTM][16];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = (wid + 4 * i) * 16 + l15, k = kt * 64 + l4 * 16 + e;
+                const bool ok = n < p.N && k < p.K;
+                const float v = Bz[(long)min(n, p.N - 1) * p.b_n + (long)min(k, p.K - 1) * p.b_k];
+                xb[i][kt][e] = ok ? v : 0.0f;
+            }
+    // ---- fixed fragments of the slice (16 rows x 64 B per k-tile: lane (l4, l15) holds bytes [16 l4, +16) of row l15) -----------
+    v4i fa[KTM], fa2[KTM];
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) {
+        const long off = ((long)z * 16 + l15) * p.Kp + (long)min(kt, ktn - 1) * 64 + l4 * 16;
+        fa[kt] = *reinterpret_cast<const v4i*>(p.A + off);
+        if (TWIN) fa2[kt] = *reinterpret_cast<const v4i*>(p.A2 + off);
+    }
+    // ---- raw_out / metric weight of this wave's 16 x 16 blocks in accumulator layout: lane -> column l15, rows 4 l4 + e ----------
+    float u[NBW][4], w[NBW][4];
+    const int wm = p.wt_mode;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = wid + 4 * i;
+            const int n = j * 16 + l15, m = 4 * l4 + e;
+            const bool ok = j < nb && n < p.N && m < p.M;
+            const long idx = ((long)z * 16 + min(m, 15)) * p.N + min(n, p.N - 1);
+            const float o = p.O[idx], gw = p.Wt[idx];
+            float wv;
+            if (wm == 1) wv = gw; else if (wm == 2) wv = o; else if (wm == 3) wv = fabsf(o); else wv = 1.0f;
+            u[i][e] = ok ? o : 0.0f;
+            w[i][e] = ok ? wv : 0.0f;
+        }
+    const int sbz = p.bs_div > 0 ? z % p.bs_div : 0, ssz = p.s_div > 0 ? z % p.s_div : 0;
+    const float flo = (float)p.lo, fhi = (float)p.hi;
+    const bool wide = !(fmaxf(-flo, fhi) < 129.0f);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float s = p.bscale[(long)c * p.bs_cs + sbz];
+        const float rcp = 1.0f / s;
+        const float s1 = p.S1 ? p.S1[(long)c * p.s_cs + ssz] : 1.0f;
+        const float s2 = (TWIN && p.S2) ? p.S2[(long)c * p.s_cs + ssz] : 1.0f;
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (wid + 4 * i < nb) {                                  // (wave-uniform guard, no break: the loop must unroll -- xb / u / w are registers)
+                v4i acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < KTM; ++kt) {
+                    if (kt < ktn) {
+                        v4i fb;
+                        if constexpr (SAT8) quant16_sat8(xb[i][kt], s, rcp, pp.qbias, fb);
+                        else quant16_any(xb[i][kt], s, rcp, flo, fhi, wide, fb);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[kt], fb, acc, 0, 0, 0);
+                        if (TWIN) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[kt], fb, acc2, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = u[i][e] - (float)acc[e] * s1;
+                    if (TWIN) d -= (float)acc2[e] * s2;
+                    const float ww = w[i][e];
+                    if (EPI == EPI_SQ_W) { const float t2 = ww * d; sum = fmaf(t2, t2, sum); }
+                    else if (EPI == EPI_ABS) sum = fmaf(ww, fabsf(d), sum);
+                    else sum = fmaf(ww * d, d, sum);                        // EPI_SQ (w = validity mask) and EPI_W_SQ
+                }
+            }
+        }
+        sum = wave_sum_dpp(sum);
+        if (lane == 63) p.part[((long)c * p.Z + z) * 4 + wid] = sum;
+    }
+}
+
 // k_slice_a: the same for a MatMul A search with K <= 64 (q.k^T): the EXPANDED operand is the 16-row slice itself -- a lane keeps
 // its 16 fp32 values of the slice in registers and re-quantises them per candidate (one fragment), the fixed operand B (int8,
 // packed once: [Z][NB * 16][64]) stays in registers as NB fragments.  One workgroup per (image, head), candidates dealt over
@@ -1883,6 +2065,7 @@ struct SliceAParams {
     const float* O; const float* Wt; int wt_mode;           // [Z][16][N]
     int Z, M, K, N, C;
     float* part;                                            // [C][Z]
+    float qbias;                                            // != 0: quant16_sat8 (symmetric 8-bit grid; bias from k_probe_cvt), else quant_fast1
 };
 template <int NBM, int EPI>
 __global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
@@ -1925,27 +2108,9 @@ __global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
         const float s = p.ascale[(long)c * p.as_cs + saz];
         const float rcp = 1.0f / s;
         const float s1 = p.S1 ? p.S1[(long)c * p.s_cs + ssz] : 1.0f;
-        unsigned qb[16];
-        float maxdev = 0.0f, magic = PACK_MAGIC;
-        asm volatile("" : "+v"(magic));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) qb[e] = quant_fast1(x[e], rcp, flo - 0.49f, fhi + 0.49f, magic, maxdev);
-        const bool bad = !(maxdev <= 0.49996f) || !(rcp < 3.0e38f) || wide;
-        if (__any(bad)) {
-            float sd = s;
-            asm volatile("" : "+v"(sd));
-            if (bad) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) qb[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(rintf(x[e] / sd), flo), fhi) + PACK_MAGIC);
-            }
-        }
-        v4i_ fa;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned lo16 = __builtin_amdgcn_perm(qb[q * 4 + 1], qb[q * 4], 0x0c0c0400u);
-            const unsigned hi16 = __builtin_amdgcn_perm(qb[q * 4 + 3], qb[q * 4 + 2], 0x0c0c0400u);
-            fa[q] = (int)(lo16 | (hi16 << 16));
-        }
+        v4i fa;
+        if (p.qbias != 0.0f) quant16_sat8(x, s, rcp, p.qbias, fa);
+        else quant16_any(x, s, rcp, flo, fhi, wide, fa);
         float sum = 0.0f;
         const v4i_ zero4 = {0, 0, 0, 0};
 #pragma unroll

@@ -106,6 +106,45 @@ def test_symmetric_plane_and_fake_quant_bit_exact(eng, lo, hi):
     np.testing.assert_array_equal(y.cpu().numpy(), fake_quant(x, rows_s, lo, hi))
 
 
+def test_sat8_quantiser_is_the_ieee_division_on_and_around_every_breakpoint(eng):
+    """quant16_sat8 (round 5: fma + v_cvt_pk_u8_f32 twice, 4.5 operations per element, csrc/p4v_kernels.h) against numpy's IEEE
+    division on the inputs built to break it: for seven scales (a power of two, values whose reciprocal rounds up / down, tiny,
+    huge) every breakpoint (k + 0.5) s of the 8-bit grid, its two fp32 neighbours on either side, the saturation ends and far
+    beyond, zeros, and 200 000 random values (1.2e-4 of them fall into the quantiser's flagged band and take the division).
+    The same plane with the quantiser switched off (tuning 12 = 11: quant_fast1) must be identical too."""
+    from oracle.ptq4vit_oracle import quant_int
+    rng = np.random.default_rng(5)
+    scales = np.array([0.25, 0.0371, 1.0 / 3.0, 0.011, 3e-7, 1.7e5, 0.7], dtype=np.float32)
+    rows = []
+    for s in scales:
+        k = np.arange(-135, 135, dtype=np.float32)
+        b = ((k + np.float32(0.5)) * s).astype(np.float32)
+        cases = [b]
+        for step in (1, 2):
+            lo_n, hi_n = b.copy(), b.copy()
+            for _ in range(step):
+                lo_n, hi_n = np.nextafter(lo_n, np.float32(-np.inf)), np.nextafter(hi_n, np.float32(np.inf))
+            cases += [lo_n, hi_n]
+        cases.append(np.array([0.0, -0.0, 127 * s, 128 * s, -128 * s, -129 * s, 1e30, -1e30, 3e38, -3e38, s, -s, s / 2, -s / 2], dtype=np.float32))
+        cases.append((rng.standard_normal(200000) * 60 * s).astype(np.float32))
+        row = np.concatenate(cases)
+        rows.append(row)
+    n = max(len(r) for r in rows)
+    n = (n + 15) // 16 * 16
+    x = np.zeros((len(scales), n), dtype=np.float32)
+    for i, r in enumerate(rows):
+        x[i, :len(r)] = r
+    want = quant_int(x, scales[:, None], -128, 127)
+    got, _ = eng.pack_plane_i8(_t(x), mode="sym", scales=torch.from_numpy(scales), rows_per_scale=1, lo=-128, hi=127, qmax=128)
+    np.testing.assert_array_equal(got.cpu().numpy()[:, :n], want)
+    try:
+        eng.debug_tuning(12, 11)
+        old, _ = eng.pack_plane_i8(_t(x), mode="sym", scales=torch.from_numpy(scales), rows_per_scale=1, lo=-128, hi=127, qmax=128)
+    finally:
+        eng.debug_tuning(12, 0)
+    np.testing.assert_array_equal(old.cpu().numpy()[:, :n], want)
+
+
 # ---- integer export (row f-3) -----------------------------------------------------------------------------------------
 def _calibrated_mini_on_gpu():
     from ptq4vit_amd.configs import PTQ4ViT
