@@ -134,7 +134,8 @@ struct Ctx {
 // are written by their kernel into mapped host memory as well and read after the stream synchronisation the host does anyway:
 // no copy command (a pageable hipMemcpyAsync is a blit kernel into a staging buffer between two waits: ~410 range read-backs
 // and ~270 interval read-backs per ViT-B calibration).  One block per stream, allocated at the stream's first use (the
-// calibrator's streams are persistent), never freed: 16 ints (ranges, weight share) + MIR_SLOTS interval vectors of MIR_SLOT floats.
+// calibrator's streams are persistent), never freed: 32 ints ([0,1] / [2,3] survivor ranges of the two tiers, [4] weight share, [8..15] / [16..23]
+// their per-score-block ranges) + MIR_SLOTS interval vectors of MIR_SLOT floats.
 // p4v_debug_set_tuning(12, 8): the copy path (A/B).
 constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
 int* host_mirror(hipStream_t st) {
@@ -144,7 +145,7 @@ int* host_mirror(hipStream_t st) {
     auto it = tab.find((void*)st);
     if (it != tab.end()) return it->second;
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64 + sizeof(float) * MIR_SLOT * MIR_SLOTS, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    if (hipHostMalloc(&p, 128 + sizeof(float) * MIR_SLOT * MIR_SLOTS, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
     tab[(void*)st] = (int*)p;
     return (int*)p;
 }
@@ -430,9 +431,12 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups);
 // one is mostly empty (ViT-B qkv: 900 tiles = 3.5 waves).  The tiles of the last, partial wave are launched separately
 // with their candidates split over q groups, so that it takes a fraction of a full wave's time; every group pays
 // the workgroup prologue (stationary operand + raw_out / raw_grad tile) again.  Cost model in microseconds.
-int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
+int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups, int nc_model = 0) {
     if (c.dry) return 0;
-    const int tiles = p.stiles * p.ttiles, nc = p.c1 - p.c0;
+    // (p.ntile > 0: only the tiles [p.tile0, p.tile0 + p.ntile) -- the open score blocks of a pruned pass; nc_model: the number of
+    // candidates the device-side range leaves, when the host knows it)
+    const int tiles = p.ntile > 0 ? p.ntile : p.stiles * p.ttiles, base = p.ntile > 0 ? p.tile0 : 0;
+    const int nc = nc_model > 0 ? nc_model : p.c1 - p.c0;
     const int full = tiles / 256 * 256, rem = tiles - full;
     const double P = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
     auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
@@ -447,12 +451,14 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
     if (q_best > 0) {
         Sweep3Params a = p, b = p;
-        a.tile0 = 0; a.ntile = full;
-        b.tile0 = full; b.ntile = rem;
+        a.tile0 = base; a.ntile = full;
+        b.tile0 = base + full; b.ntile = rem;
         CHK(launch_sweep6_part(c, a, epi, 1));
         CHK(launch_sweep6_part(c, b, epi, q_best));
     } else {
-        CHK(launch_sweep6_part(c, p, epi, cgroups));
+        Sweep3Params a = p;
+        a.tile0 = base; a.ntile = p.ntile > 0 ? tiles : 0;
+        CHK(launch_sweep6_part(c, a, epi, cgroups));
     }
     return 0;
 }
@@ -774,6 +780,8 @@ struct Pass {
     const int* crange;
     const int* crange_blk;    // ... and per score block [2 * nj] (k_prune_hull's rblk): honoured where the sweep kernel's tiles lie inside
                               // one score block (run_pass decides; otherwise every block sweeps `crange`, a superset)
+    int host_lo, host_hi;     // what the host read of `crange` (host_hi > host_lo: known) -- the launch geometry is planned for the
+    const int* host_rblk;     // candidates that will run -- and of `crange_blk` (nj <= 4; nullptr: unknown): closed blocks are not launched
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
@@ -1043,10 +1051,41 @@ int run_pass(Ctx& c, Pass& ps) {
             if (regs6) {
                 // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
                 q.stiles = s6_stiles; q.ttiles = s6_ttiles; q.E = epi6; q.crange_blk = rblk;
-                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc, q.ktiles, 256, tune(TUNE_P6) > 0 ? 0.125 * tune(TUNE_P6) : 25.0, 0.14);
+                // what the host knows of the device-side range: the launch geometry is planned for the candidates that will run
+                const bool known = ps.crange && ps.host_hi > ps.host_lo && tune(TUNE_B1_PATH) != 12;
+                const int nc_known = known ? std::max(1, std::min(ps.host_hi, c0 + nc) - std::max(ps.host_lo, c0)) : nc;
+                const double P6 = tune(TUNE_P6) > 0 ? 0.125 * tune(TUNE_P6) : 25.0;
+                if (rblk && known && ps.host_rblk && ps.nj <= 4) {
+                    // per-score-block ranges known to the host: one launch per run of OPEN blocks (a closed block -- its only survivor
+                    // is its stage-A winner -- has nothing to sweep: the q block of a ViT qkv layer); score block j = streaming
+                    // tiles [j, j + 1) * sb_div / 64
+                    const int tpb = ps.sb_div / 64;
+                    for (int j = 0; j < ps.nj;) {
+                        if (ps.host_rblk[2 * j + 1] <= ps.host_rblk[2 * j]) { ++j; continue; }
+                        int j1 = j, lo = INT_MAX, hi = 0;
+                        double fsum = 0;
+                        for (; j1 < ps.nj && ps.host_rblk[2 * j1 + 1] > ps.host_rblk[2 * j1]; ++j1) {
+                            const int l = std::max(ps.host_rblk[2 * j1], c0), h = std::min(ps.host_rblk[2 * j1 + 1], c0 + nc);
+                            lo = std::min(lo, l); hi = std::max(hi, h);
+                            fsum += std::max(0, h - l);
+                        }
+                        Sweep3Params qq = q;
+                        const int tt0 = j * tpb, tt1 = std::min(q.ttiles, j1 * tpb);
+                        qq.tile0 = tt0 * q.stiles; qq.ntile = (tt1 - tt0) * q.stiles;
+                        const int ncr = std::max(1, hi - lo);
+                        g_exec_frac = fsum / ((double)(j1 - j) * nc);
+                        int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, 256, P6, 0.14);
+                        if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(ncr, tune(TUNE_CG6)));
+                        if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 open blocks [%d, %d): tiles %d x %d ktiles %d cand %d -> cgroups %d\n", j, j1, q.stiles, tt1 - tt0, q.ktiles, ncr, cg6);
+                        if (hi > lo && qq.ntile > 0) CHK(launch_sweep6(c, qq, ps.epi, cg6, ncr));
+                        j = j1;
+                    }
+                    continue;
+                }
+                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, 256, P6, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
-                if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, cg6);
-                CHK(launch_sweep6(c, q, ps.epi, cg6));
+                if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d (%d known) -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, nc_known, cg6);
+                CHK(launch_sweep6(c, q, ps.epi, cg6, known ? nc_known : 0));
                 continue;
             }
             const long wgs = (long)q.stiles * q.ttiles;
@@ -1629,7 +1668,10 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2; pp.rblk = rblk2;
     int* hm = (ps.host_sync_ok && !c.dry && tune(TUNE_B1_PATH) != 8) ? host_mirror(c.st) : nullptr;
-    pp.r_host = hm;
+    pp.r_host = hm; pp.rblk_host = hm ? hm + 8 : nullptr;
+    int hblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // host copy of the per-block ranges stage A2 / B2 run on (nj <= 4)
+    int hlo = 0, hhi = 0;
+    bool hblk_ok = false;
     const bool hull_selects = !ps.scores_out && ps.interval && (virt || ps.nj <= 32);   // (its non-virt selection is serial over the blocks)
     SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
                      ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
@@ -1658,6 +1700,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         if (hm) { h[0] = reinterpret_cast<volatile int*>(hm)[0]; h[1] = reinterpret_cast<volatile int*>(hm)[1]; }
         if (h[0] >= h[1]) return select_without_b2();
         nsurv = h[1] - h[0];
+        hlo = h[0]; hhi = h[1];
+        if (hm && ps.nj <= 4) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[8 + i]; hblk_ok = true; }
     }
     // second tier: many survivors of a slice that holds well under all of the weight -> sweep THEM over the larger slice first
     const int* rB = r2;
@@ -1672,12 +1716,15 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         if (ps.twin) sliced2(a2.row2.pk);
         a2.cache = ps.col.expanded ? ps.cache : ps.cache ? &sc2->aplane : nullptr;
         a2.ecache = nullptr; a2.scores_keep = SA2; a2.no_select = true; a2.crange = r2; a2.crange_blk = rblk2;
+        int hblk_a2[8];                                   // (stage A2 runs on the first tier's ranges; the second hull overwrites hblk)
+        std::copy(hblk, hblk + 8, hblk_a2);
+        a2.host_lo = hlo; a2.host_hi = hhi; a2.host_rblk = hblk_ok ? hblk_a2 : nullptr;
         a2.S1_pre = S1s; a2.S2_pre = S2s; a2.s_ready = true;
         g_stage = 4;
         { const int r_ = run_pass(c, a2); g_stage = 0; if (r_) return r_; }
         if (!c.dry) {
             PruneParams pp2 = pp;                 // same bound L* (stage B1's totals), the tighter partial sums, hull into r3
-            pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3;
+            pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3; pp2.rblk_host = hm ? hm + 16 : nullptr;
             hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp2, hsl);
             HIPCHK(hipGetLastError());
             int h[2] = {0, 1};
@@ -1687,11 +1734,15 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] second tier: %d survivors of the %d-row slice -> %d of the %d-row slice (M %d N %d K %d)\n", nsurv, k, std::max(0, h[1] - h[0]), k2, ps.Mrows, ps.Ncols, ps.K);
             if (h[0] >= h[1]) return select_without_b2();
             rB = r3; rBblk = rblk3;
+            hlo = h[0]; hhi = h[1];
+            if (hm && ps.nj <= 4) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[16 + i]; }
+            else hblk_ok = false;
         }
     }
     // stage B2: whatever else survives, on all samples (an empty range when stage B1 already covers the survivors)
     Pass b2 = ps;
     b2.crange = rB; b2.crange_blk = rBblk; b2.scores_keep = S2; b2.no_select = true;
+    b2.host_lo = hlo; b2.host_hi = hhi; b2.host_rblk = hblk_ok ? hblk : nullptr;
     b2.S1_pre = S1s; b2.S2_pre = S2s; b2.s_ready = true;
     g_stage = 3;
     { const int r_ = run_pass(c, b2); g_stage = 0; if (r_) return r_; }
@@ -1904,7 +1955,7 @@ struct MirrorScope {
         float* base = (on && !c.dry && tune(TUNE_B1_PATH) != 8) ? reinterpret_cast<float*>(host_mirror(c.st)) : nullptr;
         const float* devs[MIR_SLOTS] = {a, b, d3};
         for (int i = 0; i < MIR_SLOTS; ++i)
-            g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + 16 + i * MIR_SLOT : nullptr, false, 0};
+            g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + 32 + i * MIR_SLOT : nullptr, false, 0};
     }
     ~MirrorScope() { for (auto& m : g_mir) m = IvMirror{}; }
     MirrorScope(const MirrorScope&) = delete;

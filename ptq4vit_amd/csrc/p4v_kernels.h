@@ -245,9 +245,14 @@ __global__ void k_probe_cvt(unsigned* out) {
     const float v[5] = {0.7f, 1.5f, 2.5f, -3.0f, 300.0f};
     if (threadIdx.x < 5) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(v[threadIdx.x], 0u, 0u);
 }
+// The band, tightened for the conversion this part has (round to nearest: bias 128): |x r - q| <= 2 * 2^-24 * 128.5 = 1.53e-5
+// (r = fl(1/s) and q = fl(x/s) are each within 2^-24 of the quotient) + the fma's own rounding, at most 2^-17 = 7.6e-6 below 256
+// (above, both conversions saturate) = 2.3e-5; the two biases are the nearest floats that clear it: 128 - 5 * 2^-17 (3.8e-5) and
+// 128 + 2 * 2^-16 (3.05e-5): 6.9e-5 of the elements are flagged.  Any other bias (a truncating conversion): 2^-14 on either side.
 static constexpr float QUANT_D = 6.103515625e-05f;                 // 2^-14
 __device__ __forceinline__ void quant16_sat8(const float (&x)[16], float s, float rcp, float qbias, v4i& out) {
-    const float b1 = qbias - QUANT_D, b2 = qbias + QUANT_D;
+    const bool rne = qbias == 128.0f;
+    const float b1 = rne ? 127.99996185302734375f : qbias - QUANT_D, b2 = rne ? 128.000030517578125f : qbias + QUANT_D;
     unsigned lo[4], hi[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -3820,7 +3825,8 @@ __global__ __launch_bounds__(128) void k_select(SelectParams p) {          // on
 struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; const int* r_in; int* r_out;
                      int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow;
                      int* r_host;         // optional mirror of r_out in mapped host memory (read by the host after its stream sync)
-                     int* rblk; };        // optional per-score-block survivor ranges [2 * nj] (see prune_hull)
+                     int* rblk;           // optional per-score-block survivor ranges [2 * nj] (see prune_hull)
+                     int* rblk_host; };   // optional mirror of rblk in mapped host memory, written when nj <= 4 (8 ints)
 // (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
 // r_out = hull over the blocks of stage A's first maxima
 #define PRUNE_WIDE_NJ 64        // from this many score blocks on: one THREAD per block (channel-wise weights: hundreds of blocks)
@@ -3956,7 +3962,13 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
     if (p.rblk) {
         // per-block ranges: the block's own hull (virt, healthy); the global range otherwise (NaN anywhere: everything)
         const bool per_blk = p.virt && !bad_s && !empty_s;
-        if (narrow) { for (int j = threadIdx.x; j < p.nj; j += 256) { p.rblk[2 * j] = per_blk ? sblk[3 * j] : lo_s; p.rblk[2 * j + 1] = per_blk ? sblk[3 * j + 1] : hi_s; } }
+        if (narrow) {
+            for (int j = threadIdx.x; j < p.nj; j += 256) {
+                const int l = per_blk ? sblk[3 * j] : lo_s, h = per_blk ? sblk[3 * j + 1] : hi_s;
+                p.rblk[2 * j] = l; p.rblk[2 * j + 1] = h;
+                if (p.rblk_host && p.nj <= 4) { p.rblk_host[2 * j] = l; p.rblk_host[2 * j + 1] = h; }
+            }
+        }
         else if (!per_blk) { for (int j = threadIdx.x; j < p.nj; j += 256) { p.rblk[2 * j] = lo_s; p.rblk[2 * j + 1] = hi_s; } }
     }
     return empty_s != 0;

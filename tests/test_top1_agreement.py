@@ -10,9 +10,9 @@ one on 933 / 1 000 -- random weights, noise images: the margins are of the size 
 
   * CPU: this repository's module classes with the REFERENCE's intervals installed reproduce the reference's prediction on every
     one of the 1 000 images (fp32 fake-quant forward, the arithmetic of linear.py:62-67 / matmul.py:140-145 / conv.py:609-614).
-  * GPU: the same through the int8 MFMA `quant_forward` (exact integer GEMMs, scales in the epilogue): every image whose margin
-    exceeds the fp32 noise of LayerNorm / softmax / GELU between the two machines; then the network calibrated BY THE ENGINE
-    on the same 4 images: top-1 against the raw network's labels next to the reference's 93.3 %, and image-by-image agreement.
+  * GPU: every module of the network through the int8 MFMA `quant_forward` against the CPU module on the same input (fp32
+    rounding); then top-1 against the raw network's labels for the reference-calibrated and the ENGINE-calibrated network next
+    to the reference's 93.3 % (image-by-image equality across machines is not a property a re-quantising network has: see the test).
 
 The day P4V_IMAGENET / P4V_WEIGHTS exist (tools/eval_top1.py) the only unknown left is the data.
 """
@@ -76,29 +76,45 @@ def test_reference_intervals_reproduce_the_reference_top1_on_1000_images_cpu():
 
 @pytest.mark.gpu
 def test_int8_quant_forward_and_engine_calibration_against_the_reference_top1_on_1000_images():
+    """(a) MODULE BY MODULE: each of the 74 wrapped modules of the GPU network (int8 MFMA quant_forward, reference intervals) fed
+    the input the CPU network's module saw reproduces the CPU module's output to fp32 rounding (measured 3e-7 .. 8e-7 of the
+    output range) -- the inference path is the reference's arithmetic at full DeiT-tiny size.
+    (b) THE NETWORK cannot be compared image by image across machines: LayerNorm / softmax / GELU differ by ~1e-6 between the
+    GPU and the CPU, the next module RE-QUANTISES its input, one activation that lands on the other side of a rounding boundary
+    moves an output by a whole grid step (1.8e-3 of the output range after the first block's qkv, measured), and from the third
+    block on the two runs differ by the quantisation error itself (2e-2 of the logit range; tools/diff_quant_forward.py) --
+    as would the reference on a GPU against the reference on a CPU.  What is comparable is the statistic the reference reports
+    (example/test_vit.py:26-45): top-1 over the evaluation set -- here against the raw network's predictions as labels -- for
+    the reference-calibrated network on this GPU, the ENGINE-calibrated network on this GPU, and the reference's own run (93.3 %)."""
     from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
     fx = np.load(EVAL, allow_pickle=False)
     ev = _eval_images(fx)
-    rng = float(fx["logit_range"])
     ref_pred, margin, raw_label = fx["quant_argmax"].astype(np.int64), fx["quant_margin"], fx["raw_argmax"].astype(np.int64)
-    # (a) the inference path: the reference's intervals through the int8 quant_forward
+    rng = float(fx["logit_range"])
+    # (a) every module alone, on the CPU network's own inputs
+    net_c, wr_c = _net_with_reference_intervals("cpu")
     net, wrapped = _net_with_reference_intervals("cuda")
-    q = _predict(net, ev, "cuda", 100)
-    pred = q.argmax(1).numpy()
-    head_err = float((q[:16] - torch.from_numpy(fx["quant_logits_head"])).abs().max()) / rng
-    NOISE = 2e-3 * rng                    # fp32 LayerNorm / softmax / GELU on another machine: one activation in a million lands on the
-    clear = margin > NOISE                # other side of a rounding boundary and moves the logits by a fraction of the quantisation error
-    same = pred == ref_pred
-    print(f"[top1] GPU int8 quant_forward, reference intervals: {int(same.sum())}/1000 predictions equal to the reference's "
-          f"({int(clear.sum())} images with a margin above {NOISE:.1e}: {int((same & clear).sum())} equal); first 16 images' logits to {head_err:.1e} of the range")
-    assert head_err <= 1e-3, head_err
-    assert (same | ~clear).all(), f"{int((~same & clear).sum())} clear-margin predictions differ"
-    assert same.mean() >= 0.99
-    # (b) calibrated by the engine on the same 4 images
+    seen = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, _n=n: seen.__setitem__(_n, ([t.detach().clone() for t in inp], out.detach().clone())))
+             for n, m in wr_c.items()]
+    with torch.no_grad():
+        net_c(ev[:4])
+    for h in hooks:
+        h.remove()
+    worst = (0.0, "")
+    for n, m in wrapped.items():
+        ins, out_c = seen[n]
+        with torch.no_grad():
+            out_g = m(*[t.cuda() for t in ins]).float().cpu()
+        err = float((out_g - out_c).abs().max()) / (float(out_c.abs().max()) + 1e-30)
+        worst = max(worst, (err, n))
+        assert err <= 1e-5, f"{n} ({type(m).__name__}): int8 quant_forward leaves the fp32 fake-quant forward by {err:.2e} of the output range"
+    del net_c, wr_c, seen
+    # (b) the network on this GPU: reference-calibrated, then engine-calibrated
+    pred = _predict(net, ev, "cuda", 100).argmax(1).numpy()
     for m in wrapped.values():
         m.mode = "raw"
-    with torch.no_grad():
-        raw_gpu = _predict(net, ev, "cuda", 100).argmax(1).numpy()
+    raw_gpu = _predict(net, ev, "cuda", 100).argmax(1).numpy()
     images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
 
     class Loader:
@@ -110,16 +126,16 @@ def test_int8_quant_forward_and_engine_calibration_against_the_reference_top1_on
     with contextlib.redirect_stdout(io.StringIO()):
         HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4).batching_quant_calib()
     mine = _predict(net, ev, "cuda", 100).argmax(1).numpy()
-    acc_ref = float((ref_pred == raw_label).mean())
-    acc_eng = float((mine == raw_gpu).mean())
-    agree = float((mine == ref_pred).mean())
-    agree_clear = float((mine == ref_pred)[margin > 0.02 * rng].mean()) if (margin > 0.02 * rng).any() else 1.0
-    print(f"[top1] engine-calibrated DeiT-tiny/224 BasePTQ x4: top-1 against the raw network's labels {100 * acc_eng:.1f} % "
-          f"(reference-calibrated, reference's own evaluation: {100 * acc_ref:.1f} %); same prediction as the reference on {100 * agree:.1f} % of "
-          f"the images, {100 * agree_clear:.1f} % of those whose reference margin exceeds 2 % of the logit range "
-          f"(raw labels GPU vs reference CPU: {int((raw_gpu == raw_label).sum())}/1000)")
-    # the margins of a random-weight network on noise images are of the size of the quantisation error itself (the reference's own
-    # quantised network keeps 93.3 % of the raw predictions), so an interval one grid step away -- a near-tie of the reference's
-    # cosine tables, tests/test_hip_model.py -- re-draws some predictions: bounds, not equalities
-    assert abs(acc_eng - acc_ref) <= 0.03, (acc_eng, acc_ref)
-    assert agree >= 0.85 and agree_clear >= 0.97, (agree, agree_clear)
+    acc_ref = float((ref_pred == raw_label).mean())            # the reference's own run (CPU)
+    acc_gpu = float((pred == raw_gpu).mean())                  # the reference's intervals on this GPU
+    acc_eng = float((mine == raw_gpu).mean())                  # the engine's intervals on this GPU
+    wide = margin > 0.05 * rng
+    print(f"[top1] DeiT-tiny/224 BasePTQ x4, 1000 images, labels = the raw network's predictions: reference run {100 * acc_ref:.1f} %, "
+          f"reference intervals on this GPU {100 * acc_gpu:.1f} %, engine-calibrated {100 * acc_eng:.1f} %; same prediction as the reference's "
+          f"run: {100 * float((pred == ref_pred).mean()):.1f} % / {100 * float((mine == ref_pred).mean()):.1f} % of the images "
+          f"({100 * float((pred == ref_pred)[wide].mean()):.1f} % / {100 * float((mine == ref_pred)[wide].mean()):.1f} % of the {int(wide.sum())} with a margin above "
+          f"5 % of the logit range); raw predictions GPU vs CPU {int((raw_gpu == raw_label).sum())}/1000; modules alone: worst {worst[0]:.1e} ({worst[1]})")
+    assert (raw_gpu == raw_label).mean() >= 0.99
+    assert abs(acc_gpu - acc_ref) <= 0.03 and abs(acc_eng - acc_ref) <= 0.03, (acc_ref, acc_gpu, acc_eng)
+    assert (pred == ref_pred).mean() >= 0.85 and (mine == ref_pred).mean() >= 0.85
+    assert (pred == ref_pred)[wide].mean() >= 0.97 and (mine == ref_pred)[wide].mean() >= 0.97
