@@ -27,15 +27,18 @@ def module_intervals(module):
     return out
 
 
-def install_intervals(module, values, device=None):
+def install_intervals(module, values, device=None, clone=True):
     """Give `module` the calibrated state: `values` = {attribute: tensor} as produced by `module_intervals` (or received from
-    the rank that searched the module).  Mirrors what the module's own `calibration_step2()` leaves behind."""
+    the rank that searched the module).  Mirrors what the module's own `calibration_step2()` leaves behind.  `clone=False`: the
+    caller hands over tensors nobody else writes (views of the freshly gathered exchange buffer: no copy kernel per attribute)."""
     if device is None:
         device = next((p.device for p in module.parameters()), torch.device("cpu")) if hasattr(module, "parameters") else torch.device("cpu")
     for a, val in values.items():
         if a not in INTERVAL_ATTRS:
             raise KeyError(f"unknown interval attribute {a}")
-        val = torch.as_tensor(val, dtype=torch.float32).to(device).clone()
+        val = torch.as_tensor(val, dtype=torch.float32).to(device)
+        if clone:
+            val = val.clone()
         cur = getattr(module, a, None)
         if isinstance(cur, (list, tuple)) or (a == "a_interval" and hasattr(module, "_set_a_interval") and
                                               getattr(module, "_postgelu", False) and not hasattr(module, "a_neg_interval")):

@@ -16,7 +16,8 @@ bytes -- and predicts, per world size:
                     sharded: ceil(n_sub / world) / n_sub of it + the all_to_all of the pieces (shard.choose_capture_mode's
                     transfer model: 40 GB/s per xGMI peer, two HBM passes for packing / reassembly) -- the mode is the one the
                     calibrator's rank-invariant cost model picks
-  exchange_s      = 2 small collectives + all_gather_object of the per-module times: 1.5 ms (latency-bound; RCCL init is
+  exchange_s      = 2 small collectives + all_gather_object of the per-module times: MEASURED (tools/measure_exchange.py ->
+                    profiles/r*_exchange_latency.json; 1.5 ms assumed when no measurement is committed; latency-bound; RCCL init is
                     outside the timed region)
   step_s          = capture_s + max over ranks of search_s + exchange_s          layers/s = modules / step_s
 
@@ -36,7 +37,22 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {"vitb224": ("vit_base_patch16_224", 32, 8), "vits224": ("vit_small_patch16_224", 32, 8),
            "swinb384": ("swin_base_patch4_window12_384", 128, 8), "vitb384": ("vit_base_patch16_384", 128, 6)}
-EXCHANGE_S = 1.5e-3
+EXCHANGE_S = 1.5e-3          # fallback; replaced by the measurement of tools/measure_exchange.py when profiles/ holds one
+
+
+def measured_exchange_s():
+    """exchange_intervals as measured (profiles/r*_exchange_latency.json): RCCL with one rank on the GPU box = the launch /
+    synchronisation floor of the two collectives + the host-side packing of 74 modules; a one-GPU box cannot show the xGMI hop
+    (a few microseconds for a KB), so the one-rank figure is taken as is; gloo world 2 (host transport) is kept as the upper bound."""
+    import glob, json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_exchange_latency.json")))
+    if not paths:
+        return EXCHANGE_S, "assumed"
+    d = json.load(open(paths[-1]))
+    for key in ("nccl_world1", "gloo_world2"):
+        if key in d:
+            return d[key]["exchange_intervals_ms"]["median"] * 1e-3, f"{key} ({os.path.basename(paths[-1])})"
+    return EXCHANGE_S, "assumed"
 
 
 def lpt(costs, world):
@@ -69,7 +85,7 @@ def predict(meas, worlds=(1, 2, 4, 8), gb_per_s_per_peer=40.0):
         passes_saved = 1.0 - math.ceil(n_sub / w) / n_sub
         mode = "sharded" if (w > 1 and n_sub >= 2 and cap_rep * 1e3 * passes_saved > 1.5 * t_xfer * 1e3 + 5.0) else "replicated"
         cap = cap_sh if mode == "sharded" else cap_rep
-        ex = EXCHANGE_S if w > 1 else 0.0
+        ex = measured_exchange_s()[0] if w > 1 else 0.0
         step = cap + max(search) + ex
         rows.append({"world": w, "capture_mode": mode, "capture_s": cap, "search_s_max": max(search), "search_s_mean": sum(search) / w,
                      "imbalance": max(search) / (sum(search) / w), "exchange_s": ex, "step_s": step,
