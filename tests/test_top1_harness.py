@@ -239,6 +239,12 @@ def test_eval_top1_tool_end_to_end_on_a_synthetic_imagefolder(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
     intervals.load_intervals(wrapped, ipath)
+    # every interval tensor lives where the network lives -- also those of the parameter-less MatMul wrappers (advisor, round 4)
+    for n, m in wrapped.items():
+        for a, v in intervals.module_intervals(m).items():
+            t = getattr(m, a)
+            t = t[0] if isinstance(t, (list, tuple)) else t
+            assert torch.is_tensor(t) and t.device.type == "cuda", (n, a, getattr(t, "device", None))
     g = datasets.ViTImageNetLoaderGenerator(root, "imagenet", 10, 10, 0, kwargs={"model": net})
     acc = datasets.test_classification(net, g.test_loader())
     assert acc == res["quant_top1"]

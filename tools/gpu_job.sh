@@ -20,13 +20,13 @@ for step in "$@"; do
              [ $n != 1 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
              head -24 $O/bench_${n}stream_kernel_stats.txt | cut -c1-180; rm -rf $O/prof$n ;;
     prodprof) # profile of the production step, joined with the engine's launch records (tools/prof_join.py); arg = output stem
-             stem=${arg:-r4_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
+             stem=${arg:-r5_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
              ( cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $T/trace -o t -- python $R/bench.py --profile --steps 3 --warmup 2 --dump-launches $T/launches.json > $O/prodprof_bench.json 2> $O/prodprof_bench.err )
              for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
                tag=$(echo $pass | cut -d' ' -f1)
                ( cd /tmp && timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $T/pmc_$tag -o p -- python $R/bench.py --profile --steps 1 --warmup 1 --no-roofline > $T/pmc_$tag.log 2>&1 )
                f=$(find $T/pmc_$tag -name "*counter_collection.csv" | head -1)
-               [ -n "$f" ] && { head -1 $f > $T/$tag.csv; grep -E "k_sweep|k_sos|k_bound|k_slice" $f >> $T/$tag.csv; } || echo "no counter csv for $tag: $(tail -2 $T/pmc_$tag.log)"
+               [ -n "$f" ] && { head -1 $f > $T/$tag.csv; grep -E "k_sweep|k_sos|k_bound|k_slice|k_pack" $f >> $T/$tag.csv; } || echo "no counter csv for $tag: $(tail -2 $T/pmc_$tag.log)"
              done
              python tools/prof_join.py --launches $T/launches.json --trace "$T/trace/*.db" --fetch $T/FETCH_SIZE.csv --write $T/WRITE_SIZE.csv \
                     --counters $T/TCC_HIT_sum.csv $T/SQ_VALU_MFMA_BUSY_CYCLES.csv --out $O/$stem 2>&1 | cut -c1-200 | tee $O/prodprof.log

@@ -67,6 +67,8 @@ def lpt(costs, world):
 
 
 def predict(meas, worlds=(1, 2, 4, 8), gb_per_s_per_peer=40.0):
+    # the exchange the prediction was made with travels with the measurements (`exchange_s`; files of round 4 assumed 1.5 ms)
+    ex_s = meas.get("exchange_s", EXCHANGE_S)
     ms1 = meas["module_ms_single_stream"]
     total1 = sum(ms1.values())
     overlap = total1 / (meas["search_s"] * 1e3)
@@ -85,7 +87,7 @@ def predict(meas, worlds=(1, 2, 4, 8), gb_per_s_per_peer=40.0):
         passes_saved = 1.0 - math.ceil(n_sub / w) / n_sub
         mode = "sharded" if (w > 1 and n_sub >= 2 and cap_rep * 1e3 * passes_saved > 1.5 * t_xfer * 1e3 + 5.0) else "replicated"
         cap = cap_sh if mode == "sharded" else cap_rep
-        ex = measured_exchange_s()[0] if w > 1 else 0.0
+        ex = ex_s if w > 1 else 0.0
         step = cap + max(search) + ex
         rows.append({"world": w, "capture_mode": mode, "capture_s": cap, "search_s_max": max(search), "search_s_mean": sum(search) / w,
                      "imbalance": max(search) / (sum(search) / w), "exchange_s": ex, "step_s": step,
@@ -174,7 +176,8 @@ def measure(model, calib, bits):
     out = {"model": model, "calib_images": calib, "bits": bits, "modules": len(wrapped), "step_s": wall,
            "capture_s": cal.timings["capture_s"], "search_s": cal.timings["search_s"], "n_sub": n_sub,
            "module_ms_single_stream": {n: min(v) for n, v in per.items()},
-           "cache_bytes": {n: int(sizes[n]) for n in wrapped}}
+           "cache_bytes": {n: int(sizes[n]) for n in wrapped},
+           "exchange_s": measured_exchange_s()[0], "exchange_source": measured_exchange_s()[1]}
     del net, wrapped, images, cal
     torch.cuda.empty_cache()
     engine.release_workspace()

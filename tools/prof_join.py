@@ -39,6 +39,8 @@ def family(name):
         return "k_sweep7" if targs[0] == "0" else "k_sweep7 (twin)"
     if base in ("k_sweep4", "k_sweep5"):
         return "k_sweep4/5"
+    if base == "k_slice_b2":                 # (round 5: B in registers; the engine's records keep the family name)
+        return "k_slice_b"
     if base in ("k_sweep9", "k_sweep8", "k_sweep2g", "k_sweep2", "k_sos_split", "k_bound", "k_slice_b", "k_slice_a"):
         return base
     if base == "k_sweep":
