@@ -1398,7 +1398,12 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
         const size_t lds = (size_t)nb * 16 * (Kp + 4) * sizeof(float);
         // k_slice_b: >= 1024 workgroups, >= 4 candidates each (one per wave); k_slice_b2: every wave runs every candidate of its
         // workgroup, the prologue (B -> registers) is paid per workgroup: >= 512 workgroups of >= 10 candidates
-        const int groups = v2 ? std::max(1, std::min(a.eq_n / 10, cdiv(512, Z))) : std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
+        // (k_slice_b2 keeps 3 workgroups per CU -- 2 with the twin's second accumulator set, 250 registers: whole rounds of 256 x that)
+        const int slots = 256 * (a.twin ? 2 : 3);
+        int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(512, Z)));
+        while (g2 < a.eq_n / 10 && ((long)Z * g2) % slots != 0 && ((long)Z * g2) % slots < slots * 3 / 4) ++g2;   // no mostly-empty last round
+        if (tune(TUNE_CG2) > 0) g2 = std::max(1, std::min(a.eq_n, tune(TUNE_CG2)));
+        const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
         const dim3 grid(Z, groups), block(256);
         const float qbias = (v2 && b.lo == -128 && b.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, probe) : 0.0f;   // 12 = 11: quant_fast1 in k_slice_b2 (A/B)
         const bool timed = g_stat_on;
