@@ -125,6 +125,13 @@ def aggregate_launches(recs, peak_i8=5000.0, peak_f32=157.3):
     return fams
 
 
+def _rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        return None
+
+
 def _cpu_info():
     model = "unknown"
     try:
@@ -630,6 +637,10 @@ def main():
             "top1": top1, "top1_reason": top1_reason,
             "quant_forward_img_s": qf["quant_forward_img_s"] if qf else None, "quant_forward": qf,
             "per_rank": per_rank,
+            # a first SCALE run is self-diagnosing: what the ranks talked through, which capture mode the calibrator chose
+            "distributed": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                            "rccl_version": _rccl_version(), "capture_mode": getattr(cals[-1], "capture_mode", None),
+                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "imbalance": (max(r["search_s"] for r in per_rank) / (sum(r["search_s"] for r in per_rank) / len(per_rank))) if per_rank else None,
             "roofline": roof, "cpu_baseline": cpu,
         }
