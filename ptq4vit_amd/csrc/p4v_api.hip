@@ -122,6 +122,10 @@ std::atomic<int> g_variant_word{0};
 std::atomic<int> g_tune[16];
 enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8,
        TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11, TUNE_B1_PATH = 12, TUNE_TIER2 = 13, TUNE_TIER2_DIV = 14 };   // TIER2: 1 = no second slice tier; >= 2: minimum survivor count that triggers it   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+// TUNE_B1_PATH (key 12) doubles as the A/B switch of the round-4 / round-5 paths: 1 / 2 the bound pass on k_sweep2 / k_sweep4,
+// 3 the bound pass on the sweep kernels, 5 padded 64-column planes, 6 no slice kernels, 7 cosine on the generic kernel,
+// 8 read-backs by copy (no mapped host memory), 9 no per-score-block candidate ranges, 10 k_slice_b instead of k_slice_b2,
+// 11 quant_fast1 instead of quant16_sat8, 12 launch geometry not planned for the host-known candidate range, >= 16 k_bound timing ablations
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
 struct Ctx {
@@ -1401,7 +1405,9 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
         // (k_slice_b2 keeps 3 workgroups per CU -- 2 with the twin's second accumulator set, 250 registers: whole rounds of 256 x that)
         const int slots = 256 * (a.twin ? 2 : 3);
         int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(512, Z)));
-        while (g2 < a.eq_n / 10 && ((long)Z * g2) % slots != 0 && ((long)Z * g2) % slots < slots * 3 / 4) ++g2;   // no mostly-empty last round
+        // no mostly-empty last round -- where the rounds are few (ViT: 384 batch entries; with tens of thousands of them, Swin's
+        // windows, the tail does not matter and more groups only repeat the prologue)
+        while ((long)Z * g2 < 4L * slots && g2 < a.eq_n / 10 && ((long)Z * g2) % slots != 0 && ((long)Z * g2) % slots < slots * 3 / 4) ++g2;
         if (tune(TUNE_CG2) > 0) g2 = std::max(1, std::min(a.eq_n, tune(TUNE_CG2)));
         const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
         const dim3 grid(Z, groups), block(256);
