@@ -7,6 +7,8 @@ not available offline, so the architectures are restated here with the same para
 timm's VisionTransformer; ``get_net(name)`` builds them with seeded random weights (pretrained weights can be
 loaded with ``load_state_dict`` when available).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -34,6 +36,10 @@ class Attention(nn.Module):
         """Same dataflow as reference utils/models.py:10-26: q @ k^T through matmul1, attn @ v through matmul2."""
         B, N, C = x.shape
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        if os.environ.get("P4V_QKV_CONTIGUOUS", "1") == "1":
+            # ONE copy into [3][B][H][N][D] instead of the three that torch.matmul makes of the strided q / k / v views (and again of
+            # the saved views in its backward): same values, ~5 fewer kernels per block and pass of the capture
+            qkv = qkv.contiguous()
         q, k, v = qkv.unbind(0)
         attn = self.matmul1(q, k.transpose(-2, -1)) * self.scale
         attn = self.attn_drop(attn.softmax(dim=-1))
