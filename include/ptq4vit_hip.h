@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define P4V_VERSION 130 /* 0.1.3: + p4v_pack_plane_i8, p4v_export_quantize, p4v_debug_*; stats are per calling thread */
+#define P4V_VERSION 140 /* 0.1.4: + p4v_calibrate_group (grouped launches over the modules of a network), p4v_launch_counters */
 
 /* similarity metrics: reference quant_layers/linear.py:399-424 */
 enum p4v_metric {
@@ -159,6 +159,42 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
                        const float* d_out, const float* d_grad, const float* d_mult, float* d_w_interval,
                        float* d_a_interval, float* d_scores, int32_t* d_best, void* d_workspace,
                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * p4v_calibrate_group: calibration_step2() of SEVERAL modules in one call.
+ *
+ * Replaces the loop `for name, module in ...: module.calibration_step2()` of the reference's calibrator
+ * (utils/quant_calib.py:371-372; with sequential=False the modules are independent, quant_calib.py:316-372).  Each member is
+ * exactly one p4v_linear_calibrate / p4v_matmul_calibrate / p4v_conv_calibrate call (same descriptor, same pointers, its own
+ * workspace of p4v_*_workspace_bytes(desc), no score tables); the members search in lock step and every kernel launch of the
+ * same kind is issued ONCE for all members that are at that point (one k_finish / k_pack / k_sweep6 ... over the concatenated
+ * grids instead of one per module).  The results are bit-identical to the members' single calls: a grouped kernel runs each
+ * member's own code on its own parameters.  One stream; the call returns when every member's operations have been issued
+ * (like the single calls, it synchronises the stream wherever a member needs a result on the host).
+ *
+ * kind / pointers:
+ *   P4V_JOB_LINEAR  desc = p4v_linear_desc   in = {weight, bias, x, raw_out, raw_grad}   out = {w_interval, a_interval, NULL}
+ *   P4V_JOB_MATMUL  desc = p4v_matmul_desc   in = {A, B, raw_out, raw_grad, NULL}        out = {A_interval, B_interval, split}
+ *   P4V_JOB_CONV    desc = p4v_conv_desc     in = {weight, bias, x, raw_out, raw_grad}   out = {w_interval, a_interval, NULL}
+ * `status` receives the member's own status; the call returns the first non-zero one (p4v_last_error() has its message).
+ * ---------------------------------------------------------------------------------------- */
+enum p4v_job_kind { P4V_JOB_LINEAR = 0, P4V_JOB_MATMUL = 1, P4V_JOB_CONV = 2 };
+typedef struct p4v_group_job {
+    int32_t kind;
+    int32_t status;
+    const void* desc;
+    const float* in[5];
+    const float* mult;          /* [eq_n + 1] candidate multipliers, as d_mult of the single calls */
+    float* out[3];
+    void* workspace;
+    size_t workspace_bytes;
+} p4v_group_job;
+int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream);
+
+/* PROCESS-WIDE launch counters since the last reset: out4[0] kernel launches the calibration path asked for (one module at a
+ * time these are the launches made), out4[1] kernel launches issued to the GPU (grouped ones count once), out4[2] issue
+ * rounds of p4v_calibrate_group (one stream synchronisation each), out4[3] p4v_calibrate_group calls.  `out4` may be NULL. */
+int p4v_launch_counters(int64_t* out4, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Granular entry points: ONE part of calibration_step2 per call, for callers that drive the

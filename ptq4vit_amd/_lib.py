@@ -73,6 +73,13 @@ class ExportDesc(C.Structure):
                 ("qmax", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GroupJob(C.Structure):
+    """p4v_group_job: one member of a p4v_calibrate_group call (= one p4v_*_calibrate call)."""
+    _fields_ = [("kind", C.c_int32), ("status", C.c_int32), ("desc", C.c_void_p), ("inp", C.c_void_p * 5), ("mult", C.c_void_p),
+                ("out", C.c_void_p * 3), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+JOB_LINEAR, JOB_MATMUL, JOB_CONV = 0, 1, 2
 PLANE_SYM, PLANE_SOS_HI, PLANE_SOS_LO, PLANE_TWIN = 1, 2, 3, 4
 EXPORT_SYM_I8, EXPORT_SYM_F32, EXPORT_GELU_U8, EXPORT_SOS_U8 = 0, 1, 2, 3
 
@@ -82,6 +89,7 @@ EXPORTS = [
     "p4v_linear_workspace_bytes", "p4v_linear_calibrate",
     "p4v_matmul_workspace_bytes", "p4v_matmul_calibrate",
     "p4v_conv_workspace_bytes", "p4v_conv_calibrate",
+    "p4v_calibrate_group", "p4v_launch_counters",
     "p4v_linear_quant_forward", "p4v_matmul_quant_forward",
     "p4v_amax_init_linear", "p4v_linear_search_w", "p4v_linear_search_a",
     "p4v_amax_init_matmul", "p4v_matmul_search_A", "p4v_sos_search_split", "p4v_matmul_search_B",
@@ -173,6 +181,10 @@ def load():
     lib.p4v_stats_launches.argtypes = [C.POINTER(LaunchRecord), C.c_int64, C.POINTER(C.c_int64)]
     lib.p4v_prune_counters.restype = C.c_int
     lib.p4v_prune_counters.argtypes = [C.POINTER(C.c_int64), C.c_int]
+    lib.p4v_launch_counters.restype = C.c_int
+    lib.p4v_launch_counters.argtypes = [C.POINTER(C.c_int64), C.c_int]
+    lib.p4v_calibrate_group.restype = C.c_int
+    lib.p4v_calibrate_group.argtypes = [C.POINTER(GroupJob), C.c_int32, vp]
     _lib = lib
     return lib
 

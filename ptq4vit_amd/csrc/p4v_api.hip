@@ -12,7 +12,11 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -128,30 +132,321 @@ enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, 
 // 11 quant_fast1 instead of quant16_sat8, 12 launch geometry not planned for the host-known candidate range, >= 16 k_bound timing ablations
 inline int tune(int k) { return g_tune[k].load(std::memory_order_relaxed); }
 
+struct Group;
 struct Ctx {
     hipStream_t st;
     Arena ws;
     bool dry;
+    Group* grp = nullptr;     // p4v_calibrate_group: this call is member `slot` of a group whose stream operations are deferred and
+    int slot = 0;             // issued together (grouped launches); nullptr: every operation goes to `st` at once
+    int par = 1;              // members of the group that search in lock step: the launch heuristics plan for 256 / par CUs
 };
+
+// ---- stream operations: issued at once (one module) or deferred and grouped (p4v_calibrate_group) -------------------------------
+// Every kernel launch, fill and copy of the calibration path goes through enqueue() / q_fill() / q_d2h() / q_h2d() / q_sync().
+// Without a group they act on c.st immediately.  With one, the operations of a member are queued in its own FIFO and the member
+// runs ahead until it needs a result on the host (q_sync: the survivor range of a pruned pass, an interval for the pass memo);
+// when every member of the group waits (or has finished), the last one to arrive merges the FIFOs -- repeatedly taking the most
+// common head operation over all members and issuing those launches as ONE grouped launch (k_x_g) -- synchronises the stream
+// once and releases everybody.  The members' operations never depend on each other (separate modules, separate scratch), every
+// member's own order is kept, and a grouped launch runs each member's body on its own parameters: bit-identical results.
+struct StatInfo { int kind; double macs, alg; int stage, gx, gz; double bytes; };   // a timed sweep launch (bench.py roofline)
+struct QOp;
+struct KernelDesc {
+    hipError_t (*one)(const QOp&, hipStream_t);
+    hipError_t (*many)(const QOp* const*, int, hipStream_t);   // nullptr: the kernel has no grouped entry point
+    int cap;                                                    // members per grouped launch
+};
+constexpr int QOP_PARAM_BYTES = 480;
+struct QOp {
+    enum Type : int { KERNEL, FILL, D2H, H2D, COPY2D };
+    int type = KERNEL;
+    const KernelDesc* kd = nullptr;
+    dim3 grid, block;
+    unsigned lds = 0;
+    alignas(16) char params[QOP_PARAM_BYTES];
+    void* dst = nullptr; const void* src = nullptr; size_t bytes = 0; int value = 0;
+    size_t dpitch = 0, spitch = 0, width = 0, height = 0;
+    std::vector<char> payload;      // H2D: the host data (the caller's buffer may be gone when the operation is issued)
+    bool timed = false; StatInfo si{};
+};
+inline hipError_t lds_attr(const void* fn, unsigned lds, std::atomic<bool>& done) {
+    if (lds <= 48 * 1024 || done.load(std::memory_order_acquire)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.store(true, std::memory_order_release);
+    return e;
+}
+template <typename P, void (*K1)(P), void (*KG)(GroupArgs<P>)> struct Kern {
+    static_assert(sizeof(P) <= QOP_PARAM_BYTES, "kernel parameter block larger than a queued operation holds");
+    static hipError_t one(const QOp& op, hipStream_t st) {
+        static std::atomic<bool> attr{false};
+        if (hipError_t e = lds_attr((const void*)K1, op.lds, attr); e != hipSuccess) return e;
+        P p;
+        std::memcpy(&p, op.params, sizeof(P));
+        void* args[] = {&p};
+        return hipLaunchKernel((const void*)K1, op.grid, op.block, args, op.lds, st);
+    }
+    static hipError_t many(const QOp* const* ops, int n, hipStream_t st) {
+        static std::atomic<bool> attr{false};
+        GroupArgs<P> a;
+        unsigned off = 0, lds = 0;
+        a.n = n;
+        for (int m = 0; m < n; ++m) {
+            const QOp& op = *ops[m];
+            a.off[m] = off; a.gx[m] = op.grid.x; a.gy[m] = op.grid.y; a.gz[m] = op.grid.z;
+            std::memcpy(&a.p[m], op.params, sizeof(P));
+            off += (unsigned)rup((long)op.grid.x * op.grid.y * op.grid.z, 8);
+            lds = std::max(lds, op.lds);
+        }
+        a.off[n] = off;
+        if (hipError_t e = lds_attr((const void*)KG, lds, attr); e != hipSuccess) return e;
+        void* args[] = {&a};
+        return hipLaunchKernel((const void*)KG, dim3(off), ops[0]->block, args, lds, st);
+    }
+    static const KernelDesc* desc() { static const KernelDesc d{&one, &many, GroupArgs<P>::CAP}; return &d; }
+};
+template <typename P, void (*K1)(P)> struct Kern1 {      // kernels off the grouped path (generic fallbacks, API helpers)
+    static_assert(sizeof(P) <= QOP_PARAM_BYTES, "kernel parameter block larger than a queued operation holds");
+    static hipError_t one(const QOp& op, hipStream_t st) {
+        static std::atomic<bool> attr{false};
+        if (hipError_t e = lds_attr((const void*)K1, op.lds, attr); e != hipSuccess) return e;
+        P p;
+        std::memcpy(&p, op.params, sizeof(P));
+        void* args[] = {&p};
+        return hipLaunchKernel((const void*)K1, op.grid, op.block, args, op.lds, st);
+    }
+    static const KernelDesc* desc() { static const KernelDesc d{&one, nullptr, 1}; return &d; }
+};
+#define KERN(P, NAME) (Kern<P, NAME, NAME##_g>::desc())
+#define KERN_T(P, NAME, ...) (Kern<P, NAME<__VA_ARGS__>, NAME##_g<__VA_ARGS__>>::desc())
+#define KERN1_T(P, NAME, ...) (Kern1<P, NAME<__VA_ARGS__>>::desc())
+
+constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
+constexpr size_t MIRROR_BYTES = 128 + sizeof(float) * MIR_SLOT * MIR_SLOTS;
+inline int* mirror_alloc() {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, MIRROR_BYTES, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    return (int*)p;
+}
+
+// The rendezvous of one p4v_calibrate_group call (see above).
+struct Group {
+    hipStream_t st = nullptr;
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<QOp>> q;      // member FIFOs: written by the member while it runs, read by the issuer while every member is blocked
+    std::vector<int> state;              // 0 running, 1 waiting in q_sync, 2 finished
+    int blocked = 0;
+    unsigned long gen = 0;
+    int status = 0;                      // first HIP error of an issue round (every waiting member returns it)
+    std::string err;
+    std::vector<int*> mirrors;           // one mapped host block per member (host_mirror)
+    bool stat_on = false;
+    std::vector<StatRec>* stat_recs = nullptr;      // the CALLING thread's launch records: one per grouped launch
+    long n_ops = 0, n_launches = 0, n_rounds = 0;
+    int issue_kernels(std::vector<const QOp*>& ops);
+    int issue_round();                   // (mu held, every member blocked)
+    int sync(int slot);
+    void finish(int slot);
+};
+
+// Process-wide counters (p4v_launch_counters): [0] kernel launches the calibration path asked for (one module at a time these ARE
+// the launches), [1] kernel launches issued to the GPU, [2] issue rounds of the groups, [3] group calls.
+std::atomic<long long> g_launch_cnt[4];
+int enqueue_now(hipStream_t st, const QOp& op, bool timed, std::vector<StatRec>* recs) {
+    g_launch_cnt[1].fetch_add(1, std::memory_order_relaxed);
+    StatRec rec{};
+    if (timed) {
+        HIPCHK(hipEventCreate(&rec.a));
+        HIPCHK(hipEventCreate(&rec.b));
+        HIPCHK(hipEventRecord(rec.a, st));
+    }
+    HIPCHK(op.kd->one(op, st));
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, st));
+        rec.kind = op.si.kind; rec.macs = op.si.macs; rec.alg = op.si.alg; rec.stage = op.si.stage; rec.gx = op.si.gx; rec.gz = op.si.gz; rec.bytes = op.si.bytes;
+        recs->push_back(rec);
+    }
+    return 0;
+}
+int issue_plain(hipStream_t st, const QOp& op) {
+    switch (op.type) {
+        case QOp::FILL: HIPCHK(hipMemsetAsync(op.dst, op.value, op.bytes, st)); break;
+        case QOp::D2H: HIPCHK(hipMemcpyAsync(op.dst, op.src, op.bytes, hipMemcpyDeviceToHost, st)); break;
+        case QOp::H2D: HIPCHK(hipMemcpyAsync(op.dst, op.payload.data(), op.bytes, hipMemcpyHostToDevice, st)); break;
+        case QOp::COPY2D: HIPCHK(hipMemcpy2DAsync(op.dst, op.dpitch, op.src, op.spitch, op.width, op.height, hipMemcpyDeviceToDevice, st)); break;
+        default: break;
+    }
+    return 0;
+}
+// one grouped launch per <= cap members of `ops` (all of one kernel entry point and block shape), in balanced chunks
+int Group::issue_kernels(std::vector<const QOp*>& ops) {
+    const KernelDesc* kd = ops[0]->kd;
+    const int total = (int)ops.size();
+    if (!kd->many || total == 1) {
+        for (const QOp* op : ops) { CHK(enqueue_now(st, *op, op->timed && stat_recs, stat_recs)); ++n_launches; }
+        return 0;
+    }
+    const int chunks = cdiv(total, kd->cap), per = cdiv(total, chunks);
+    for (int i0 = 0; i0 < total; i0 += per) {
+        const int m = std::min(per, total - i0);
+        bool timed = stat_recs != nullptr;
+        for (int i = 0; i < m; ++i) timed = timed && ops[i0 + i]->timed;
+        StatRec rec{};
+        if (timed) {
+            HIPCHK(hipEventCreate(&rec.a));
+            HIPCHK(hipEventCreate(&rec.b));
+            HIPCHK(hipEventRecord(rec.a, st));
+        }
+        HIPCHK(kd->many(ops.data() + i0, m, st));
+        g_launch_cnt[1].fetch_add(1, std::memory_order_relaxed);
+        ++n_launches;
+        if (timed) {      // ONE record per kernel launch (1:1 with a kernel trace): the members' work added up
+            HIPCHK(hipEventRecord(rec.b, st));
+            const StatInfo& s0 = ops[i0]->si;
+            rec.kind = s0.kind; rec.stage = s0.stage; rec.gz = s0.gz;
+            for (int i = 0; i < m; ++i) { const StatInfo& s = ops[i0 + i]->si; rec.macs += s.macs; rec.alg += s.alg; rec.bytes += s.bytes; rec.gx += s.gx; }
+            stat_recs->push_back(rec);
+        }
+    }
+    return 0;
+}
+int Group::issue_round() {
+    ++n_rounds;
+    g_launch_cnt[2].fetch_add(1, std::memory_order_relaxed);
+    std::vector<const QOp*> bucket;
+    for (;;) {
+        // the most common head operation over the members (kernel entry point + block shape; plain operations go one by one)
+        int best = -1, best_n = 0;
+        for (int i = 0; i < n; ++i) {
+            if (q[i].empty()) continue;
+            const QOp& h = q[i].front();
+            if (h.type != QOp::KERNEL) { best = i; best_n = 0; break; }        // fills / copies: at once, in member order
+            int cnt = 0;
+            for (int j = i; j < n; ++j)
+                if (!q[j].empty()) { const QOp& o = q[j].front(); cnt += o.type == QOp::KERNEL && o.kd == h.kd && o.block.x == h.block.x && o.block.y == h.block.y && o.block.z == h.block.z; }
+            if (cnt > best_n) { best = i; best_n = cnt; }
+        }
+        if (best < 0) break;
+        const QOp& h = q[best].front();
+        if (h.type != QOp::KERNEL) {
+            const int r = issue_plain(st, h);
+            ++n_ops;
+            q[best].pop_front();
+            if (r) return r;
+            continue;
+        }
+        bucket.clear();
+        std::vector<int> who;
+        for (int j = best; j < n; ++j)
+            if (!q[j].empty()) { const QOp& o = q[j].front(); if (o.type == QOp::KERNEL && o.kd == h.kd && o.block.x == h.block.x && o.block.y == h.block.y && o.block.z == h.block.z) { bucket.push_back(&o); who.push_back(j); } }
+        n_ops += (long)bucket.size();
+        const int r = issue_kernels(bucket);
+        for (int j : who) q[j].pop_front();
+        if (r) return r;
+    }
+    return 0;
+}
+int Group::sync(int slot) {
+    std::unique_lock<std::mutex> lk(mu);
+    state[slot] = 1;
+    ++blocked;
+    if (blocked == n) {
+        int r = issue_round();
+        if (!r && hipStreamSynchronize(st) != hipSuccess) r = fail(P4V_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        if (r && !status) { status = r; err = g_err; }
+        blocked = 0;
+        for (int i = 0; i < n; ++i) { if (state[i] == 1) state[i] = 0; else if (state[i] == 2) ++blocked; }
+        ++gen;
+        cv.notify_all();
+    } else {
+        const unsigned long g = gen;
+        cv.wait(lk, [&] { return gen != g; });
+    }
+    if (status) { g_err = err; return status; }
+    return 0;
+}
+void Group::finish(int slot) {
+    std::unique_lock<std::mutex> lk(mu);
+    state[slot] = 2;
+    ++blocked;
+    if (blocked < n) return;
+    bool waiting = false;
+    for (int i = 0; i < n; ++i) waiting = waiting || state[i] == 1;
+    int r = issue_round();
+    if (!r && waiting && hipStreamSynchronize(st) != hipSuccess) r = fail(P4V_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    if (r && !status) { status = r; err = g_err; }
+    blocked = 0;
+    for (int i = 0; i < n; ++i) { if (state[i] == 1) state[i] = 0; else if (state[i] == 2) ++blocked; }
+    ++gen;
+    cv.notify_all();
+}
+
+// a kernel launch of the calibration path; `si`: the launch is one of the timed sweeps (roofline records)
+template <typename P> int enqueue(Ctx& c, const KernelDesc* kd, dim3 grid, dim3 block, size_t lds, const P& p, const StatInfo* si = nullptr) {
+    if (c.dry) return 0;
+    QOp op;
+    op.type = QOp::KERNEL; op.kd = kd; op.grid = grid; op.block = block; op.lds = (unsigned)lds;
+    static_assert(sizeof(P) <= QOP_PARAM_BYTES, "parameter block too large");
+    std::memcpy(op.params, &p, sizeof(P));
+    if (si) { op.timed = true; op.si = *si; }
+    g_launch_cnt[0].fetch_add(1, std::memory_order_relaxed);
+    if (c.grp) { c.grp->q[c.slot].push_back(std::move(op)); return 0; }
+    return enqueue_now(c.st, op, si != nullptr, &g_stat_recs);
+}
+int q_fill(Ctx& c, void* dst, int value, size_t bytes) {        // (k_fill_bytes: a kernel of this library, so that fills join the grouped launches)
+    if (c.dry || bytes == 0) return 0;
+    const FillBytesParams p{dst, value, (long)bytes};
+    const long items = (bytes & 3) == 0 ? (long)(bytes >> 2) : (long)bytes;
+    return enqueue(c, KERN(FillBytesParams, k_fill_bytes), dim3((unsigned)std::min<long>(cdiv(items, 256), 2048)), dim3(256), 0, p, nullptr);
+}
+int q_d2h(Ctx& c, void* host, const void* dev, size_t bytes) {       // `host` must stay valid until the next q_sync
+    if (!c.grp) { HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c.st)); return 0; }
+    QOp op; op.type = QOp::D2H; op.dst = host; op.src = dev; op.bytes = bytes;
+    c.grp->q[c.slot].push_back(std::move(op));
+    return 0;
+}
+int q_h2d(Ctx& c, void* dev, const void* host, size_t bytes) {       // (callers synchronise before `host` goes away)
+    if (!c.grp) { HIPCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c.st)); return 0; }
+    QOp op; op.type = QOp::H2D; op.dst = dev; op.bytes = bytes;
+    op.payload.assign((const char*)host, (const char*)host + bytes);
+    c.grp->q[c.slot].push_back(std::move(op));
+    return 0;
+}
+int q_copy2d(Ctx& c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (!c.grp) { HIPCHK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, c.st)); return 0; }
+    QOp op; op.type = QOp::COPY2D; op.dst = dst; op.src = src; op.dpitch = dpitch; op.spitch = spitch; op.width = width; op.height = height;
+    c.grp->q[c.slot].push_back(std::move(op));
+    return 0;
+}
+int q_sync(Ctx& c) {
+    if (c.grp) return c.grp->sync(c.slot);
+    HIPCHK(hipStreamSynchronize(c.st));
+    return 0;
+}
 
 // Small device -> host results (the survivor range of a pruned pass, the slice's weight share, the intervals a pass selected)
 // are written by their kernel into mapped host memory as well and read after the stream synchronisation the host does anyway:
 // no copy command (a pageable hipMemcpyAsync is a blit kernel into a staging buffer between two waits: ~410 range read-backs
-// and ~270 interval read-backs per ViT-B calibration).  One block per stream, allocated at the stream's first use (the
-// calibrator's streams are persistent), never freed: 32 ints ([0,1] / [2,3] survivor ranges of the two tiers, [4] weight share, [8..15] / [16..23]
-// their per-score-block ranges) + MIR_SLOTS interval vectors of MIR_SLOT floats.
-// p4v_debug_set_tuning(12, 8): the copy path (A/B).
-constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
-int* host_mirror(hipStream_t st) {
+// and ~270 interval read-backs per ViT-B calibration).  One block per (device, stream) -- per MEMBER inside a group --, allocated
+// at first use (the calibrator's streams are persistent), never freed: 32 ints ([0,1] / [2,3] survivor ranges of the two tiers,
+// [4] weight share, [8..15] / [16..23] their per-score-block ranges) + MIR_SLOTS interval vectors of MIR_SLOT floats.  The null
+// stream has no block (calls from different threads would share it): it takes the copy path, as p4v_debug_set_tuning(12, 8) does.
+int* host_mirror(Ctx& c) {
+    if (c.grp) return c.grp->mirrors[c.slot];
+    if (!c.st) return nullptr;
     static std::mutex mu;
-    static std::unordered_map<void*, int*> tab;
+    static std::unordered_map<unsigned long long, int*> tab;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const unsigned long long key = (unsigned long long)(uintptr_t)c.st ^ ((unsigned long long)(dev + 1) << 56);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = tab.find((void*)st);
+    auto it = tab.find(key);
     if (it != tab.end()) return it->second;
-    void* p = nullptr;
-    if (hipHostMalloc(&p, 128 + sizeof(float) * MIR_SLOT * MIR_SLOTS, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
-    tab[(void*)st] = (int*)p;
-    return (int*)p;
+    int* p = mirror_alloc();
+    tab[key] = p;
+    return p;
 }
 // The interval vectors of the *_impl call running on this thread that are mirrored (MirrorScope binds them, launch_select /
 // k_prune_hull write through attach_mirror, read_dev reads).  `valid`: the last writer of the whole device vector was a
@@ -165,11 +460,13 @@ IvMirror* mirror_of(const float* dev) {
 }
 void attach_mirror(SelectParams& sl) {
     sl.iv_host = nullptr; sl.aux_host = nullptr;
-    if (!sl.interval) return;
-    if (IvMirror* m = mirror_of(sl.interval); m && sl.nj <= MIR_SLOT && sl.out_off == 0 && (sl.nj == 1 || sl.out_js == 1)) {
-        sl.iv_host = m->host; m->valid = true; m->count = sl.nj;
-    } else if (m) m->valid = false;
-    if (IvMirror* m = mirror_of(sl.aux_out); m && sl.nj <= MIR_SLOT) { sl.aux_host = m->host; m->valid = true; m->count = sl.nj; }
+    // whatever this selection writes, the mirrors of its outputs are stale until it proves otherwise
+    IvMirror* mi = mirror_of(sl.interval);
+    IvMirror* ma = mirror_of(sl.aux_out);
+    if (mi) mi->valid = false;
+    if (ma) ma->valid = false;
+    if (mi && sl.nj <= MIR_SLOT && sl.out_off == 0 && (sl.nj == 1 || sl.out_js == 1)) { sl.iv_host = mi->host; mi->valid = true; mi->count = sl.nj; }
+    if (ma && sl.nj <= MIR_SLOT) { sl.aux_host = ma->host; ma->valid = true; ma->count = sl.nj; }
 }
 
 void metric_epi(int metric, int* epi, int* wt_mode) {
@@ -187,53 +484,54 @@ void metric_epi(int metric, int* epi, int* wt_mode) {
 int launch_absmax(Ctx& c, const float* src, const long (&st)[4], int D0, int D1, int R, int C, int nV, int nH,
                   int crb_r, int crb_c, int signed_max, unsigned* out) {
     if (c.dry) return 0;
-    HIPCHK(hipMemsetAsync(out, 0, sizeof(unsigned) * (size_t)D1 * nV * nH, c.st));  // 0 < enc(x) for every float x
+    CHK(q_fill(c, out, 0, sizeof(unsigned) * (size_t)D1 * nV * nH));  // 0 < enc(x) for every float x
     AbsMaxParams p{src, st[0], st[1], st[2], st[3], D0, D1, R, C, nV, nH, crb_r, crb_c, 0, signed_max, out};
     p.row_tile = std::max(1, std::min(crb_r, std::max(1, 8192 / std::max(1, std::min(crb_c, C)))));
     const int tiles_per_v = cdiv(crb_r, p.row_tile);
     dim3 grid(tiles_per_v * nV * nH, D1, D0);
-    hipLaunchKernelGGL(k_absmax, grid, dim3(256), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(AbsMaxParams, k_absmax), grid, dim3(256), 0, p);
 }
 
 int launch_interval(Ctx& c, const unsigned* enc, int n, float denom, int broadcast, float* interval) {
     if (c.dry) return 0;
-    hipLaunchKernelGGL(k_interval_from_max, dim3(cdiv(n, 64)), dim3(64), 0, c.st, enc, n, denom, broadcast, interval);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(IntervalParams, k_interval_from_max), dim3(cdiv(n, 64)), dim3(64), 0, IntervalParams{enc, n, denom, broadcast, interval});
 }
 
 int launch_cands(Ctx& c, const float* mult, const float* interval, int ncand, int nblk, float* cands) {
     if (c.dry) return 0;
-    hipLaunchKernelGGL(k_make_cands, dim3(cdiv((long)ncand * nblk, 256)), dim3(256), 0, c.st, mult, interval, ncand, nblk, cands);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(CandsParams, k_make_cands), dim3(cdiv((long)ncand * nblk, 256)), dim3(256), 0, CandsParams{mult, interval, ncand, nblk, cands});
 }
 
 int launch_scale(Ctx& c, ScaleParams p) {
     if (c.dry) return 0;
-    hipLaunchKernelGGL(k_scale_table, dim3(cdiv((long)p.C * p.nblk, 256)), dim3(256), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(ScaleParams, k_scale_table), dim3(cdiv((long)p.C * p.nblk, 256)), dim3(256), 0, p);
 }
 
 // The rounding of v_cvt_pk_u8_f32 (k_probe_cvt, once per process) -> the bias of quant16_sat8: 128.5 where the conversion
-// truncates, 128 where it rounds to nearest; 0 = not usable (the kernels keep quant_fast1).  `scratch`: 8 device words.
-float cvt_bias(Ctx& c, unsigned* scratch) {
-    static std::atomic<int> state{0};      // 0 unknown, 1 truncates, 2 rounds to nearest, 3 unusable
-    int st = state.load(std::memory_order_relaxed);
-    if (st == 0 && !c.dry && scratch) {
-        unsigned h[5] = {9, 9, 9, 9, 9};
-        hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(64), 0, c.st, scratch);
-        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c.st) == hipSuccess &&
-            hipStreamSynchronize(c.st) == hipSuccess) {
-            const bool sat = h[3] == 0 && h[4] == 255;
-            st = (sat && h[0] == 0 && h[1] == 1 && h[2] == 2) ? 1 : (sat && h[0] == 1 && h[1] == 2 && (h[2] == 2 || h[2] == 3)) ? 2 : 3;
-        } else { (void)hipGetLastError(); st = 3; }
-        if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] v_cvt_pk_u8_f32(0.7, 1.5, 2.5, -3, 300) = %u %u %u %u %u -> mode %d\n", h[0], h[1], h[2], h[3], h[4], st);
-        state.store(st, std::memory_order_relaxed);
-    }
+// truncates, 128 where it rounds to nearest; 0 = not usable (the kernels keep quant_fast1).  The probe writes 8 words of a
+// scratch allocation of its own (never the caller's workspace or output), under a mutex, on the caller's stream; only a probe
+// that RAN and returned unexpected values latches "unusable" -- a failed launch / copy / synchronisation (a capturing stream, ...)
+// leaves the state unknown: this call keeps quant_fast1 and the next one probes again.
+std::atomic<int> g_cvt_state{0};      // 0 unknown, 1 truncates, 2 rounds to nearest, 3 unusable
+void cvt_probe(hipStream_t stream) {
+    if (g_cvt_state.load(std::memory_order_acquire) != 0) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_cvt_state.load(std::memory_order_acquire) != 0) return;
+    static unsigned* scratch = nullptr;
+    if (!scratch && hipMalloc(&scratch, 8 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; return; }
+    unsigned h[5] = {9, 9, 9, 9, 9};
+    hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(64), 0, stream, scratch);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    const bool sat = h[3] == 0 && h[4] == 255;
+    const int st = (sat && h[0] == 0 && h[1] == 1 && h[2] == 2) ? 1 : (sat && h[0] == 1 && h[1] == 2 && (h[2] == 2 || h[2] == 3)) ? 2 : 3;
+    if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] v_cvt_pk_u8_f32(0.7, 1.5, 2.5, -3, 300) = %u %u %u %u %u -> mode %d\n", h[0], h[1], h[2], h[3], h[4], st);
+    g_cvt_state.store(st, std::memory_order_release);
+}
+float cvt_bias(Ctx& c) {
+    if (!c.dry && !c.grp) cvt_probe(c.st);         // (a group probes once, on the calling thread, before its members start)
+    const int st = g_cvt_state.load(std::memory_order_acquire);
     return st == 1 ? 128.5f : st == 2 ? 128.0f : 0.0f;
 }
 template <typename T> int launch_pack(Ctx& c, const PackParams& p_) {
@@ -241,7 +539,7 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p_) {
     PackParams p = p_;
     // the full symmetric 8-bit grid: quant16_sat8 once the conversion has been probed (the *_impl entry points do that first);
     // tuning 12 = 11 keeps quant_fast1 (A/B)
-    p.qbias = (sizeof(T) == 1 && p.mode == PACK_SYM && p.lo == -128 && p.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, nullptr) : 0.0f;
+    p.qbias = (sizeof(T) == 1 && p.mode == PACK_SYM && p.lo == -128 && p.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c) : 0.0f;
     const long total = (long)p.Z * p.Rp * (p.Kp / 16);
     if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack (%ld 16-element runs)", total);
     // (a pruned launch lets most candidate groups exit at once: fewer, longer-running workgroups)
@@ -249,30 +547,33 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p_) {
     if (p.mode == PACK_TWIN_I8) {
         if (sizeof(T) != 1 || p.C != 1 || p.c_inner != 0 || !p.scales || p.conv || p.zdiv > 0)
             return fail(P4V_ERR_UNSUPPORTED, "merged twin plane: one fixed row-major int8 plane only");
-        hipLaunchKernelGGL(k_pack_twin, dim3(blocks), dim3(256), 0, c.st, p);
-        HIPCHK(hipGetLastError());
-        return 0;
+        return enqueue(c, KERN(PackParams, k_pack_twin), dim3(blocks), dim3(256), 0, p);
     }
     if (tune(TUNE_PRINT) > 1) fprintf(stderr, "[p4v] k_pack stage %d: Z %d Rp %d Kp %d C %d crange %d done %d layout %d blocks %d\n", g_stage, p.Z, p.Rp, p.Kp, p.C, p.crange != nullptr, p.done != nullptr, p.c_inner, blocks);
-    hipLaunchKernelGGL(k_pack<T>, dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN_T(PackParams, k_pack, T), dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, p);
 }
 
-template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams& p, int epi, int cgroups = 1) {
+// epilogue dispatch of a kernel family: E = the metric's epilogue as a template argument
+#define P4V_EPI4(epi, X)                                   \
+    switch (epi) {                                         \
+        case EPI_SQ_W: { constexpr int E = EPI_SQ_W; X; }  \
+        case EPI_SQ: { constexpr int E = EPI_SQ; X; }      \
+        case EPI_ABS: { constexpr int E = EPI_ABS; X; }    \
+        default: { constexpr int E = EPI_W_SQ; X; }        \
+    }
+
+template <typename T, bool TWIN> int launch_sweep_epi(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const size_t lds = 2 * (TWIN ? 3 : 2) * SW_TILE_BYTES;
     dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
     switch (epi) {
-        case EPI_SQ_W: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ_W>), grid, block, lds, c.st, p); break;
-        case EPI_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_SQ>), grid, block, lds, c.st, p); break;
-        case EPI_ABS: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_ABS>), grid, block, lds, c.st, p); break;
-        case EPI_W_SQ: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_W_SQ>), grid, block, lds, c.st, p); break;
-        case EPI_STORE: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_STORE>), grid, block, lds, c.st, p); break;
-        case EPI_FWD: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_FWD>), grid, block, lds, c.st, p); break;
-        default: hipLaunchKernelGGL((k_sweep<T, TWIN, EPI_COS>), grid, block, lds, c.st, p); break;
+        case EPI_SQ_W: return enqueue(c, KERN_T(SweepParams, k_sweep, T, TWIN, EPI_SQ_W), grid, block, lds, p, si);
+        case EPI_SQ: return enqueue(c, KERN_T(SweepParams, k_sweep, T, TWIN, EPI_SQ), grid, block, lds, p, si);
+        case EPI_ABS: return enqueue(c, KERN_T(SweepParams, k_sweep, T, TWIN, EPI_ABS), grid, block, lds, p, si);
+        case EPI_W_SQ: return enqueue(c, KERN_T(SweepParams, k_sweep, T, TWIN, EPI_W_SQ), grid, block, lds, p, si);
+        case EPI_STORE: return enqueue(c, KERN1_T(SweepParams, k_sweep, T, TWIN, EPI_STORE), grid, block, lds, p, si);
+        case EPI_FWD: return enqueue(c, KERN1_T(SweepParams, k_sweep, T, TWIN, EPI_FWD), grid, block, lds, p, si);
+        default: return enqueue(c, KERN1_T(SweepParams, k_sweep, T, TWIN, EPI_COS), grid, block, lds, p, si);
     }
-    HIPCHK(hipGetLastError());
-    return 0;
 }
 
 // k_sweep2g: large K, column operand expanded, row operand invariant (weight search): two candidates per pass
@@ -281,55 +582,28 @@ bool sweep2g_ok(const SweepParams& p) {
            !(g_variant & 256);
 }
 
-template <bool TWIN> int launch_sweep2g_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool TWIN> int launch_sweep2g_epi(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const int per = 2 * cdiv(p.c1 - p.c0, 2 * cgroups);
     const size_t lds = (size_t)SW2_NS * (TWIN ? 4 : 3) * SW2_TILE + (size_t)per * 8 * sizeof(float) * (TWIN ? 3 : 2);
     dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
-#define P4V_LAUNCH2G(E)                                                                                        \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep2g<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep2g<TWIN, E>), grid, block, lds, c.st, p);                                   \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH2G(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH2G(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH2G(EPI_ABS); break;
-        default: P4V_LAUNCH2G(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH2G
-    HIPCHK(hipGetLastError());
-    return 0;
+    P4V_EPI4(epi, return enqueue(c, KERN_T(SweepParams, k_sweep2g, TWIN, E), grid, block, lds, p, si))
 }
 
-template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool TWIN> int launch_sweep2_epi(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
     const size_t lds = (size_t)SW2_NS * (TWIN ? 3 : 2) * SW2_TILE + (size_t)per * 8 * sizeof(float) * (TWIN ? 3 : 2);
     dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
-#define P4V_LAUNCH2(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false; /* benign race: the attribute is idempotent */                           \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep2<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep2<TWIN, E>), grid, block, lds, c.st, p);                                    \
-    } while (0)
     switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH2(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH2(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH2(EPI_ABS); break;
-        case EPI_FWD: P4V_LAUNCH2(EPI_FWD); break;
-        case EPI_STORE: P4V_LAUNCH2(EPI_STORE); break;
-        case EPI_COS: P4V_LAUNCH2(EPI_COS); break;
-        default: P4V_LAUNCH2(EPI_W_SQ); break;
+        case EPI_SQ_W: return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_SQ_W), grid, block, lds, p, si);
+        case EPI_SQ: return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_SQ), grid, block, lds, p, si);
+        case EPI_ABS: return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_ABS), grid, block, lds, p, si);
+        case EPI_FWD: return enqueue(c, KERN1_T(SweepParams, k_sweep2, TWIN, EPI_FWD), grid, block, lds, p, si);
+        case EPI_STORE:     // (the twin instance has no register to spare for the group prologue: single launches)
+            if constexpr (TWIN) return enqueue(c, KERN1_T(SweepParams, k_sweep2, TWIN, EPI_STORE), grid, block, lds, p, si);
+            else return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_STORE), grid, block, lds, p, si);
+        case EPI_COS: return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_COS), grid, block, lds, p, si);
+        default: return enqueue(c, KERN_T(SweepParams, k_sweep2, TWIN, EPI_W_SQ), grid, block, lds, p, si);
     }
-#undef P4V_LAUNCH2
-    HIPCHK(hipGetLastError());
-    return 0;
 }
 
 #ifdef P4V_TRACE
@@ -353,6 +627,12 @@ int trace_dump(Ctx& c, dim3 grid, int ktiles) {
 }
 #endif
 
+// the record of a timed sweep launch (bench.py roofline): every launch is recorded, also a stage whose device-side candidate
+// range is empty -- the records are the production launches, 1:1 with a kernel trace
+inline StatInfo stat_info(int kind, double macs, double alg, int gx, int gz, double bytes) {
+    return StatInfo{kind, macs * g_exec_frac, alg * g_exec_frac, g_stage, gx, gz, bytes};
+}
+
 int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair) {
     if (c.dry) return 0;
     const int per = pair ? 2 * cdiv(p.c1 - p.c0, 2 * cgroups) : cdiv(p.c1 - p.c0, cgroups);
@@ -361,68 +641,20 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
-    StatRec rec{};
-    if (timed) {
-        HIPCHK(hipEventCreate(&rec.a));
-        HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 5;
-        rec.macs = (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0);
-        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
-        HIPCHK(hipEventRecord(rec.a, c.st));
-    }
-#define P4V_LAUNCH4(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        static bool attr5_set = false;                                                                         \
-        if (!attr5_set) {                                                                                      \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep5<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr5_set = true;                                                                                  \
-        }                                                                                                      \
-        if (pair) hipLaunchKernelGGL((k_sweep5<E>), grid, block, lds, c.st, p);                                \
-        else hipLaunchKernelGGL((k_sweep4<E>), grid, block, lds, c.st, p);                                     \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH4(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH4(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH4(EPI_ABS); break;
-        default: P4V_LAUNCH4(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH4
-    HIPCHK(hipGetLastError());
+    const StatInfo si = stat_info(5, (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0), g_alg_macs_cand * (p.c1 - p.c0),
+                                  (int)grid.x, (int)grid.z, g_alg_bytes);
+    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    if (pair) { P4V_EPI4(epi, CHK(enqueue(c, KERN_T(Sweep3Params, k_sweep5, E), grid, block, lds, p, sp)); break) }
+    else { P4V_EPI4(epi, CHK(enqueue(c, KERN_T(Sweep3Params, k_sweep4, E), grid, block, lds, p, sp)); break) }
 #ifdef P4V_TRACE
     CHK(trace_dump(c, grid, p.ktiles));
 #endif
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = g_alg_bytes; g_stat_recs.push_back(rec);
-    }
     return 0;
 }
 
 template <int KT, int RB>
-int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds) {
-#define P4V_LAUNCH6(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep6<E, KT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep6<E, KT, RB>), grid, dim3(512 / RB), lds, c.st, p);                         \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH6(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH6(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH6(EPI_ABS); break;
-        default: P4V_LAUNCH6(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH6
-    return 0;
+int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds, const StatInfo* si) {
+    P4V_EPI4(epi, return enqueue(c, KERN_T(Sweep3Params, k_sweep6, E, KT, RB), grid, dim3(512 / RB), lds, p, si))
 }
 
 // k_sweep6 (stationary operand in registers): K = 192 / 256 / 384 / 512 / 768 bytes -- the Linear layers of
@@ -435,6 +667,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups);
 // one is mostly empty (ViT-B qkv: 900 tiles = 3.5 waves).  The tiles of the last, partial wave are launched separately
 // with their candidates split over q groups, so that it takes a fraction of a full wave's time; every group pays
 // the workgroup prologue (stationary operand + raw_out / raw_grad tile) again.  Cost model in microseconds.
+// (Inside a group the other members' tiles fill the last wave: no split.)
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups, int nc_model = 0) {
     if (c.dry) return 0;
     // (p.ntile > 0: only the tiles [p.tile0, p.tile0 + p.ntile) -- the open score blocks of a pruned pass; nc_model: the number of
@@ -445,7 +678,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups, int nc_mo
     const double P = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
     auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
     int q_best = 0;
-    if (rem > 0 && full > 0 && !(g_variant & 16384)) {
+    if (rem > 0 && full > 0 && !(g_variant & 16384) && c.par <= 1) {
         double best = waves((long)tiles * cgroups) * (P + cdiv(nc, cgroups) * t_c) * 0.97;   // the uniform plan
         for (int q = 1; q <= std::min(nc, 12); ++q) {
             const double t = waves(full) * (P + nc * t_c) + waves((long)rem * q) * (P + cdiv(nc, q) * t_c);
@@ -479,20 +712,13 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
-    StatRec rec{};
-    if (timed) {   // one record per kernel launch; a split sweep books its work in proportion to the tiles of each part
-        const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
-        HIPCHK(hipEventCreate(&rec.a));
-        HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = 2;
-        rec.macs = share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0);
-        rec.alg = share * g_alg_macs_cand * (p.c1 - p.c0);
-        rec.bytes = -share;        // (a split sweep books the pass's bytes in proportion to its tiles: resolved when the record is pushed)
-        HIPCHK(hipEventRecord(rec.a, c.st));
-    }
+    // one record per kernel launch; a split sweep books its work (and the pass's bytes) in proportion to the tiles of each part
+    const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
+    const StatInfo si = stat_info(2, share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0),
+                                  share * g_alg_macs_cand * (p.c1 - p.c0), (int)grid.x, (int)grid.z, share * g_alg_bytes);
+    const StatInfo* sp = g_stat_on ? &si : nullptr;
     int r;
-#define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds))
+#define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds, sp) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds, sp))
     switch (p.ktiles) {
         case 12: r = P4V_KT(12); break;
         case 8: r = P4V_KT(8); break;
@@ -502,14 +728,9 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     }
 #undef P4V_KT
     if (r) return r;
-    HIPCHK(hipGetLastError());
 #ifdef P4V_TRACE
     CHK(trace_dump(c, grid, p.ktiles));
 #endif
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = -rec.bytes * g_alg_bytes; g_stat_recs.push_back(rec);
-    }
     return 0;
 }
 
@@ -529,28 +750,11 @@ int sweep9_halves(const SweepParams& p, bool twin, int epi) {
     const double waste = (double)rup(p.M, 128) * rup(p.N, 128) / ((double)rup(p.M, 16) * rup(p.N, 16));
     return (waste >= 1.4 || (g_variant & 1048576)) ? halves : 0;
 }
-template <bool ROWS_FIXED> int launch_sweep9_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool ROWS_FIXED> int launch_sweep9_epi(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
     const size_t lds = (size_t)SW9_NS * SW9_STAGE + (size_t)per * SW9_NW * sizeof(float) * 2;
     dim3 grid(p.halves, p.Z, cgroups), block(SW9_NW * 64);
-#define P4V_LAUNCH9B(E)                                                                                        \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep9<ROWS_FIXED, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep9<ROWS_FIXED, E>), grid, block, lds, c.st, p);                              \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH9B(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH9B(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH9B(EPI_ABS); break;
-        default: P4V_LAUNCH9B(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH9B
-    HIPCHK(hipGetLastError());
-    return 0;
+    P4V_EPI4(epi, return enqueue(c, KERN_T(SweepParams, k_sweep9, ROWS_FIXED, E), grid, block, lds, p, si))
 }
 
 // k_sweep8: single k-tile (K <= 64) int8 sweep with the fixed operand's fragments in registers: q.k^T of every ViT / Swin
@@ -559,58 +763,24 @@ bool sweep8_ok(const SweepParams& p, bool twin, int epi) {
            !(g_variant & 65536);
 }
 
-template <bool ROWS_FIXED, bool SKIP> int launch_sweep8_epi_s(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool ROWS_FIXED, bool SKIP> int launch_sweep8_epi_s(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
     const size_t lds = (size_t)SW8_NS * SW2_TILE + (size_t)per * 8 * sizeof(float) * 2;
     dim3 grid(p.mtiles * p.ntiles, p.Z, cgroups), block(512);
-#define P4V_LAUNCH8(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep8<ROWS_FIXED, E, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep8<ROWS_FIXED, E, SKIP>), grid, block, lds, c.st, p);                        \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH8(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH8(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH8(EPI_ABS); break;
-        default: P4V_LAUNCH8(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH8
-    HIPCHK(hipGetLastError());
-    return 0;
+    P4V_EPI4(epi, return enqueue(c, KERN_T(SweepParams, k_sweep8, ROWS_FIXED, E, SKIP), grid, block, lds, p, si))
 }
 // The padding skip of k_sweep2 (wave parts without a valid element do no MFMA / epilogue work) is available here only as an A/B
 // switch (variant 262144): measured slower at 197 tokens (4 of 32 parts padding: 459 vs 428 us) AND at the 144 tokens of a Swin
 // window (17 of 32 parts: 10.0 vs 9.3 ms per module) -- a single-k-tile candidate is paced by its ring step (DMA landing +
 // barrier), not by the MFMAs and the epilogue it would skip.
-template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, int epi, int cgroups) {
+template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, int epi, int cgroups, const StatInfo* si) {
     const bool skip = (g_variant & 262144) != 0;
-    return skip ? launch_sweep8_epi_s<ROWS_FIXED, true>(c, p, epi, cgroups) : launch_sweep8_epi_s<ROWS_FIXED, false>(c, p, epi, cgroups);
+    return skip ? launch_sweep8_epi_s<ROWS_FIXED, true>(c, p, epi, cgroups, si) : launch_sweep8_epi_s<ROWS_FIXED, false>(c, p, epi, cgroups, si);
 }
 
 // k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)
-template <int TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds) {
-#define P4V_LAUNCH7(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep7<TWIN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sweep7<TWIN, E>), grid, dim3(512), lds, c.st, p);                                \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH7(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH7(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH7(EPI_ABS); break;
-        default: P4V_LAUNCH7(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH7
-    HIPCHK(hipGetLastError());
-    return 0;
+template <int TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds, const StatInfo* si) {
+    P4V_EPI4(epi, return enqueue(c, KERN_T(Sweep7Params, k_sweep7, TWIN, E), grid, dim3(512), lds, p, si))
 }
 
 int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups) {   // twin: 0 plain, 1 two planes, 2 merged plane
@@ -624,91 +794,49 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     Sweep7Params q = p;
     q.cgroups = cgroups;
     dim3 grid(p.rtiles * p.ctiles * cgroups, 1, 1);
-    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
-    StatRec rec{};
-    if (timed) {
-        HIPCHK(hipEventCreate(&rec.a));
-        HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = twin ? 4 : 3;
-        rec.macs = (double)p.rtiles * 256 * (double)p.ctiles * 256 * (double)p.ldk * nc;   // (twin: 128 samples x 2 planes)
-        rec.alg = g_alg_macs_cand * nc;
-        HIPCHK(hipEventRecord(rec.a, c.st));
-    }
-    CHK(twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds) : launch_sweep7_epi<0>(c, q, epi, grid, lds));
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.gx = (int)grid.x; rec.gz = (int)grid.z; rec.bytes = g_alg_bytes; g_stat_recs.push_back(rec);
-    }
-    return 0;
+    // (twin: 128 samples x 2 planes)
+    const StatInfo si = stat_info(twin ? 4 : 3, (double)p.rtiles * 256 * (double)p.ctiles * 256 * (double)p.ldk * nc, g_alg_macs_cand * nc,
+                                  (int)grid.x, (int)grid.z, g_alg_bytes);
+    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    return twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds, sp) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds, sp) : launch_sweep7_epi<0>(c, q, epi, grid, lds, sp);
 }
 
 int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool fast = false, int cgroups = 1) {
     if (c.dry) return 0;
-    const bool timed = g_stat_on;   // (every launch is recorded, also a stage whose device-side candidate range is empty: the records are the production launches, 1:1 with a kernel trace)
-    StatRec rec{};
-    if (timed) {
-        HIPCHK(hipEventCreate(&rec.a));
-        HIPCHK(hipEventCreate(&rec.b));
-        rec.kind = i8 ? 0 : 1;
-        const double kelems = (double)p.ldk / (i8 ? 1 : 4);
-        rec.macs = (double)p.mtiles * SW_BM * (double)p.ntiles * SW_BN * kelems * p.Z * (p.c1 - p.c0) * (twin ? 2 : 1);
-        rec.alg = g_alg_macs_cand * (p.c1 - p.c0);
-        HIPCHK(hipEventRecord(rec.a, c.st));
-    }
-    int r;
+    // kernel family of the record (p4v_launch_record.kind): 12 k_bound, 6 k_sweep9, 7 k_sweep8, 8 k_sweep2g, 9 k_sweep2, 0 / 1 generic int8 / fp32
+    const int kind = (fast && p.bound) ? 12 : (fast && p.halves > 0) ? 6 : (fast && sweep8_ok(p, twin, epi)) ? 7 :
+                     (fast && epi != EPI_COS && sweep2g_ok(p)) ? 8 : fast ? 9 : i8 ? 0 : 1;
+    const double kelems = (double)p.ldk / (i8 ? 1 : 4);
+    const StatInfo si = stat_info(kind, (double)p.mtiles * SW_BM * (double)p.ntiles * SW_BN * kelems * p.Z * (p.c1 - p.c0) * (twin ? 2 : 1),
+                                  g_alg_macs_cand * (p.c1 - p.c0),
+                                  (fast && p.bound) ? p.mtiles * p.ntiles * 2 : (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles, cgroups, g_alg_bytes);
+    const StatInfo* sp = g_stat_on ? &si : nullptr;
     if (fast && p.bound) {
         const dim3 grid(p.mtiles * p.ntiles * 2), block(256);      // 128 x 64 workgroup tiles
-        switch (epi) {
-            case EPI_SQ_W: hipLaunchKernelGGL((k_bound<EPI_SQ_W>), grid, block, 0, c.st, p); break;
-            case EPI_SQ: hipLaunchKernelGGL((k_bound<EPI_SQ>), grid, block, 0, c.st, p); break;
-            case EPI_ABS: hipLaunchKernelGGL((k_bound<EPI_ABS>), grid, block, 0, c.st, p); break;
-            default: hipLaunchKernelGGL((k_bound<EPI_W_SQ>), grid, block, 0, c.st, p); break;
-        }
-        r = hipGetLastError() == hipSuccess ? 0 : fail(P4V_ERR_HIP, "k_bound launch failed");
-    } else
-    if (fast && p.halves > 0) r = p.a_cs == 0 ? launch_sweep9_epi<true>(c, p, epi, cgroups) : launch_sweep9_epi<false>(c, p, epi, cgroups);
-    else if (fast && sweep8_ok(p, twin, epi)) r = p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups) : launch_sweep8_epi<false>(c, p, epi, cgroups);
-    else if (fast && epi != EPI_COS && sweep2g_ok(p)) r = twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups) : launch_sweep2g_epi<false>(c, p, epi, cgroups);
-    else if (fast) r = twin ? launch_sweep2_epi<true>(c, p, epi, cgroups) : launch_sweep2_epi<false>(c, p, epi, cgroups);
-    else if (i8) r = twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups);
-    else r = twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups) : launch_sweep_epi<float, false>(c, p, epi, cgroups);
-    if (timed) {
-        HIPCHK(hipEventRecord(rec.b, c.st));
-        // kernel family of the record (p4v_launch_record.kind): 6 k_sweep9, 7 k_sweep8, 8 k_sweep2g, 9 k_sweep2, 0 / 1 generic int8 / fp32
-        if (fast && p.bound) rec.kind = 12;
-        else if (fast && p.halves > 0) rec.kind = 6;
-        else if (fast && sweep8_ok(p, twin, epi)) rec.kind = 7;
-        else if (fast && epi != EPI_COS && sweep2g_ok(p)) rec.kind = 8;
-        else if (fast) rec.kind = 9;
-        rec.macs *= g_exec_frac; rec.alg *= g_exec_frac; rec.stage = g_stage; rec.bytes = g_alg_bytes;
-        rec.gx = (fast && p.bound) ? p.mtiles * p.ntiles * 2 : (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles; rec.gz = cgroups;
-        g_stat_recs.push_back(rec);
+        P4V_EPI4(epi, return enqueue(c, KERN_T(SweepParams, k_bound, E), grid, block, 0, p, sp))
     }
-    return r;
+    if (fast && p.halves > 0) return p.a_cs == 0 ? launch_sweep9_epi<true>(c, p, epi, cgroups, sp) : launch_sweep9_epi<false>(c, p, epi, cgroups, sp);
+    if (fast && sweep8_ok(p, twin, epi)) return p.a_cs == 0 ? launch_sweep8_epi<true>(c, p, epi, cgroups, sp) : launch_sweep8_epi<false>(c, p, epi, cgroups, sp);
+    if (fast && epi != EPI_COS && sweep2g_ok(p)) return twin ? launch_sweep2g_epi<true>(c, p, epi, cgroups, sp) : launch_sweep2g_epi<false>(c, p, epi, cgroups, sp);
+    if (fast) return twin ? launch_sweep2_epi<true>(c, p, epi, cgroups, sp) : launch_sweep2_epi<false>(c, p, epi, cgroups, sp);
+    if (i8) return twin ? launch_sweep_epi<int8_t, true>(c, p, epi, cgroups, sp) : launch_sweep_epi<int8_t, false>(c, p, epi, cgroups, sp);
+    return twin ? launch_sweep_epi<float, true>(c, p, epi, cgroups, sp) : launch_sweep_epi<float, false>(c, p, epi, cgroups, sp);
 }
 
 int launch_finish(Ctx& c, const FinishParams& p) {
-    if (c.dry) return 0;
-    hipLaunchKernelGGL(k_finish, dim3(p.C, p.nj), dim3(256), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(FinishParams, k_finish), dim3(p.C, p.nj), dim3(256), 0, p);
 }
 
 int launch_finish_cos(Ctx& c, const FinishCosParams& p) {
-    if (c.dry) return 0;
     const int gy = p.j_mode == 3 ? cdiv(p.S, 256) : p.nj;
-    hipLaunchKernelGGL(k_finish_cos, dim3(p.C, gy), dim3(p.j_mode == 3 ? 256 : 1024), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(FinishCosParams, k_finish_cos), dim3(p.C, gy), dim3(p.j_mode == 3 ? 256 : 1024), 0, p);
 }
 
 int launch_select(Ctx& c, const SelectParams& p_) {
     if (c.dry) return 0;
     SelectParams p = p_;
     attach_mirror(p);
-    hipLaunchKernelGGL(k_select, dim3(p.nj), dim3(128), 0, c.st, p);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return enqueue(c, KERN(SelectParams, k_select), dim3(p.nj), dim3(128), 0, p);
 }
 
 // ---- one search pass -------------------------------------------------------------------------------
@@ -808,6 +936,8 @@ static const long PLANE_BUDGET_DEFAULT = 6L << 30;  // bytes of candidate-expand
 // 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary
 // operand) again.  Cost model in microseconds, constants measured on MI355X (profiles/): minimise
 // rounds * (prologue + candidates_per_group * ktiles * tile_time).
+// (inside a group the lock-step members share the chip: each plans for its share of the workgroup slots)
+inline int cu_slots(const Ctx& c, int slots) { return std::max(8, slots / std::max(1, c.par)); }
 int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_us, double tile_us, int cg_max = 25) {
     int best = 1;
     double best_t = 1e30;
@@ -903,7 +1033,7 @@ int run_pass(Ctx& c, Pass& ps) {
         pc->buf = c.ws.get_top((size_t)exp_plane * chunk_al + slack);
         pc->done = reinterpret_cast<unsigned char*>(c.ws.get_top((size_t)rup(ps.eq_n, 256)));
         pc->assigned = true; pc->valid = false;
-        if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 0, (size_t)ps.eq_n, c.st));
+        if (!c.dry && pc->done) CHK(q_fill(c, pc->done, 0, (size_t)ps.eq_n));
     }
     char* rowbuf = (pc && ps.row.expanded) ? pc->buf : c.ws.get<char>((size_t)row_plane1 * (ps.row.expanded ? chunk_al : 1) + slack);
     char* row2buf = ps.twin ? c.ws.get<char>((size_t)row_plane1 * (ps.row2.expanded ? chunk : 1)) : nullptr;
@@ -951,21 +1081,19 @@ int run_pass(Ctx& c, Pass& ps) {
         pe.SR = a_search ? ps.Ncols : ps.Mrows; pe.TR = a_search ? ps.Mrows : ps.Ncols;
         pe.bias_on_t = a_search ? 0 : 1; pe.wt_mode = ps.wt_mode;
         pe.stiles = s6_stiles; pe.ttiles = s6_ttiles; pe.E = epi6;
-        if (zero_bias) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
+        if (zero_bias) CHK(q_fill(c, zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np)));
         const long chunks = (long)(epi6_bytes / 16);
-        hipLaunchKernelGGL(k_prep_epi6, dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 32)), dim3(256), 0, c.st, pe);
-        HIPCHK(hipGetLastError());
+        CHK(enqueue(c, KERN(PrepEpi6Params, k_prep_epi6), dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 32)), dim3(256), 0, pe));
     }
     if (ec) ec->valid = true;
     if (big7 && !c.dry) {
         PrepEpiParams pe{ps.O, ps.G ? ps.G : ps.O, ps.bias, ps.o_ms, ps.Mrows, ps.Ncols, ps.wt_mode,
                          Np / 256, Mp / (ps.twin ? 128 : 256), ps.twin ? 1 : 0, epi7};
         const long chunks = (long)Mp * Np * 2 / 4;
-        hipLaunchKernelGGL(k_prep_epi, dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 16)), dim3(256), 0, c.st, pe);
-        HIPCHK(hipGetLastError());
+        CHK(enqueue(c, KERN(PrepEpiParams, k_prep_epi), dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 16)), dim3(256), 0, pe));
     }
 
-    if (zero_bias && !c.dry) HIPCHK(hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np), c.st));
+    if (zero_bias && !c.dry) CHK(q_fill(c, zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np)));
     if (ps.use_s1 && !ps.s_ready) {
         ps.s1.S = S1; ps.s1.C = ps.eq_n; ps.s1.nblk = ps.s_cs;
         CHK(launch_scale(c, ps.s1));
@@ -1001,8 +1129,7 @@ int run_pass(Ctx& c, Pass& ps) {
         if (!c.dry) {
             const long total = (long)p1.Z * Mp * (Kp / 16);
             if (total >= (1L << 31)) return fail(P4V_ERR_UNSUPPORTED, "operand plane too large for k_pack_dual (%ld 16-element runs)", total);
-            hipLaunchKernelGGL(k_pack_dual, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 64)), dim3(256), 0, c.st, p1, p2);
-            HIPCHK(hipGetLastError());
+            CHK(enqueue(c, KERN(PackDualParams, k_pack_dual), dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 64)), dim3(256), 0, PackDualParams{p1, p2}));
         }
     } else {
         if (!ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, 1));
@@ -1019,18 +1146,18 @@ int run_pass(Ctx& c, Pass& ps) {
         if (ps.col.expanded && !packed) CHK(pack(ps.col, colbuf, NpB, ps.col_zs_shared, c0, nc));
         if (pc && !ps.crange && !packed) {   // every candidate is in the buffer now (a pruned pass packs a range and keeps flags)
             pc->valid = true;
-            if (!c.dry && pc->done) HIPCHK(hipMemsetAsync(pc->done, 1, (size_t)ps.eq_n, c.st));
+            if (!c.dry && pc->done) CHK(q_fill(c, pc->done, 1, (size_t)ps.eq_n));
         }
         if (g_stat_on && ps.crange && !c.dry) {     // roofline step only: how many of this launch's candidates run
             int h[2] = {0, 0};
-            HIPCHK(hipMemcpyAsync(h, ps.crange, sizeof h, hipMemcpyDeviceToHost, c.st));
-            HIPCHK(hipStreamSynchronize(c.st));
+            CHK(q_d2h(c, h, ps.crange, sizeof h));
+            CHK(q_sync(c));
             const int lo = std::max(h[0], c0), hi = std::min(h[1], c0 + nc);
             g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
             if ((rblk || rblk_z) && ps.nj <= 64) {               // equal-sized score blocks, each on its own range
                 int hb[128];
-                HIPCHK(hipMemcpyAsync(hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj, hipMemcpyDeviceToHost, c.st));
-                HIPCHK(hipStreamSynchronize(c.st));
+                CHK(q_d2h(c, hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj));
+                CHK(q_sync(c));
                 double sum = 0;
                 for (int j = 0; j < ps.nj; ++j) sum += std::max(0, std::min(std::min(hb[2 * j + 1], h[1]), c0 + nc) - std::max(std::max(hb[2 * j], h[0]), c0));
                 g_exec_frac = sum / ((double)nc * ps.nj);
@@ -1078,7 +1205,7 @@ int run_pass(Ctx& c, Pass& ps) {
                         qq.tile0 = tt0 * q.stiles; qq.ntile = (tt1 - tt0) * q.stiles;
                         const int ncr = std::max(1, hi - lo);
                         g_exec_frac = fsum / ((double)(j1 - j) * nc);
-                        int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, 256, P6, 0.14);
+                        int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, cu_slots(c, 256), P6, 0.14);
                         if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(ncr, tune(TUNE_CG6)));
                         if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 open blocks [%d, %d): tiles %d x %d ktiles %d cand %d -> cgroups %d\n", j, j1, q.stiles, tt1 - tt0, q.ktiles, ncr, cg6);
                         if (hi > lo && qq.ntile > 0) CHK(launch_sweep6(c, qq, ps.epi, cg6, ncr));
@@ -1086,14 +1213,14 @@ int run_pass(Ctx& c, Pass& ps) {
                     }
                     continue;
                 }
-                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, 256, P6, 0.14);
+                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, cu_slots(c, 256), P6, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d (%d known) -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, nc_known, cg6);
                 CHK(launch_sweep6(c, q, ps.epi, cg6, known ? nc_known : 0));
                 continue;
             }
             const long wgs = (long)q.stiles * q.ttiles;
-            const int cgroups = choose_cgroups(wgs, nc, q.ktiles, 256, 30.0, 0.15);
+            const int cgroups = choose_cgroups(wgs, nc, q.ktiles, cu_slots(c, 256), 30.0, 0.15);
             CHK(launch_sweep4(c, q, ps.epi, cgroups, pairs));
             continue;
         }
@@ -1114,7 +1241,7 @@ int run_pass(Ctx& c, Pass& ps) {
             // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
             // (up to one candidate per workgroup: stage A of a pruned pass is 3 tiles x 100 candidates -- with the 25 groups of the
             // other sweeps 75 workgroups on 256 CUs, 140-160 us per launch)
-            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, 256, 6.0, 0.62, 100);
+            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, cu_slots(c, 256), 6.0, 0.62, 100);
             if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
             q.order = tune(TUNE_ORDER7) > 0 ? tune(TUNE_ORDER7) - 1 : 1;
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);
@@ -1153,12 +1280,12 @@ int run_pass(Ctx& c, Pass& ps) {
             // generic sweep: 2 workgroups per CU; per k-tile step ~2.6 us with fp32 operands (8 x mfma_f32_32x32x2 per
             // 32x32 block), ~1.6 us on the int8 grid (measured on the patch-embedding search)
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
-            cgroups = choose_cgroups(wgs, nc, sp.ktiles, 512, 20.0, ps.i8 ? 1.6 : 2.6);
+            cgroups = choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, 512), 20.0, ps.i8 ? 1.6 : 2.6);
         }
         if (fast || fast_cos) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
-                                        : choose_cgroups(wgs, nc, sp.ktiles, ps.twin ? 256 : 512, ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
+                                        : choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, ps.twin ? 256 : 512), ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
         sp.bound = bound ? 1 : 0;
         if (bound) sp.dbg = tune(TUNE_B1_PATH) >= 16 ? (tune(TUNE_B1_PATH) >> 4) : 0;   // (tuning 12 = 16 / 32: k_bound timing ablations)
@@ -1170,7 +1297,7 @@ int run_pass(Ctx& c, Pass& ps) {
                 sp.rows_p_stream = sp.a_cs == 0 ? Np : Mp;
                 sp.p_zs = (long)h9 * SW9_NW; sp.p_cs = sp.p_zs * ps.Z;
                 nine_halves = h9;
-                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, SW9_NW == 4 ? 512 : 256, 12.0, 0.9);
+                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, cu_slots(c, SW9_NW == 4 ? 512 : 256), 12.0, 0.9);
             }
         }
         if (fast && !ps.store_out) {
@@ -1263,8 +1390,8 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
     const bool new_idx = sc->idx_src != wsrc || sc->idx_wt != g.wt_mode || (g.wt_mode != 1 && sc->o_src != g.O);
     if (new_idx) {
         // the heaviest rows of every segment by their share of the metric weight
-        hipLaunchKernelGGL(k_row_mass, dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, c.st, g.G ? g.G : g.O, g.O, zrows, (long)g.Ncols, g.wt_mode, sc->mass);
-        hipLaunchKernelGGL(k_topk_rows, dim3(g.segs), dim3(1024), 0, c.st, sc->mass, g.seg_rows, g.k, sc->idx);
+        CHK(enqueue(c, KERN(RowMassParams, k_row_mass), dim3((unsigned)cdiv(zrows, 4)), dim3(256), 0, RowMassParams{g.G ? g.G : g.O, g.O, zrows, (long)g.Ncols, g.wt_mode, sc->mass}));
+        CHK(enqueue(c, KERN(TopkParams, k_topk_rows), dim3(g.segs), dim3(1024), 0, TopkParams{sc->mass, g.seg_rows, g.k, sc->idx}));
         sc->idx_src = wsrc; sc->idx_wt = g.wt_mode;
         sc->o_src = sc->g_src = sc->r_src = nullptr;
         if (sc->frac && host_sync_ok && !(g_variant & 8388608)) {
@@ -1274,11 +1401,11 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
             // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
             // (variant 8388608: always prune)
             float f = 1.0f;
-            int* hm = tune(TUNE_B1_PATH) == 8 ? nullptr : host_mirror(c.st);
-            hipLaunchKernelGGL(k_mass_fraction, dim3(1), dim3(1024), 0, c.st, sc->mass, zrows, sc->idx, g.segs, g.seg_rows, g.k, sc->frac,
-                               hm ? reinterpret_cast<float*>(hm + 4) : nullptr);
-            if (!hm) HIPCHK(hipMemcpyAsync(&f, sc->frac, sizeof f, hipMemcpyDeviceToHost, c.st));
-            HIPCHK(hipStreamSynchronize(c.st));
+            int* hm = tune(TUNE_B1_PATH) == 8 ? nullptr : host_mirror(c);
+            CHK(enqueue(c, KERN(MassFracParams, k_mass_fraction), dim3(1), dim3(1024), 0,
+                        MassFracParams{sc->mass, zrows, sc->idx, g.segs, g.seg_rows, g.k, sc->frac, hm ? reinterpret_cast<float*>(hm + 4) : nullptr}));
+            if (!hm) CHK(q_d2h(c, &f, sc->frac, sizeof f));
+            CHK(q_sync(c));
             if (hm) f = *reinterpret_cast<volatile float*>(hm + 4);
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] slice holds %.4f of the metric weight (%d x %d of %d rows)\n", f, g.segs, g.k, g.seg_rows);
             sc->frac_host = f;
@@ -1293,10 +1420,11 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
         sc->k_eff = g.k;
     }
     const int rows = g.segs * g.k;
+    int gather_rc = 0;
     auto gather = [&](const float* src, long s0, long s3, int d3, float* dst, int seg, int zdiv, long sz2, long sz) {
         GatherParams gp{src, s0, 0, 0, s3, 1, 1, d3, sc->idx, rows, dst, seg, zdiv, sz2, sz};
         const long total = (long)rows * d3;
-        hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, gp);
+        if (const int r_ = enqueue(c, KERN(GatherParams, k_gather), dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, gp)) gather_rc = r_;
     };
     const int seg = g.lin ? 0 : g.k;
     const long o_seg = (long)g.seg_rows * g.Ncols;                // raw_out / raw_grad: dense [Z][M][N]
@@ -1305,14 +1433,13 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
     if (sc->r_src != g.row_src) {
         if (g.conv) {
             const long total = (long)rows * g.K;
-            hipLaunchKernelGGL(k_gather_im2col, dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, c.st, g.conv_pk, sc->idx, rows, sc->Rs);
+            CHK(enqueue(c, KERN(GatherIm2colParams, k_gather_im2col), dim3((unsigned)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, GatherIm2colParams{g.conv_pk, sc->idx, rows, sc->Rs}));
         } else if (g.lin) gather(g.row_src, g.s_r, 1, g.K, sc->Rs, 0, 1, 0, 0);
         else gather(g.row_src, g.s_r, g.s_k, g.K, sc->Rs, g.k, g.zdiv, g.s_z2, g.s_z);
         sc->r_src = g.row_src;
         sc->aplane.valid = false;
     }
-    HIPCHK(hipGetLastError());
-    return 0;
+    return gather_rc;
 }
 
 bool prune_ok(const Pass& ps) {
@@ -1340,14 +1467,14 @@ constexpr int PRUNE_FP32_CHAIN = 128 + 6;
 inline float prune_margin() { return std::max(1e-4f, 4.0f * 2.0f * (float)PRUNE_FP32_CHAIN * 5.9604645e-8f); }
 int prune_crosscheck_begin(Ctx& c, const float* interval, int n, std::vector<float>& keep) {
     keep.resize(n);
-    HIPCHK(hipMemcpyAsync(keep.data(), interval, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
-    HIPCHK(hipStreamSynchronize(c.st));
+    CHK(q_d2h(c, keep.data(), interval, sizeof(float) * n));
+    CHK(q_sync(c));
     return 0;
 }
 int prune_crosscheck_end(Ctx& c, const float* interval, int n, const std::vector<float>& pruned, const char* what) {
     std::vector<float> full(n);
-    HIPCHK(hipMemcpyAsync(full.data(), interval, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
-    HIPCHK(hipStreamSynchronize(c.st));
+    CHK(q_d2h(c, full.data(), interval, sizeof(float) * n));
+    CHK(q_sync(c));
     for (int i = 0; i < n; ++i)
         if (std::memcmp(&full[i], &pruned[i], sizeof(float)) != 0)
             return fail(P4V_ERR_INVALID, "exact candidate pruning selected another candidate than the full sweep (%s, output %d: %.9g vs %.9g)", what, i, (double)pruned[i], (double)full[i]);
@@ -1373,7 +1500,6 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
     int8_t* A2 = a.twin ? c.ws.get<int8_t>((size_t)Z * 16 * Kp) : nullptr;
     const bool v2 = tune(TUNE_B1_PATH) != 10;           // k_slice_b2 (B in registers, waves deal the column blocks); 12 = 10: k_slice_b (A/B)
     float* part = c.ws.get<float>((size_t)a.eq_n * Z * (v2 ? 4 : 1));
-    unsigned* probe = c.ws.get<unsigned>(8);
     float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     float* S2 = !a.twin ? nullptr : a.S2_pre ? a.S2_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
@@ -1403,71 +1529,34 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
         // k_slice_b: >= 1024 workgroups, >= 4 candidates each (one per wave); k_slice_b2: every wave runs every candidate of its
         // workgroup, the prologue (B -> registers) is paid per workgroup: >= 512 workgroups of >= 10 candidates
         // (k_slice_b2 keeps 3 workgroups per CU -- 2 with the twin's second accumulator set, 250 registers: whole rounds of 256 x that)
-        const int slots = 256 * (a.twin ? 2 : 3);
-        int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(512, Z)));
+        const int slots = std::max(8, 256 * (a.twin ? 2 : 3) / std::max(1, c.par));
+        int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(std::max(1, 512 / std::max(1, c.par)), Z)));
         // no mostly-empty last round -- where the rounds are few (ViT: 384 batch entries; with tens of thousands of them, Swin's
         // windows, the tail does not matter and more groups only repeat the prologue)
         while ((long)Z * g2 < 4L * slots && g2 < a.eq_n / 10 && ((long)Z * g2) % slots != 0 && ((long)Z * g2) % slots < slots * 3 / 4) ++g2;
         if (tune(TUNE_CG2) > 0) g2 = std::max(1, std::min(a.eq_n, tune(TUNE_CG2)));
-        const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
+        const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / std::max(1, c.par)), Z)));
         const dim3 grid(Z, groups), block(256);
-        const float qbias = (v2 && b.lo == -128 && b.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, probe) : 0.0f;   // 12 = 11: quant_fast1 in k_slice_b2 (A/B)
-        const bool timed = g_stat_on;
-        StatRec rec{};
-        if (timed) {
-            HIPCHK(hipEventCreate(&rec.a));
-            HIPCHK(hipEventCreate(&rec.b));
-            rec.kind = 13;
-            rec.alg = (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n;
-            rec.macs = 16.0 * nb * 16 * Kp * Z * a.eq_n * (a.twin ? 2 : 1);
-            HIPCHK(hipEventRecord(rec.a, c.st));
-        }
-#define P4V_LAUNCH_SB(TW, KTM, NBM, E)                                                                          \
-        do {                                                                                                    \
-            static bool attr_set = false;                                                                       \
-            if (!attr_set) {                                                                                    \
-                HIPCHK(hipFuncSetAttribute((const void*)k_slice_b<TW, KTM, NBM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
-                attr_set = true;                                                                                \
-            }                                                                                                   \
-            hipLaunchKernelGGL((k_slice_b<TW, KTM, NBM, E>), grid, block, lds, c.st, kp);                       \
-        } while (0)
-#define P4V_LAUNCH_SB_E(TW, KTM, NBM)                                                                           \
-        switch (a.epi) {                                                                                        \
-            case EPI_SQ_W: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_SQ_W); break;                                        \
-            case EPI_SQ: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_SQ); break;                                            \
-            case EPI_ABS: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_ABS); break;                                          \
-            default: P4V_LAUNCH_SB(TW, KTM, NBM, EPI_W_SQ); break;                                              \
-        }
+        const float qbias = (v2 && b.lo == -128 && b.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c) : 0.0f;   // 12 = 11: quant_fast1 in k_slice_b2 (A/B)
+        const StatInfo si{13, 16.0 * nb * 16 * Kp * Z * a.eq_n * (a.twin ? 2 : 1), (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n, g_stage, Z, groups,
+                          4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z};
+        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        int r_ = 0;
         if (v2) {
             SliceB2Params kp2{kp, qbias};
-#define P4V_LAUNCH_SB2(TW, KTM, NBW, E)                                                                          \
-            do {                                                                                                 \
-                if (qbias != 0.0f) hipLaunchKernelGGL((k_slice_b2<TW, KTM, NBW, E, true>), grid, block, 0, c.st, kp2);   \
-                else hipLaunchKernelGGL((k_slice_b2<TW, KTM, NBW, E, false>), grid, block, 0, c.st, kp2);        \
-            } while (0)
-#define P4V_LAUNCH_SB2_E(TW, KTM, NBW)                                                                           \
-            switch (a.epi) {                                                                                     \
-                case EPI_SQ_W: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_SQ_W); break;                                    \
-                case EPI_SQ: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_SQ); break;                                        \
-                case EPI_ABS: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_ABS); break;                                      \
-                default: P4V_LAUNCH_SB2(TW, KTM, NBW, EPI_W_SQ); break;                                          \
-            }
-            if (Kp == 64) { if (a.twin) P4V_LAUNCH_SB2_E(true, 1, 4) else P4V_LAUNCH_SB2_E(false, 1, 4) }
-            else { if (a.twin) P4V_LAUNCH_SB2_E(true, 4, 1) else P4V_LAUNCH_SB2_E(false, 4, 1) }
-#undef P4V_LAUNCH_SB2_E
+#define P4V_LAUNCH_SB2(TW, KTM, NBW)                                                                                                  \
+            P4V_EPI4(a.epi, r_ = (qbias != 0.0f) ? enqueue(c, KERN_T(SliceB2Params, k_slice_b2, TW, KTM, NBW, E, true), grid, block, 0, kp2, sp)   \
+                                                 : enqueue(c, KERN_T(SliceB2Params, k_slice_b2, TW, KTM, NBW, E, false), grid, block, 0, kp2, sp); break)
+            if (Kp == 64) { if (a.twin) { P4V_LAUNCH_SB2(true, 1, 4) } else { P4V_LAUNCH_SB2(false, 1, 4) } }
+            else { if (a.twin) { P4V_LAUNCH_SB2(true, 4, 1) } else { P4V_LAUNCH_SB2(false, 4, 1) } }
 #undef P4V_LAUNCH_SB2
-        } else
-        if (Kp == 64) { if (a.twin) P4V_LAUNCH_SB_E(true, 1, 13) else P4V_LAUNCH_SB_E(false, 1, 13) }
-        else { if (a.twin) P4V_LAUNCH_SB_E(true, 4, 4) else P4V_LAUNCH_SB_E(false, 4, 4) }
-#undef P4V_LAUNCH_SB_E
+        } else {
+#define P4V_LAUNCH_SB(TW, KTM, NBM) P4V_EPI4(a.epi, r_ = enqueue(c, KERN_T(SliceBParams, k_slice_b, TW, KTM, NBM, E), grid, block, lds, kp, sp); break)
+            if (Kp == 64) { if (a.twin) { P4V_LAUNCH_SB(true, 1, 13) } else { P4V_LAUNCH_SB(false, 1, 13) } }
+            else { if (a.twin) { P4V_LAUNCH_SB(true, 4, 4) } else { P4V_LAUNCH_SB(false, 4, 4) } }
 #undef P4V_LAUNCH_SB
-        HIPCHK(hipGetLastError());
-        if (timed) {
-            HIPCHK(hipEventRecord(rec.b, c.st));
-            rec.stage = g_stage; rec.gx = Z; rec.gz = groups;
-            rec.bytes = 4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z;
-            g_stat_recs.push_back(rec);
         }
+        if (r_) return r_;
     }
     const int pw = v2 ? 4 : 1;                          // floats per (candidate, batch entry): one per wave of k_slice_b2
     FinishParams fp{part, (long)Z * pw, (long)pw, pw, 1, Z, pw, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
@@ -1492,7 +1581,6 @@ int run_slice_a(Ctx& c, Pass& a, float* SA) {
     const size_t mark = c.ws.off;
     int8_t* Bp = c.ws.get<int8_t>((size_t)Z * nb * 16 * 64);
     float* part = c.ws.get<float>((size_t)a.eq_n * Z);
-    unsigned* probe = c.ws.get<unsigned>(8);
     float* S1 = a.S1_pre ? a.S1_pre : c.ws.get<float>((size_t)a.eq_n * a.s_cs);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     if (!a.s_ready) {
@@ -1512,32 +1600,13 @@ int run_slice_a(Ctx& c, Pass& a, float* SA) {
         kp.S1 = S1; kp.s_cs = a.s_cs; kp.s_div = a.sb_div;
         kp.O = a.O; kp.Wt = a.G ? a.G : a.O; kp.wt_mode = a.wt_mode;
         kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
-        kp.qbias = (r.lo == -128 && r.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c, probe) : 0.0f;
-        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(1024, Z)));
+        kp.qbias = (r.lo == -128 && r.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c) : 0.0f;
+        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / std::max(1, c.par)), Z)));
         const dim3 grid(Z, groups), block(256);
-        const bool timed = g_stat_on;
-        StatRec rec{};
-        if (timed) {
-            HIPCHK(hipEventCreate(&rec.a));
-            HIPCHK(hipEventCreate(&rec.b));
-            rec.kind = 14;
-            rec.alg = (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n;
-            rec.macs = 16.0 * nb * 16 * 64 * Z * a.eq_n;
-            HIPCHK(hipEventRecord(rec.a, c.st));
-        }
-        switch (a.epi) {
-            case EPI_SQ_W: hipLaunchKernelGGL((k_slice_a<13, EPI_SQ_W>), grid, block, 0, c.st, kp); break;
-            case EPI_SQ: hipLaunchKernelGGL((k_slice_a<13, EPI_SQ>), grid, block, 0, c.st, kp); break;
-            case EPI_ABS: hipLaunchKernelGGL((k_slice_a<13, EPI_ABS>), grid, block, 0, c.st, kp); break;
-            default: hipLaunchKernelGGL((k_slice_a<13, EPI_W_SQ>), grid, block, 0, c.st, kp); break;
-        }
-        HIPCHK(hipGetLastError());
-        if (timed) {
-            HIPCHK(hipEventRecord(rec.b, c.st));
-            rec.stage = g_stage; rec.gx = Z; rec.gz = groups;
-            rec.bytes = 4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z;
-            g_stat_recs.push_back(rec);
-        }
+        const StatInfo si{14, 16.0 * nb * 16 * 64 * Z * a.eq_n, (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n, g_stage, Z, groups,
+                          4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z};
+        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        P4V_EPI4(a.epi, CHK(enqueue(c, KERN_T(SliceAParams, k_slice_a, 13, E), grid, block, 0, kp, sp)); break)
     }
     FinishParams fp{part, (long)Z, 1L, 1, 1, Z, 1, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
     CHK(launch_finish(c, fp));
@@ -1656,7 +1725,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     PruneParams pp{SA, SB, ps.eq_n, ps.nj, prune_margin(), r1, r1, virt ? 1 : 0, best_idx, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, vrow};
     g_stage = 1;
     { const int r_ = slice_b_ok(a) ? run_slice_b(c, a, SA) : slice_a_ok(a) ? run_slice_a(c, a, SA) : run_pass(c, a); g_stage = 0; if (r_) return r_; }
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    CHK(enqueue(c, KERN(PruneParams, k_prune_pick), dim3(1), dim3(256), 0, pp));
     // stage B1: the stage-A winners on all samples -> the bound
     Pass b1 = ps;
     b1.scores_keep = SB; b1.no_select = true;
@@ -1678,7 +1747,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     { const int r_ = run_pass(c, b1); g_stage = 0; if (r_) return r_; }
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2; pp.rblk = rblk2;
-    int* hm = (ps.host_sync_ok && !c.dry && tune(TUNE_B1_PATH) != 8) ? host_mirror(c.st) : nullptr;
+    int* hm = (ps.host_sync_ok && !c.dry && tune(TUNE_B1_PATH) != 8) ? host_mirror(c) : nullptr;
     pp.r_host = hm; pp.rblk_host = hm ? hm + 8 : nullptr;
     int hblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // host copy of the per-block ranges stage A2 / B2 run on (nj <= 4)
     int hlo = 0, hhi = 0;
@@ -1687,15 +1756,14 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     SelectParams hsl{SB, ps.eq_n, ps.nj, ps.cands, ps.cand_cs, ps.cand_js, ps.cand_off, hull_selects ? ps.interval : nullptr,
                      ps.out_js, ps.out_off, ps.aux_out, ps.aux_div, nullptr, 0, ps.best_out};
     attach_mirror(hsl);
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl); HIPCHK(hipGetLastError()); }
+    CHK(enqueue(c, KERN(HullParams, k_prune_hull), dim3(1), dim3(256), 0, HullParams{pp, hsl}));
     // nothing survives besides stage B1's candidates: the pass's selection without another sweep
     auto select_without_b2 = [&]() -> int {
         PRUNE_COUNT(1);
         if (hull_selects) {}          // k_prune_hull made the selection
         else if (virt) {          // every block's only survivor is its stage-A winner: the table with those entries filled in
-            hipLaunchKernelGGL(k_fill_f32, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, -INFINITY, (int)tab);
-            hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
-            HIPCHK(hipGetLastError());
+            CHK(enqueue(c, KERN(FillParams, k_fill_f32), dim3(cdiv((long)tab, 256)), dim3(256), 0, FillParams{S2, -INFINITY, (int)tab}));
+            CHK(enqueue(c, KERN(MergeVirtParams, k_merge_virtual), dim3(cdiv(ps.nj, 64)), dim3(64), 0, MergeVirtParams{S2, SB, best_idx, ps.nj}));
             CHK(launch_pass_select(c, ps, S2));
         } else CHK(launch_pass_select(c, ps, SB));
         c.ws.off = mark;
@@ -1706,8 +1774,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         // the caller synchronises after this pass anyway: read the survivor range (8 bytes); in the usual case stage B1's
         // candidates are the only survivors and its totals decide -- the ~10 launches of an empty stage B2 are not made
         int h[2] = {0, 1};
-        if (!hm) HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
-        HIPCHK(hipStreamSynchronize(c.st));
+        if (!hm) CHK(q_d2h(c, h, r2, sizeof h));
+        CHK(q_sync(c));
         if (hm) { h[0] = reinterpret_cast<volatile int*>(hm)[0]; h[1] = reinterpret_cast<volatile int*>(hm)[1]; }
         if (h[0] >= h[1]) return select_without_b2();
         nsurv = h[1] - h[0];
@@ -1736,11 +1804,10 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         if (!c.dry) {
             PruneParams pp2 = pp;                 // same bound L* (stage B1's totals), the tighter partial sums, hull into r3
             pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3; pp2.rblk_host = hm ? hm + 16 : nullptr;
-            hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp2, hsl);
-            HIPCHK(hipGetLastError());
+            CHK(enqueue(c, KERN(HullParams, k_prune_hull), dim3(1), dim3(256), 0, HullParams{pp2, hsl}));
             int h[2] = {0, 1};
-            if (!hm) HIPCHK(hipMemcpyAsync(h, r3, sizeof h, hipMemcpyDeviceToHost, c.st));
-            HIPCHK(hipStreamSynchronize(c.st));
+            if (!hm) CHK(q_d2h(c, h, r3, sizeof h));
+            CHK(q_sync(c));
             if (hm) { h[0] = reinterpret_cast<volatile int*>(hm)[2]; h[1] = reinterpret_cast<volatile int*>(hm)[3]; }
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] second tier: %d survivors of the %d-row slice -> %d of the %d-row slice (M %d N %d K %d)\n", nsurv, k, std::max(0, h[1] - h[0]), k2, ps.Mrows, ps.Ncols, ps.K);
             if (h[0] >= h[1]) return select_without_b2();
@@ -1761,9 +1828,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     // entries stage B2 did NOT evaluate (-inf) with stage B1's -- i.e. it matters when the device-side range was empty and this
     // path ran without the host knowing (no pass memo): then every block's only survivor is stage B1's candidate.
     if (!c.dry) {
-        if (virt) hipLaunchKernelGGL(k_merge_virtual, dim3(cdiv(ps.nj, 64)), dim3(64), 0, c.st, S2, SB, best_idx, ps.nj);
-        else hipLaunchKernelGGL(k_merge_scores, dim3(cdiv((long)tab, 256)), dim3(256), 0, c.st, S2, SB, (int)tab);
-        HIPCHK(hipGetLastError());
+        if (virt) CHK(enqueue(c, KERN(MergeVirtParams, k_merge_virtual), dim3(cdiv(ps.nj, 64)), dim3(64), 0, MergeVirtParams{S2, SB, best_idx, ps.nj}));
+        else CHK(enqueue(c, KERN(MergeParams, k_merge_scores), dim3(cdiv((long)tab, 256)), dim3(256), 0, MergeParams{S2, SB, (int)tab}));
         CHK(launch_pass_select(c, ps, S2));
     }
     c.ws.off = mark;
@@ -1781,27 +1847,10 @@ struct SosSplitJob {
 bool sos_split_ok(int M, int K, int N, bool cosm) {
     return !cosm && K <= 200 && M <= 256 && N <= 64 && !(g_variant & 131072);
 }
-template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int epi) {
+template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int epi, const StatInfo* si) {
     const dim3 grid(kp.halves, kp.Z), block(256);
     const size_t lds = (size_t)2 * KS * 64 * sizeof(float);
-#define P4V_LAUNCH9(E)                                                                                         \
-    do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)k_sos_split<KS, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_sos_split<KS, E>), grid, block, lds, c.st, kp);                                  \
-    } while (0)
-    switch (epi) {
-        case EPI_SQ_W: P4V_LAUNCH9(EPI_SQ_W); break;
-        case EPI_SQ: P4V_LAUNCH9(EPI_SQ); break;
-        case EPI_ABS: P4V_LAUNCH9(EPI_ABS); break;
-        default: P4V_LAUNCH9(EPI_W_SQ); break;
-    }
-#undef P4V_LAUNCH9
-    HIPCHK(hipGetLastError());
-    return 0;
+    P4V_EPI4(epi, return enqueue(c, KERN_T(SosSplitParams, k_sos_split, KS, E), grid, block, lds, kp, si))
 }
 // one launch of the split-search kernel on `kp` (+ k_finish into `scores`, [C] floats); `crange`: device-side candidate range
 SelectParams sos_select_params(const SosSplitJob& j, const float* scores) {
@@ -1813,34 +1862,21 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
     kp.part = part; kp.crange = crange;
     if (!c.dry) {
-        HIPCHK(hipMemsetAsync(part, 0, sizeof(float) * (size_t)kp.C * kp.Z * slots, c.st));   // slots of all-padding waves
-        const bool timed = g_stat_on;
-        StatRec rec{};
+        CHK(q_fill(c, part, 0, sizeof(float) * (size_t)kp.C * kp.Z * slots));   // slots of all-padding waves
         const int KS = kp.K <= 64 ? 32 : kp.K <= 144 ? 72 : 100;
-        if (timed) {
-            double frac = 1.0;
-            if (crange) {
-                int h[2] = {0, kp.C};
-                HIPCHK(hipMemcpyAsync(h, crange, sizeof h, hipMemcpyDeviceToHost, c.st));
-                HIPCHK(hipStreamSynchronize(c.st));
-                frac = (double)std::max(0, std::min(h[1], kp.C) - std::max(h[0], 0)) / kp.C;
-            }
-            HIPCHK(hipEventCreate(&rec.a));
-            HIPCHK(hipEventCreate(&rec.b));
-            rec.kind = 11;
-            rec.macs = frac * (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C;
-            rec.alg = frac * (double)kp.Z * kp.M * kp.K * kp.N * kp.C;
-            HIPCHK(hipEventRecord(rec.a, c.st));
+        double frac = 1.0;
+        if (g_stat_on && crange) {
+            int h[2] = {0, kp.C};
+            CHK(q_d2h(c, h, crange, sizeof h));
+            CHK(q_sync(c));
+            frac = (double)std::max(0, std::min(h[1], kp.C) - std::max(h[0], 0)) / kp.C;
         }
-        if (KS == 32) CHK(launch_sos_split_ks<32>(c, kp, j.epi));
-        else if (KS == 72) CHK(launch_sos_split_ks<72>(c, kp, j.epi));
-        else CHK(launch_sos_split_ks<100>(c, kp, j.epi));
-        if (timed) {
-            HIPCHK(hipEventRecord(rec.b, c.st));
-            rec.stage = g_stage; rec.gx = kp.halves; rec.gz = kp.Z;
-            rec.bytes = 4.0 * ((double)kp.Z * kp.M * kp.K + (double)kp.Z * kp.K * kp.N) + 8.0 * (double)kp.Z * kp.M * kp.N;
-            g_stat_recs.push_back(rec);
-        }
+        const StatInfo si{11, frac * (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C, frac * (double)kp.Z * kp.M * kp.K * kp.N * kp.C, g_stage, kp.halves, kp.Z,
+                          4.0 * ((double)kp.Z * kp.M * kp.K + (double)kp.Z * kp.K * kp.N) + 8.0 * (double)kp.Z * kp.M * kp.N};
+        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        if (KS == 32) CHK(launch_sos_split_ks<32>(c, kp, j.epi, sp));
+        else if (KS == 72) CHK(launch_sos_split_ks<72>(c, kp, j.epi, sp));
+        else CHK(launch_sos_split_ks<100>(c, kp, j.epi, sp));
     }
     FinishParams fp{part, (long)kp.Z * slots, (long)slots, slots, 1, kp.Z, slots, kp.C, 0, 1, 1, j.norm, scores, crange};
     return launch_finish(c, fp);
@@ -1897,27 +1933,25 @@ int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j) {
     PruneParams pp{SA, SB, kp.C, 1, prune_margin(), r1, r1, 0, nullptr, nullptr, 0, 0, 0, nullptr};
     g_stage = 1;
     { const int r_ = sos_sweep(c, j, a, nullptr, SA); g_stage = 0; if (r_) return r_; }
-    if (!c.dry) { hipLaunchKernelGGL(k_prune_pick, dim3(1), dim3(256), 0, c.st, pp); HIPCHK(hipGetLastError()); }
+    CHK(enqueue(c, KERN(PruneParams, k_prune_pick), dim3(1), dim3(256), 0, pp));
     g_stage = 2;
     { const int r_ = sos_sweep(c, j, kp, r1, SB); g_stage = 0; if (r_) return r_; }   // B1
     pp.r_out = r2;                                // (+ the selection from its totals when nothing else survives)
     if (!c.dry) {
         SelectParams hsl = sos_select_params(j, SB);
         attach_mirror(hsl);
-        hipLaunchKernelGGL(k_prune_hull, dim3(1), dim3(256), 0, c.st, pp, hsl);
-        HIPCHK(hipGetLastError());
+        CHK(enqueue(c, KERN(HullParams, k_prune_hull), dim3(1), dim3(256), 0, HullParams{pp, hsl}));
     }
     if (j.host_sync_ok && !c.dry) {
         int h[2] = {0, 1};
-        HIPCHK(hipMemcpyAsync(h, r2, sizeof h, hipMemcpyDeviceToHost, c.st));
-        HIPCHK(hipStreamSynchronize(c.st));
+        CHK(q_d2h(c, h, r2, sizeof h));
+        CHK(q_sync(c));
         if (h[0] >= h[1]) { PRUNE_COUNT(1); c.ws.off = mark; return 0; }
     }
     g_stage = 3;
     { const int r_ = sos_sweep(c, j, kp, r2, S2); g_stage = 0; if (r_) return r_; }   // B2
     if (!c.dry) {
-        hipLaunchKernelGGL(k_merge_scores, dim3(1), dim3(256), 0, c.st, S2, SB, kp.C);
-        HIPCHK(hipGetLastError());
+        CHK(enqueue(c, KERN(MergeParams, k_merge_scores), dim3(1), dim3(256), 0, MergeParams{S2, SB, kp.C}));
     }
     CHK(sos_select(c, j, S2));
     c.ws.off = mark;
@@ -1943,27 +1977,26 @@ struct PassMemo {
 int read_dev(Ctx& c, const float* d, int n, std::vector<float>& h) {
     h.resize(n);
     if (IvMirror* m = mirror_of(d); m && m->valid && m->count == n) {      // the selection that wrote `d` also wrote the mirror
-        HIPCHK(hipStreamSynchronize(c.st));
+        CHK(q_sync(c));
         const volatile float* src = m->host;
         for (int i = 0; i < n; ++i) h[i] = src[i];
         return 0;
     }
-    HIPCHK(hipMemcpyAsync(h.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, c.st));
-    HIPCHK(hipStreamSynchronize(c.st));
-    return 0;
+    CHK(q_d2h(c, h.data(), d, sizeof(float) * n));
+    return q_sync(c);
 }
 
 int write_dev(Ctx& c, float* d, const std::vector<float>& h) {
     if (IvMirror* m = mirror_of(d)) m->valid = false;
-    HIPCHK(hipMemcpyAsync(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, c.st));
-    HIPCHK(hipStreamSynchronize(c.st));   // h may go out of scope
-    return 0;
+    CHK(q_h2d(c, d, h.data(), sizeof(float) * h.size()));
+    if (c.grp) return 0;                    // (a group's queue holds a copy of the data: the restore needs no round trip)
+    return q_sync(c);                       // h may go out of scope
 }
 
 // binds the interval vectors of one *_impl call (the ones its pass memo reads back) to the stream's mapped block
 struct MirrorScope {
     MirrorScope(Ctx& c, bool on, const float* a, const float* b = nullptr, const float* d3 = nullptr) {
-        float* base = (on && !c.dry && tune(TUNE_B1_PATH) != 8) ? reinterpret_cast<float*>(host_mirror(c.st)) : nullptr;
+        float* base = (on && !c.dry && tune(TUNE_B1_PATH) != 8) ? reinterpret_cast<float*>(host_mirror(c)) : nullptr;
         const float* devs[MIR_SLOTS] = {a, b, d3};
         for (int i = 0; i < MIR_SLOTS; ++i)
             g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + 32 + i * MIR_SLOT : nullptr, false, 0};
@@ -2019,7 +2052,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     if (cosm && !fwd_out && (nH > 1 || nA > 1)) return fail(P4V_ERR_UNSUPPORTED, "linear: cosine with n_H>1 / n_a>1 is not implemented on the GPU");
     const int ncand = d->eq_n + 1;
 
-    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
+    cvt_bias(c);     // (first call of the process: probe the conversion quant16_sat8 relies on)
     // ---- interval initialisation (linear.py:380-397 / 576-599) ---------------------------------------
     unsigned* enc_w = c.ws.get<unsigned>((size_t)nV * nH);
     unsigned* enc_a = c.ws.get<unsigned>((size_t)nA);
@@ -2134,8 +2167,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     mp.x = w_iv; mp.x_cs = 0; mp.x_js = 1; mp.y = nullptr; mp.y_const = 1.0f; mp.C = ncand; mp.nblk = nV * nH; mp.S = w_mix;
                     CHK(launch_scale(c, mp));
                     for (int v = 0; v < nV; ++v)
-                        HIPCHK(hipMemcpy2DAsync(w_mix + v * nH + h, sizeof(float) * nV * nH, w_cands + v * nH + h,
-                                                sizeof(float) * nV * nH, sizeof(float), ncand, hipMemcpyDeviceToDevice, c.st));
+                        CHK(q_copy2d(c, w_mix + v * nH + h, sizeof(float) * nV * nH, w_cands + v * nH + h, sizeof(float) * nV * nH, sizeof(float), ncand));
                 }
                 wc = w_mix;
             }
@@ -2192,8 +2224,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     ScaleParams mp{};
                     mp.x = a_iv; mp.x_cs = 0; mp.x_js = 1; mp.y = nullptr; mp.y_const = 1.0f; mp.C = ncand; mp.nblk = nA; mp.S = a_mix;
                     CHK(launch_scale(c, mp));
-                    HIPCHK(hipMemcpy2DAsync(a_mix + a, sizeof(float) * nA, a_cands + a, sizeof(float) * nA, sizeof(float), ncand,
-                                            hipMemcpyDeviceToDevice, c.st));
+                    CHK(q_copy2d(c, a_mix + a, sizeof(float) * nA, a_cands + a, sizeof(float) * nA, sizeof(float), ncand));
                 }
                 ac = a_mix;
             }
@@ -2273,7 +2304,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     const bool cosm = epi == EPI_COS;
     if (wt_mode == 1 && !G && !fwd_out && sg.searches()) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
     if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
-    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
+    cvt_bias(c);     // (first call of the process: probe the conversion quant16_sat8 relies on)
     const int ncand = d->eq_n + 1;
     const int NSPLIT = 20;  // matmul.py:636
 
@@ -2304,8 +2335,8 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
         if (d->sos && !c.dry) {
             float sc[NSPLIT];
             for (int i = 0; i < NSPLIT; ++i) sc[i] = (float)std::ldexp(1.0, -i);  // 2**(-i), exact in fp32
-            HIPCHK(hipMemcpyAsync(split_cands, sc, sizeof sc, hipMemcpyHostToDevice, c.st));
-            HIPCHK(hipStreamSynchronize(c.st));  // sc lives on this stack frame
+            CHK(q_h2d(c, split_cands, sc, sizeof sc));
+            if (!c.grp) CHK(q_sync(c));          // sc lives on this stack frame (a group's queue holds a copy)
         }
     }
     // logical [Z][rows][K] views: A rows = m, B rows = n (B given as [K][N])
@@ -2493,7 +2524,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     const bool aquant = d->a_bit < 32;
     const int aq = aquant ? (1 << (d->a_bit - 1)) : 0;
     if (aquant && !d->channelwise) return fail(P4V_ERR_UNSUPPORTED, "conv: the layer-wise class cannot search activations (reference conv.py:420 raises IndexError); use a_bit=32");
-    cvt_bias(c, c.ws.get<unsigned>(8));     // (first call of the process: probe the conversion quant16_sat8 relies on)
+    cvt_bias(c);     // (first call of the process: probe the conversion quant16_sat8 relies on)
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
@@ -2531,9 +2562,8 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
     if (prunable && !c.dry) {
         const dim3 grid(cdiv(L, 32), cdiv(oc, 32), b);
-        hipLaunchKernelGGL(k_nchw_to_rows, grid, dim3(256), 0, c.st, O, oc, L, Ot);
-        if (G) hipLaunchKernelGGL(k_nchw_to_rows, grid, dim3(256), 0, c.st, G, oc, L, Gt);
-        HIPCHK(hipGetLastError());
+        CHK(enqueue(c, KERN(NchwRowsParams, k_nchw_to_rows), grid, dim3(256), 0, NchwRowsParams{O, oc, L, Ot}));
+        if (G) CHK(enqueue(c, KERN(NchwRowsParams, k_nchw_to_rows), grid, dim3(256), 0, NchwRowsParams{G, oc, L, Gt}));
     }
     // x as im2col rows.  per_image: Z = batch, rows = pixels of one image (channel-wise cosine reduces over pixels)
     auto x_operand = [&](bool expanded, const float* scales, int sc_cs, bool per_image) {
@@ -2637,6 +2667,75 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     return 0;
 }
 
+// ---- p4v_calibrate_group: the members' calibration_step2 in lock step, launches grouped ----------------------------------------
+// Worker threads are persistent (a ViT-B calibration runs 74 members; thread creation per call would cost as much as a search
+// pass): a task is handed to an idle worker or a new one is started -- every member of a group must be running at the same time,
+// they rendezvous.  The pool object is never destroyed (workers are detached and outlive static destruction order).
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> tasks;
+    int idle = 0;
+    void run(std::function<void()> f) {
+        std::unique_lock<std::mutex> lk(mu);
+        tasks.push_back(std::move(f));
+        if (idle >= (int)tasks.size()) { cv.notify_one(); return; }
+        lk.unlock();
+        std::thread([this] { loop(); }).detach();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            while (tasks.empty()) { ++idle; cv.wait(lk); --idle; }
+            auto f = std::move(tasks.front());
+            tasks.pop_front();
+            lk.unlock();
+            f();
+            lk.lock();
+        }
+    }
+};
+WorkerPool& worker_pool() { static WorkerPool* p = new WorkerPool; return *p; }
+
+int* group_mirror(hipStream_t st, int dev, int slot) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, int*> tab;
+    char key[64];
+    snprintf(key, sizeof key, "%p/%d/%d", (void*)st, dev, slot);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tab.find(key);
+    if (it != tab.end()) return it->second;
+    int* p = mirror_alloc();
+    tab[key] = p;
+    return p;
+}
+
+int run_group_member(const p4v_group_job& j, Ctx& c) {
+    switch (j.kind) {
+        case P4V_JOB_LINEAR: {
+            const p4v_linear_desc* d = (const p4v_linear_desc*)j.desc;
+            if (!j.in[0] || !j.in[2] || !j.in[3] || !j.mult || !j.out[0] || !j.out[1] || !j.workspace) return fail(P4V_ERR_INVALID, "group: linear member with a null pointer");
+            if (d->has_bias && !j.in[1]) return fail(P4V_ERR_INVALID, "group: linear member has_bias set but bias is NULL");
+            return linear_impl(d, j.in[0], d->has_bias ? j.in[1] : nullptr, j.in[2], j.in[3], j.in[4], j.mult, j.out[0], j.out[1], nullptr, nullptr, c);
+        }
+        case P4V_JOB_MATMUL: {
+            const p4v_matmul_desc* d = (const p4v_matmul_desc*)j.desc;
+            if (!j.in[0] || !j.in[1] || !j.in[2] || !j.mult || !j.out[0] || !j.out[1] || !j.workspace) return fail(P4V_ERR_INVALID, "group: matmul member with a null pointer");
+            return matmul_impl(d, j.in[0], j.in[1], j.in[2], j.in[3], j.mult, j.out[0], j.out[1], j.out[2], nullptr, nullptr, c);
+        }
+        case P4V_JOB_CONV: {
+            const p4v_conv_desc* d = (const p4v_conv_desc*)j.desc;
+            if (!j.in[0] || !j.in[2] || !j.in[3] || !j.mult || !j.out[0] || !j.out[1] || !j.workspace) return fail(P4V_ERR_INVALID, "group: conv member with a null pointer");
+            if (d->has_bias && !j.in[1]) return fail(P4V_ERR_INVALID, "group: conv member has_bias set but bias is NULL");
+            return conv_impl(d, j.in[0], d->has_bias ? j.in[1] : nullptr, j.in[2], j.in[3], j.in[4], j.mult, j.out[0], j.out[1], nullptr, nullptr, c);
+        }
+        default: return fail(P4V_ERR_INVALID, "group: unknown member kind %d", j.kind);
+    }
+}
+size_t group_desc_bytes(int kind) {
+    return kind == P4V_JOB_LINEAR ? sizeof(p4v_linear_desc) : kind == P4V_JOB_MATMUL ? sizeof(p4v_matmul_desc) : kind == P4V_JOB_CONV ? sizeof(p4v_conv_desc) : 0;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -2721,6 +2820,66 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
     Ctx c{(hipStream_t)stream, Arena(d_workspace, workspace_bytes), false};
     return conv_impl(desc, d_weight, desc->has_bias ? d_bias : nullptr, d_x, d_out, d_grad, d_mult, d_w_interval, d_a_interval,
                      d_scores, d_best, c);
+}
+
+
+int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(P4V_ERR_INVALID, "p4v_calibrate_group: bad job list");
+    if (n_jobs == 0) return 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        jobs[i].status = 0;
+        if (!jobs[i].desc || group_desc_bytes(jobs[i].kind) == 0) return fail(P4V_ERR_INVALID, "p4v_calibrate_group: member %d has no descriptor / an unknown kind", i);
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    cvt_probe((hipStream_t)stream);
+    Group g;
+    g.st = (hipStream_t)stream; g.n = n_jobs;
+    g.q.resize(n_jobs); g.state.assign(n_jobs, 0); g.mirrors.resize(n_jobs);
+    for (int i = 0; i < n_jobs; ++i) g.mirrors[i] = tune(TUNE_B1_PATH) == 8 ? nullptr : group_mirror(g.st, dev, i);
+    g.stat_on = g_stat_on;
+    g.stat_recs = g_stat_on ? &g_stat_recs : nullptr;
+    g_launch_cnt[3].fetch_add(1, std::memory_order_relaxed);
+    std::vector<std::string> errs(n_jobs);
+    std::atomic<long> memo_hits{0}, memo_misses{0};
+    std::mutex dmu;
+    std::condition_variable dcv;
+    int left = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        // members with the same descriptor run the same launches in lock step: they share the chip
+        int par = 0;
+        for (int k = 0; k < n_jobs; ++k)
+            par += jobs[k].kind == jobs[i].kind && std::memcmp(jobs[k].desc, jobs[i].desc, group_desc_bytes(jobs[i].kind)) == 0;
+        worker_pool().run([&, i, par] {
+            (void)hipSetDevice(dev);
+            g_stat_on = g.stat_on; g_stage = 0; g_exec_frac = 1.0; g_memo_hits = 0; g_memo_misses = 0; g_err.clear();
+            Ctx c{g.st, Arena(jobs[i].workspace, jobs[i].workspace_bytes), false, &g, i, par};
+            const int r = run_group_member(jobs[i], c);
+            jobs[i].status = r;
+            if (r) errs[i] = g_err;
+            memo_hits += g_memo_hits; memo_misses += g_memo_misses;
+            g_stat_on = false;
+            g.finish(i);
+            std::lock_guard<std::mutex> lk(dmu);
+            if (--left == 0) dcv.notify_all();
+        });
+    }
+    {
+        std::unique_lock<std::mutex> lk(dmu);
+        dcv.wait(lk, [&] { return left == 0; });
+    }
+    g_memo_hits += memo_hits.load(); g_memo_misses += memo_misses.load();
+    if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] group of %d: %ld launches asked for, %ld issued in %ld rounds\n", n_jobs, g.n_ops, g.n_launches, g.n_rounds);
+    if (g.status) { g_err = g.err; return g.status; }
+    for (int i = 0; i < n_jobs; ++i)
+        if (jobs[i].status) { g_err = errs[i]; return jobs[i].status; }
+    return 0;
+}
+
+int p4v_launch_counters(int64_t* out4, int reset) {
+    if (out4) for (int i = 0; i < 4; ++i) out4[i] = (int64_t)g_launch_cnt[i].load(std::memory_order_relaxed);
+    if (reset) for (int i = 0; i < 4; ++i) g_launch_cnt[i].store(0, std::memory_order_relaxed);
+    return 0;
 }
 
 // ---- granular entry points: one part of calibration_step2 per call ----------
@@ -2987,7 +3146,7 @@ int p4v_debug_set_tuning(int key, int value) {
 
 int p4v_debug_topk_rows(const float* d_mass, int segs, int n, int k, int32_t* d_idx, void* stream) {
     if (!d_mass || !d_idx || segs <= 0 || n <= 0 || k <= 0 || k > n) return fail(P4V_ERR_INVALID, "p4v_debug_topk_rows: bad argument");
-    hipLaunchKernelGGL(k_topk_rows, dim3(segs), dim3(1024), 0, (hipStream_t)stream, d_mass, n, k, d_idx);
+    hipLaunchKernelGGL(k_topk_rows, dim3(segs), dim3(1024), 0, (hipStream_t)stream, TopkParams{d_mass, n, k, d_idx});
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -3003,9 +3162,7 @@ int p4v_pack_plane_i8(const p4v_plane_desc* d, const float* d_x, const float* d_
     if (d->mode == P4V_PLANE_SYM && d_scales && d->rows_per_scale <= 0) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: rows_per_scale");
     if (d->lo < -128 || d->hi > 127 || d->qmax < 2 || d->qmax > 128) return fail(P4V_ERR_INVALID, "p4v_pack_plane_i8: grid wider than int8");
     Ctx c{(hipStream_t)stream, Arena(nullptr, 0), false};
-    // (first use of the process: the conversion quant16_sat8 relies on is probed into the head of the destination plane -- at
-    // least 64 bytes, overwritten by the pack below on the same stream)
-    cvt_bias(c, (d->rows * d->cols_padded >= 32) ? reinterpret_cast<unsigned*>(d_q) : nullptr);
+    cvt_bias(c);     // (first use of the process: the conversion quant16_sat8 relies on is probed, into a scratch of the library's own)
     PackParams p = pack2d(d_x, d->rows, d->cols, d->cols);
     p.Rp = (int)d->rows; p.Kp = (int)d->cols_padded; p.dst = d_q; p.C = 1;
     p.scales = d_scales; p.sc_cs = 0; p.neg_scale = d->const_scale;

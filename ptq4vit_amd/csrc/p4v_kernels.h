@@ -23,6 +23,43 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
+// One kernel body, two entry points (round 6: grouped launches)
+// ------------------------------------------------------------------------------------------
+// Every kernel of the calibration path is a __device__ body k_x_body(params, blockIdx, gridDim) -- the parameters shadow HIP's
+// built-ins, so the body reads exactly like a kernel -- with two __global__ entry points:
+//   k_x(P p)              one launch = one module's grid                           (calibration_step2() of a single module)
+//   k_x_g(GroupArgs<P> a) one launch = the CONCATENATED grids of several modules  (p4v_calibrate_group: the modules of a network are
+//                         independent, reference utils/quant_calib.py:316-372, and search in lock step; a ViT-B calibration is
+//                         ~3 800 launches of mostly 1-250 workgroups one module at a time, ~12-70 x fewer grouped)
+// A workgroup of k_x_g finds its member m by a scalar scan of the block offsets, rebuilds the member's own (blockIdx, gridDim) from
+// its flat index and runs the body on a.p[m] -- the same instructions on the same values as the single launch, so the results are
+// bit-identical by construction.  Every member's block count is padded to a multiple of 8 (the XCD round-robin of the hardware
+// dispatcher then sees each member's blocks as a launch of its own would have; the padding blocks return at once).  The
+// argument block travels as a kernel argument: CAP members per launch (the kernel-argument segment, with the 256 bytes of
+// implicit arguments the compiler appends, stays within 4 KB).
+#ifndef P4V_GROUP_KERNARG
+#define P4V_GROUP_KERNARG (4096 - 256)
+#endif
+template <typename P> struct GroupArgs {
+    static constexpr int CAP_RAW = (P4V_GROUP_KERNARG - 16) / (int)(sizeof(P) + 16);
+    static constexpr int CAP = CAP_RAW > 64 ? 64 : CAP_RAW;
+    int n;
+    unsigned off[CAP + 1];            // first flat block of member m; off[n] = total
+    unsigned gx[CAP], gy[CAP], gz[CAP];
+    P p[CAP];
+};
+#define P4V_BIDX uint3{blockIdx.x, blockIdx.y, blockIdx.z}
+#define P4V_GDIM uint3{gridDim.x, gridDim.y, gridDim.z}
+#define P4V_GROUP_ENTER(a)                                                                           \
+    int m_ = 0;                                                                                      \
+    while (m_ + 1 < a.n && blockIdx.x >= a.off[m_ + 1]) ++m_;                                        \
+    m_ = __builtin_amdgcn_readfirstlane(m_);                                                         \
+    const unsigned b_ = blockIdx.x - a.off[m_];                                                      \
+    const uint3 vg_{a.gx[m_], a.gy[m_], a.gz[m_]};                                                   \
+    if (b_ >= vg_.x * vg_.y * vg_.z) return;                                                         \
+    const uint3 vb_{b_ % vg_.x, (b_ / vg_.x) % vg_.y, b_ / (vg_.x * vg_.y)}
+
+// ------------------------------------------------------------------------------------------
 // block abs-max (reference linear.py:385,395; matmul.py:435-436; conv.py:487,494)
 // ------------------------------------------------------------------------------------------
 // Monotonic float <-> uint encoding so that an integer atomicMax implements an exact
@@ -46,7 +83,7 @@ struct AbsMaxParams {
     unsigned* out;            // [D1][nV][nH] ordered-encoded running max
 };
 
-__global__ __launch_bounds__(256) void k_absmax(AbsMaxParams p) {
+__device__ __forceinline__ void k_absmax_body(const AbsMaxParams& p, const uint3 blockIdx, const uint3 gridDim) {
     // grid.x = ceil(crb_r / row_tile) * nV * nH, grid.y = D1, grid.z = D0
     int bx = blockIdx.x;
     const int h = bx % p.nH; bx /= p.nH;
@@ -91,9 +128,13 @@ __global__ __launch_bounds__(256) void k_absmax(AbsMaxParams p) {
         if (m > -INFINITY) atomicMax(p.out + ((long)blockIdx.y * p.nV + v) * p.nH + h, enc_ordered(m));
     }
 }
+__global__ __launch_bounds__(256) void k_absmax(AbsMaxParams p) { k_absmax_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_absmax_g(GroupArgs<AbsMaxParams> a) { P4V_GROUP_ENTER(a); k_absmax_body(a.p[m_], vb_, vg_); }
 
 // interval[j] = max[j] / (qmax - 0.5)   (linear.py:385); `broadcast`: init_layerwise (linear.py:383)
-__global__ void k_interval_from_max(const unsigned* enc, int n, float denom, int broadcast, float* interval) {
+struct IntervalParams { const unsigned* enc; int n; float denom; int broadcast; float* interval; };
+__device__ __forceinline__ void k_interval_from_max_body(const IntervalParams& a, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [enc, n, denom, broadcast, interval] = a;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float m;
@@ -105,13 +146,19 @@ __global__ void k_interval_from_max(const unsigned* enc, int n, float denom, int
     }
     interval[j] = m / denom;
 }
+__global__ void k_interval_from_max(IntervalParams p) { k_interval_from_max_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_interval_from_max_g(GroupArgs<IntervalParams> a) { P4V_GROUP_ENTER(a); k_interval_from_max_body(a.p[m_], vb_, vg_); }
 
 // cands[c][j] = mult[c] * interval[j]  (fp32 multiply, linear.py:544-545)
-__global__ void k_make_cands(const float* mult, const float* interval, int ncand, int nblk, float* cands) {
+struct CandsParams { const float* mult; const float* interval; int ncand, nblk; float* cands; };
+__device__ __forceinline__ void k_make_cands_body(const CandsParams& a, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [mult, interval, ncand, nblk, cands] = a;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncand * nblk) return;
     cands[i] = mult[i / nblk] * interval[i % nblk];
 }
+__global__ void k_make_cands(CandsParams p) { k_make_cands_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_make_cands_g(GroupArgs<CandsParams> a) { P4V_GROUP_ENTER(a); k_make_cands_body(a.p[m_], vb_, vg_); }
 
 // S[c][j] = X(c,j) * Y(c,j); each factor is a device array (with candidate / block strides) or a constant.
 struct ScaleParams {
@@ -120,7 +167,7 @@ struct ScaleParams {
     int C, nblk;
     float* S;
 };
-__global__ void k_scale_table(ScaleParams p) {
+__device__ __forceinline__ void k_scale_table_body(const ScaleParams& p, const uint3 blockIdx, const uint3 gridDim) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.C * p.nblk) return;
     const int c = i / p.nblk, j = i % p.nblk;
@@ -128,6 +175,8 @@ __global__ void k_scale_table(ScaleParams p) {
     const float y = p.y ? p.y[c * p.y_cs + j * p.y_js] : p.y_const;
     p.S[i] = x * y;
 }
+__global__ void k_scale_table(ScaleParams p) { k_scale_table_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_scale_table_g(GroupArgs<ScaleParams> a) { P4V_GROUP_ENTER(a); k_scale_table_body(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_pack: fake quantisation of one operand into a K-contiguous, zero-padded plane
@@ -331,7 +380,7 @@ __device__ __forceinline__ void quant16_any(const float (&x)[16], float s, float
 static constexpr int PACK_CG = 10;
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack(PackParams p) {
+__device__ __forceinline__ void k_pack_body(const PackParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const unsigned kchunks = p.Kp / 16;
     const unsigned total = (unsigned)p.Z * p.Rp * kchunks;      // < 2^31: checked by the launcher
     const int cbeg = blockIdx.y * PACK_CG, cend = min(p.C, cbeg + PACK_CG);
@@ -453,13 +502,17 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
         }
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(PackParams p) { k_pack_body<T>(p, P4V_BIDX, P4V_GDIM); }
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_g(GroupArgs<PackParams> a) { P4V_GROUP_ENTER(a); k_pack_body<T>(a.p[m_], vb_, vg_); }
 
 // PACK_TWIN_I8: both grid indices of the post-GELU twin (linear.py:605-606) in ONE int8 plane, row-major [Z][Rp][Kp], zero
 // padded.  A kernel of its own: the plane is small and fixed (one per weight-search pass) and k_pack's hot path is register
 // sensitive (the extra branch there cost it an occupancy step: 112 -> 155 VGPRs).  IEEE divisions, as the reference divides;
 // the supports are disjoint (x > 0 clamps the negative range to 0, x < 0 the positive one), so the sum is the index that is
 // not zero and fits the int8 range.
-__global__ __launch_bounds__(256) void k_pack_twin(PackParams p) {
+__device__ __forceinline__ void k_pack_twin_body(const PackParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const unsigned kchunks = p.Kp / 16;
     const unsigned total = (unsigned)p.Z * p.Rp * kchunks;
     const float s = p.scales[0], sn = p.neg_scale, flo = (float)p.lo, fhi = (float)p.hi;
@@ -485,6 +538,8 @@ __global__ __launch_bounds__(256) void k_pack_twin(PackParams p) {
         *reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p.dst) + (((long)z * p.Rp + r) * p.Kp + (long)kc * 16)) = v4i{w[0], w[1], w[2], w[3]};
     }
 }
+__global__ __launch_bounds__(256) void k_pack_twin(PackParams p) { k_pack_twin_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_pack_twin_g(GroupArgs<PackParams> a) { P4V_GROUP_ENTER(a); k_pack_twin_body(a.p[m_], vb_, vg_); }
 
 
 // Both int8 planes of a twin operand from ONE read of the source: the post-GELU twin's positive / negative range
@@ -492,7 +547,9 @@ __global__ __launch_bounds__(256) void k_pack_twin(PackParams p) {
 // PACK_SOS_HI / PACK_SOS_LO).  Same arithmetic as k_pack's per-element path (pack_value: IEEE division), two fixed planes
 // (C = 1), one scale each (no blocks), row-major [Z][Rp][Kp].  Memory-bound: the source is read once instead of twice
 // (quant_forward at batch 128: 310 MB per fc2, 238 MB per attention-probability operand).
-__global__ __launch_bounds__(256) void k_pack_dual(PackParams p, PackParams p2) {
+struct PackDualParams { PackParams p; PackParams p2; };
+__device__ __forceinline__ void k_pack_dual_body(const PackDualParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [p, p2] = a_;
     const unsigned kchunks = p.Kp / 16;
     const unsigned total = (unsigned)p.Z * p.Rp * kchunks;
     const float s1 = p.scales ? p.scales[0] : p.neg_scale, s2 = p2.scales ? p2.scales[0] : p2.neg_scale;
@@ -536,6 +593,8 @@ __global__ __launch_bounds__(256) void k_pack_dual(PackParams p, PackParams p2) 
         __builtin_nontemporal_store(v4i{w2[0], w2[1], w2[2], w2[3]}, reinterpret_cast<v4i*>(reinterpret_cast<int8_t*>(p2.dst) + o));
     }
 }
+__global__ __launch_bounds__(256) void k_pack_dual(PackDualParams p) { k_pack_dual_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_pack_dual_g(GroupArgs<PackDualParams> a) { P4V_GROUP_ENTER(a); k_pack_dual_body(a.p[m_], vb_, vg_); }
 
 // Plain 2-D helpers behind p4v_quantize_i8 / p4v_fake_quant (quant_forward building blocks).
 __global__ void k_fake_quant_rows(const float* x, long rows, long cols, const float* scales, long rows_per_scale,
@@ -700,7 +759,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <typename T, bool TWIN, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
+__device__ __forceinline__ void k_sweep_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = TWIN ? 3 : 2;                 // planes per stage: A, (A2), B
     constexpr int STAGE = NPL * SW_TILE_BYTES;
@@ -918,6 +977,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) {
         }
     }
 }
+template <typename T, bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep(SweepParams p) { k_sweep_body<T, TWIN, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <typename T, bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_sweep_body<T, TWIN, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep2: the fast int8 candidate sweep (linear layers and attention matmuls, element-wise metrics)
@@ -967,7 +1030,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool TWIN, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
+__device__ __forceinline__ void k_sweep2_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = TWIN ? 3 : 2;
     constexpr int STAGE = NPL * SW2_TILE;
@@ -1286,6 +1349,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }
 }
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) { k_sweep2_body<TWIN, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_sweep2_body<TWIN, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_bound: ONE candidate over ALL samples -- stage B1 of a pruned pass (p4v_api.hip::run_pass_pruned), the bound L*
@@ -1308,7 +1375,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep2(SweepParams p) {
 // only set the bound (margin: prune_margin), and whenever more than the bound's own candidate survives, stage B2 re-evaluates
 // ALL survivors with the unpruned kernels.
 template <int EPI>
-__global__ __launch_bounds__(256, 4) void k_bound(SweepParams p) {
+__device__ __forceinline__ void k_bound_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
@@ -1425,6 +1492,10 @@ __global__ __launch_bounds__(256, 4) void k_bound(SweepParams p) {
     sum = wave_sum_dpp(sum);
     if (lane == 63) slot[0] = sum;
 }
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void k_bound(SweepParams p) { k_bound_body<EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void k_bound_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_bound_body<EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep8: k_sweep2 for K <= 64 (ONE k-tile: the q.k^T matmuls of every ViT / DeiT / Swin, head_dim <= 64)
@@ -1441,7 +1512,7 @@ static constexpr int SW8_NS = 8;
 #define P4V_SW8_DBG 0      // timing-only ablations: 1 no operand stream in the loop, 2 no MFMAs, 4 no epilogue arithmetic
 #endif
 template <bool ROWS_FIXED, int EPI, bool SKIP>
-__global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
+__device__ __forceinline__ void k_sweep8_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = reinterpret_cast<float*>(smem + SW8_NS * SW2_TILE);   // [per][8 waves]
 
@@ -1651,6 +1722,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) {
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }
 }
+template <bool ROWS_FIXED, int EPI, bool SKIP>
+__global__ __launch_bounds__(512, 2) void k_sweep8(SweepParams p) { k_sweep8_body<ROWS_FIXED, EPI, SKIP>(p, P4V_BIDX, P4V_GDIM); }
+template <bool ROWS_FIXED, int EPI, bool SKIP>
+__global__ __launch_bounds__(512, 2) void k_sweep8_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_sweep8_body<ROWS_FIXED, EPI, SKIP>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep9: single-k-tile sweeps (q.k^T, K <= 64) on 16 x 16 blocks
@@ -1672,7 +1747,7 @@ static constexpr int SW9_NW = P4V_SW9_NW, SW9_NS = (SW9_NW == 4 ? 4 : 8), SW9_ST
 static constexpr int SW9_PIECES = 16 / SW9_NW;            // 1 KB LDS-DMA pieces (16 rows) per wave and candidate
 
 template <bool ROWS_FIXED, int EPI>
-__global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
+__device__ __forceinline__ void k_sweep9_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = reinterpret_cast<float*>(smem + SW9_NS * SW9_STAGE);   // [per][SW9_NW waves]
     typedef int v4i_ __attribute__((ext_vector_type(4)));
@@ -1834,6 +1909,10 @@ __global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) {
     for (int i = tid; i < ncand * SW9_NW; i += SW9_NW * 64)
         p.part[(long)(c_lo + i / SW9_NW) * p.p_cs + (long)z * p.p_zs + half * SW9_NW + (i % SW9_NW)] = res[i];
 }
+template <bool ROWS_FIXED, int EPI>
+__global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9(SweepParams p) { k_sweep9_body<ROWS_FIXED, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <bool ROWS_FIXED, int EPI>
+__global__ __launch_bounds__(SW9_NW * 64, 2) void k_sweep9_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_sweep9_body<ROWS_FIXED, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_slice_b: stage A of a pruned MatMul B search -- all candidates of B on the 16-row sample slice, B quantised IN the kernel
@@ -1860,7 +1939,7 @@ struct SliceBParams {
     float* part;                                            // [C][Z]
 };
 template <bool TWIN, int KTM, int NBM, int EPI>
-__global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) {
+__device__ __forceinline__ void k_slice_b_body(const SliceBParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bt = reinterpret_cast<float*>(smem);                         // [NB * 16][Kp + 4] fp32, zero padded
     typedef int v4i_ __attribute__((ext_vector_type(4)));
@@ -1972,6 +2051,10 @@ __global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) {
         if (lane == 63) p.part[(long)c * p.Z + z] = sum;
     }
 }
+template <bool TWIN, int KTM, int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_b(SliceBParams p) { k_slice_b_body<TWIN, KTM, NBM, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <bool TWIN, int KTM, int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_b_g(GroupArgs<SliceBParams> a) { P4V_GROUP_ENTER(a); k_slice_b_body<TWIN, KTM, NBM, EPI>(a.p[m_], vb_, vg_); }
 
 // k_slice_b2 (round 5): k_slice_b with B in REGISTERS.  k_slice_b dealt the candidates over the four waves: every wave
 // re-read all of B (fp32) from the LDS for each of its candidates -- 4 KB of ds_read_b128 and the address arithmetic per 1 KB
@@ -1985,7 +2068,7 @@ struct SliceB2Params {
     float qbias;            // bias of quant16_sat8's conversion (k_probe_cvt); 0: the conversion is not usable -> SAT8 must be false
 };
 template <bool TWIN, int KTM, int NBW, int EPI, bool SAT8>
-__global__ __launch_bounds__(256, 2) void k_slice_b2(SliceB2Params pp) {
+__device__ __forceinline__ void k_slice_b2_body(const SliceB2Params& pp, const uint3 blockIdx, const uint3 gridDim) {
     const SliceBParams& p = pp.b;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2071,6 +2154,10 @@ __global__ __launch_bounds__(256, 2) void k_slice_b2(SliceB2Params pp) {
         if (lane == 63) p.part[((long)c * p.Z + z) * 4 + wid] = sum;
     }
 }
+template <bool TWIN, int KTM, int NBW, int EPI, bool SAT8>
+__global__ __launch_bounds__(256, 2) void k_slice_b2(SliceB2Params p) { k_slice_b2_body<TWIN, KTM, NBW, EPI, SAT8>(p, P4V_BIDX, P4V_GDIM); }
+template <bool TWIN, int KTM, int NBW, int EPI, bool SAT8>
+__global__ __launch_bounds__(256, 2) void k_slice_b2_g(GroupArgs<SliceB2Params> a) { P4V_GROUP_ENTER(a); k_slice_b2_body<TWIN, KTM, NBW, EPI, SAT8>(a.p[m_], vb_, vg_); }
 
 // k_slice_a: the same for a MatMul A search with K <= 64 (q.k^T): the EXPANDED operand is the 16-row slice itself -- a lane keeps
 // its 16 fp32 values of the slice in registers and re-quantises them per candidate (one fragment), the fixed operand B (int8,
@@ -2088,7 +2175,7 @@ struct SliceAParams {
     float qbias;                                            // != 0: quant16_sat8 (symmetric 8-bit grid; bias from k_probe_cvt), else quant_fast1
 };
 template <int NBM, int EPI>
-__global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
+__device__ __forceinline__ void k_slice_a_body(const SliceAParams& p, const uint3 blockIdx, const uint3 gridDim) {
     typedef int v4i_ __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2151,6 +2238,10 @@ __global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
         if (lane == 63) p.part[(long)c * p.Z + z] = sum;
     }
 }
+template <int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) { k_slice_a_body<NBM, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int NBM, int EPI>
+__global__ __launch_bounds__(256, 2) void k_slice_a_g(GroupArgs<SliceAParams> a) { P4V_GROUP_ENTER(a); k_slice_a_body<NBM, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep2g: k_sweep2 for LARGE K with two candidates per pass (weight search of fc2-like layers)
@@ -2165,7 +2256,7 @@ __global__ __launch_bounds__(256, 2) void k_slice_a(SliceAParams p) {
 // Requirements (host): column operand expanded (b_cs != 0), row operand invariant (a_cs == 0), p.Z == 1 or z handled
 // by blockIdx.y as in k_sweep2.  An odd candidate count runs its last candidate twice (second result dropped).
 template <bool TWIN, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
+__device__ __forceinline__ void k_sweep2g_body(const SweepParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = TWIN ? 4 : 3;                    // planes: A, (A2), B(c), B(c+1)
     constexpr int PLANE = SW2_NS * SW2_TILE;
@@ -2361,6 +2452,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) {
         p.part[(long)cc * p.p_cs + (long)z * p.p_zs + (long)(mt * 2 + (wv >> 2)) * p.Np + nt * 4 + (wv & 3)] = res[i];
     }
 }
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2g(SweepParams p) { k_sweep2g_body<TWIN, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <bool TWIN, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep2g_g(GroupArgs<SweepParams> a) { P4V_GROUP_ENTER(a); k_sweep2g_body<TWIN, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // Stationary-operand int8 sweep (k_sweep4 below): parameter block
@@ -2416,7 +2511,7 @@ struct Sweep3Params {
 static constexpr int SW4_NS = 6;
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
+__device__ __forceinline__ void k_sweep4_body(const Sweep3Params& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ktiles = p.ktiles;
     const int ring0 = ktiles * SW2_TILE;                 // LDS byte offset of the ring
@@ -2578,6 +2673,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
         p.part[(long)cc * p.p_cs + (long)(st * 2 + (wv >> 2)) * p.NG + tt * 4 + (wv & 3)] = res[i];
     }
 }
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) { k_sweep4_body<EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep4_g(GroupArgs<Sweep3Params> a) { P4V_GROUP_ENTER(a); k_sweep4_body<EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep5: k_sweep4 with TWO candidates per pass (candidate pair = one "pair-step" per k-tile)
@@ -2595,7 +2694,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep4(Sweep3Params p) {
 static constexpr int SW5_NP = 3;
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
+__device__ __forceinline__ void k_sweep5_body(const Sweep3Params& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P4V_TRACE
     unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
@@ -2794,6 +2893,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) {
     if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)total; trc[9] = __builtin_amdgcn_s_memtime(); }
 #endif
 }
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep5(Sweep3Params p) { k_sweep5_body<EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep5_g(GroupArgs<Sweep3Params> a) { P4V_GROUP_ENTER(a); k_sweep5_body<EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep6: stationary operand in REGISTERS, one wave per SIMD (K = KT * 64 bytes, KT <= 12)
@@ -2829,7 +2932,7 @@ struct PrepEpi6Params {
     int stiles, ttiles;
     float* E;
 };
-__global__ __launch_bounds__(256) void k_prep_epi6(PrepEpi6Params p) {
+__device__ __forceinline__ void k_prep_epi6_body(const PrepEpi6Params& p, const uint3 blockIdx, const uint3 gridDim) {
     const long total = (long)p.stiles * p.ttiles * 8 * 2 * 4 * 2 * 64;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int lane = (int)(i & 63), k = (int)((i >> 6) & 1), q = (int)((i >> 7) & 3), cb = (int)((i >> 9) & 1), b = (int)((i >> 10) & 7);
@@ -2854,6 +2957,8 @@ __global__ __launch_bounds__(256) void k_prep_epi6(PrepEpi6Params p) {
         reinterpret_cast<v4f*>(p.E)[i] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_prep_epi6(PrepEpi6Params p) { k_prep_epi6_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_prep_epi6_g(GroupArgs<PrepEpi6Params> a) { P4V_GROUP_ENTER(a); k_prep_epi6_body(a.p[m_], vb_, vg_); }
 
 // Timing-only ablations (tools/build_ablation_libs.sh, never shipped): -DP4V_SW6_DBG = 1 no operand stream in the loop,
 // 2 no MFMAs, 4 no epilogue, 8 no fragment reads, 16 no epilogue-operand loads in the prologue, 32 no stationary-operand
@@ -2862,7 +2967,7 @@ __global__ __launch_bounds__(256) void k_prep_epi6(PrepEpi6Params p) {
 #define P4V_SW6_DBG 0
 #endif
 template <int EPI, int KT, int RB>
-__global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Params p) {
+__device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3 blockIdx, const uint3 gridDim) {
     constexpr int NW = 8 / RB;                           // waves per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P4V_TRACE
@@ -3176,6 +3281,10 @@ __global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Para
     if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)ncand; trc[9] = __builtin_amdgcn_s_memtime(); }
 #endif
 }
+template <int EPI, int KT, int RB>
+__global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6(Sweep3Params p) { k_sweep6_body<EPI, KT, RB>(p, P4V_BIDX, P4V_GDIM); }
+template <int EPI, int KT, int RB>
+__global__ __launch_bounds__(512 / RB, RB == 2 ? 1 : 2) void k_sweep6_g(GroupArgs<Sweep3Params> a) { P4V_GROUP_ENTER(a); k_sweep6_body<EPI, KT, RB>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep7: int8 candidate sweep for LARGE K (K >= 1024: fc2 of every ViT, every Linear of ViT-L / Swin stage 4)
@@ -3242,7 +3351,7 @@ struct PrepEpiParams {
     int rtiles, ctiles, twin;
     float* E;
 };
-__global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) {
+__device__ __forceinline__ void k_prep_epi_body(const PrepEpiParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const int NQ = p.twin ? 1 : 2, NSB = 8 * NQ;
     const long total = (long)p.rtiles * p.ctiles * 8 * NSB * 4 * 64;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -3270,6 +3379,8 @@ __global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) {
         reinterpret_cast<v4f*>(p.E)[i] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) { k_prep_epi_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_prep_epi_g(GroupArgs<PrepEpiParams> a) { P4V_GROUP_ENTER(a); k_prep_epi_body(a.p[m_], vb_, vg_); }
 
 // TW = 0: one sample-side plane.  TW = 1: twin, two planes streamed side by side (128 samples x 2 planes per tile).
 // TW = 2: twin whose two ranges have DISJOINT supports (post-GELU, linear.py:605-606), streamed as ONE merged int8 plane
@@ -3277,7 +3388,7 @@ __global__ __launch_bounds__(256) void k_prep_epi(PrepEpiParams p) {
 // VALU operations per dword in the wave's load phase: a quarter less LDS-DMA (three 1 KB pieces per wave and k-tile instead
 // of four) and 10 instead of 12 fragment reads per k-tile; the MFMAs, accumulators and epilogue are those of TW = 1.
 template <int TW, int EPI>
-__global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
+__device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3 blockIdx, const uint3 gridDim) {
     constexpr bool TWIN = TW != 0, MERGED = TW == 2;
     constexpr int PPT = MERGED ? 3 : 4;                  // LDS-DMA pieces per wave and k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3632,6 +3743,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) {
         p.part[(long)cc * p.p_cs + (long)(ct * 4 + (wv & 3)) * p.NG + rt * 8 + (wv >> 2) * 4 + j] = res[i];
     }
 }
+template <int TW, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep7(Sweep7Params p) { k_sweep7_body<TW, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int TW, int EPI>
+__global__ __launch_bounds__(512, 2) void k_sweep7_g(GroupArgs<Sweep7Params> a) { P4V_GROUP_ENTER(a); k_sweep7_body<TW, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_sos_split: the split search of the split-of-softmax matmul (reference matmul.py:600-631) in one kernel
@@ -3666,7 +3781,7 @@ struct SosSplitParams {
 #define P4V_SOS_DBG 0          // timing-only ablations: 1 no quantisation arithmetic, 2 no B fragment reads, 4 no MFMAs
 #endif
 template <int KS, int EPI>
-__global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
+__device__ __forceinline__ void k_sos_split_body(const SosSplitParams& p, const uint3 blockIdx, const uint3 gridDim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Bt = reinterpret_cast<float*>(smem);                    // [2 KS][64]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3770,6 +3885,10 @@ __global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) {
         if (lane == 63) p.part[((long)c * p.Z + z) * (p.halves * 4) + half * 4 + wid] = sum;
     }
 }
+template <int KS, int EPI>
+__global__ __launch_bounds__(256, 1) void k_sos_split(SosSplitParams p) { k_sos_split_body<KS, EPI>(p, P4V_BIDX, P4V_GDIM); }
+template <int KS, int EPI>
+__global__ __launch_bounds__(256, 1) void k_sos_split_g(GroupArgs<SosSplitParams> a) { P4V_GROUP_ENTER(a); k_sos_split_body<KS, EPI>(a.p[m_], vb_, vg_); }
 
 // ------------------------------------------------------------------------------------------
 // k_finish / k_select
@@ -3826,11 +3945,13 @@ __device__ __forceinline__ void select_block(const SelectParams& p, int j, int c
         if (p.best_out) p.best_out[j] = best;
     }
 }
-__global__ __launch_bounds__(128) void k_select(SelectParams p) {          // one workgroup per score block
+__device__ __forceinline__ void k_select_body(const SelectParams& p, const uint3 blockIdx, const uint3 gridDim) {          // one workgroup per score block
     __shared__ float sv[128];
     __shared__ int si[128];
     select_block(p, blockIdx.x, 0, p.C, sv, si);
 }
+__global__ __launch_bounds__(128) void k_select(SelectParams p) { k_select_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(128) void k_select_g(GroupArgs<SelectParams> a) { P4V_GROUP_ENTER(a); k_select_body(a.p[m_], vb_, vg_); }
 
 // ---- exact candidate pruning: the kernels between the stages (run_pass_pruned, p4v_api.hip) ------------------------------------
 // virt (several score blocks): stage B1 evaluates ONE synthetic candidate whose scale in block j is the scale of block j's own
@@ -3886,11 +4007,13 @@ __device__ __forceinline__ void prune_pick(const PruneParams& p, float* sv, int*
     }
     if (threadIdx.x == 0) { p.r_out[0] = lo; p.r_out[1] = hi; }
 }
-__global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) {
+__device__ __forceinline__ void k_prune_pick_body(const PruneParams& p, const uint3 blockIdx, const uint3 gridDim) {
     __shared__ float sv[256];
     __shared__ int si[512];
     prune_pick(p, sv, si);
 }
+__global__ __launch_bounds__(256) void k_prune_pick(PruneParams p) { k_prune_pick_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_prune_pick_g(GroupArgs<PruneParams> a) { P4V_GROUP_ENTER(a); k_prune_pick_body(a.p[m_], vb_, vg_); }
 // r_out = what stage B2 has to evaluate: the hull of the candidates whose stage-A bound reaches the best complete score, or the
 // empty range when stage B1 already evaluated all of them.  Returns (to every thread) whether the range is empty.
 // rblk (optional, 2 ints per score block): the same PER BLOCK -- the blocks of a pass are scored independently, so block j only
@@ -3992,7 +4115,9 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
 // from the table that holds them and -inf elsewhere.  (Tried and dropped: running these one-workgroup steps as the tail of the last
 // workgroup of k_finish -- the agent-scope release/acquire it needs writes back and invalidates the L2 of every XCD per workgroup;
 // +20 us per k_finish, 3 ms per calibration slower than the separate launches.)
-__global__ __launch_bounds__(256) void k_prune_hull(PruneParams p, SelectParams sl) {
+struct HullParams { PruneParams p; SelectParams sl; };
+__device__ __forceinline__ void k_prune_hull_body(const HullParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [p, sl] = a_;
     __shared__ float sv[256];
     __shared__ int si[256];
     __shared__ int sh[8];
@@ -4014,6 +4139,8 @@ __global__ __launch_bounds__(256) void k_prune_hull(PruneParams p, SelectParams 
         for (int j = 0; j < sl.nj; ++j) select_block(sl, j, a, b, sv, si);
     }
 }
+__global__ __launch_bounds__(256) void k_prune_hull(HullParams p) { k_prune_hull_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_prune_hull_g(GroupArgs<HullParams> a) { P4V_GROUP_ENTER(a); k_prune_hull_body(a.p[m_], vb_, vg_); }
 
 struct FinishParams {
     const float* part; long p_cs, p_zs; int Np, MT, Z, N, C;
@@ -4028,7 +4155,7 @@ struct FinishParams {
 
 // One workgroup per (candidate, block): fixed thread->element assignment, double accumulation,
 // fixed-shape tree: the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void k_finish(FinishParams p) {
+__device__ __forceinline__ void k_finish_body(const FinishParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const int c = blockIdx.x, j = blockIdx.y;
     __shared__ double red[256];
     if (p.mark_done && c == 0 && j == 0) {
@@ -4073,6 +4200,8 @@ __global__ __launch_bounds__(256) void k_finish(FinishParams p) {
         if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(-p.norm * red[0]);
     }
 }
+__global__ __launch_bounds__(256) void k_finish(FinishParams p) { k_finish_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_finish_g(GroupArgs<FinishParams> a) { P4V_GROUP_ENTER(a); k_finish_body(a.p[m_], vb_, vg_); }
 
 // Cosine finish.  `part` holds triples (dot, |sim|^2, |raw|^2) laid out [C][ZB][ZV][FS][Sp][3]:
 // ZB real batch entries, ZV feature blocks swept as separate GEMMs, FS 64-feature slabs, Sp padded samples.
@@ -4095,7 +4224,7 @@ __device__ __forceinline__ float cos_item(const FinishCosParams& p, int c, int z
     const float na = fmaxf(sqrtf(oo), 1e-8f), nb = fmaxf(sqrtf(nn), 1e-8f);
     return dot / (na * nb);
 }
-__global__ __launch_bounds__(1024) void k_finish_cos(FinishCosParams p) {
+__device__ __forceinline__ void k_finish_cos_body(const FinishCosParams& p, const uint3 blockIdx, const uint3 gridDim) {
     // block size: 256 for j_mode 3 (thread = sample), 1024 otherwise (one workgroup per (candidate, score block) reads the
     // candidate's whole table -- 92 MB per pass for a ViT-B proj layer, 370 MB for fc1: 16 waves keep enough loads in flight)
     const int c = blockIdx.x, j = blockIdx.y, nt = blockDim.x;
@@ -4128,6 +4257,8 @@ __global__ __launch_bounds__(1024) void k_finish_cos(FinishCosParams p) {
     }
     if (threadIdx.x == 0) p.scores[(long)c * p.nj + j] = (float)(p.norm * red[0]);
 }
+__global__ __launch_bounds__(1024) void k_finish_cos(FinishCosParams p) { k_finish_cos_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(1024) void k_finish_cos_g(GroupArgs<FinishCosParams> a) { P4V_GROUP_ENTER(a); k_finish_cos_body(a.p[m_], vb_, vg_); }
 
 // argmax over candidates per block (torch.argmax semantics: first maximum, NaN is the maximum) and
 // gather of the winning candidate interval (linear.py:493-494).
@@ -4148,7 +4279,9 @@ __global__ __launch_bounds__(1024) void k_finish_cos(FinishCosParams p) {
 //   k_topk_rows: indices of the k heaviest rows, ascending (radix select on the float bits + ordered compaction; one
 //                workgroup; deterministic)
 //   k_gather:    dst[i][...] = src[idx[i]][...] for a 3-D strided inner block (dense destination)
-__global__ __launch_bounds__(256) void k_row_mass(const float* W, const float* O, long rows, long cols, int wt_mode, float* mass) {
+struct RowMassParams { const float* W; const float* O; long rows; long cols; int wt_mode; float* mass; };
+__device__ __forceinline__ void k_row_mass_body(const RowMassParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [W, O, rows, cols, wt_mode, mass] = a_;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -4163,6 +4296,8 @@ __global__ __launch_bounds__(256) void k_row_mass(const float* W, const float* O
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) mass[r] = s;
 }
+__global__ __launch_bounds__(256) void k_row_mass(RowMassParams p) { k_row_mass_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_row_mass_g(GroupArgs<RowMassParams> a) { P4V_GROUP_ENTER(a); k_row_mass_body(a.p[m_], vb_, vg_); }
 // mass2[i] = sum of `group` consecutive masses (matmul: the heads of one image)
 __global__ void k_group_mass(const float* mass, int n_groups, int group, float* out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4171,7 +4306,9 @@ __global__ void k_group_mass(const float* mass, int n_groups, int group, float* 
     for (int i = 0; i < group; ++i) s += mass[(long)g * group + i];
     out[g] = s;
 }
-__global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n, int k, int* idx_all) {
+struct TopkParams { const float* mass_all; int n; int k; int* idx_all; };
+__device__ __forceinline__ void k_topk_rows_body(const TopkParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [mass_all, n, k, idx_all] = a_;
     // one workgroup per segment (matmul: the rows of one (image, head); Linear: a single segment); indices are segment-local.
     // Radix select, one byte of the key per pass (256-bin histogram in the LDS, a wave whose keys share the digit adds its count
     // once), then an ordered compaction with wave ballots: 4 + 1 passes over the masses and one barrier per 1024 rows
@@ -4247,10 +4384,14 @@ __global__ __launch_bounds__(1024) void k_topk_rows(const float* mass_all, int n
         eq_taken += eq_take;
     }
 }
+__global__ __launch_bounds__(1024) void k_topk_rows(TopkParams p) { k_topk_rows_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(1024) void k_topk_rows_g(GroupArgs<TopkParams> a) { P4V_GROUP_ENTER(a); k_topk_rows_body(a.p[m_], vb_, vg_); }
 // dst[r][a][b][c] = src[seg_off(r / seg) + idx[r] * s0 + a * s1 + b * s2 + c * s3]; seg = rows per segment (0: one segment),
 // seg_off(z) = (z / zdiv) * sz2 + (z % zdiv) * sz (two-level batch stride: image, head)
 // frac[0] = (weight of the selected rows) / (weight of all rows): how tight the slice's bounds are
-__global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long n, const int* idx, int segs, int seg_rows, int k, float* frac, float* frac_host) {
+struct MassFracParams { const float* mass; long n; const int* idx; int segs; int seg_rows; int k; float* frac; float* frac_host; };
+__device__ __forceinline__ void k_mass_fraction_body(const MassFracParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [mass, n, idx, segs, seg_rows, k, frac, frac_host] = a_;
     __shared__ double red[1024];
     double tot = 0.0, sel = 0.0;
     for (long i = threadIdx.x; i < n; i += 1024) tot += (double)mass[i];
@@ -4268,9 +4409,11 @@ __global__ __launch_bounds__(1024) void k_mass_fraction(const float* mass, long 
         if (frac_host) frac_host[0] = f;               // mapped host memory: read after the stream sync, no copy command
     }
 }
+__global__ __launch_bounds__(1024) void k_mass_fraction(MassFracParams p) { k_mass_fraction_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(1024) void k_mass_fraction_g(GroupArgs<MassFracParams> a) { P4V_GROUP_ENTER(a); k_mass_fraction_body(a.p[m_], vb_, vg_); }
 
 struct GatherParams { const float* src; long s0, s1, s2, s3; int d1, d2, d3; const int* idx; int k; float* dst; int seg, zdiv; long sz2, sz; };
-__global__ __launch_bounds__(256) void k_gather(GatherParams p) {
+__device__ __forceinline__ void k_gather_body(const GatherParams& p, const uint3 blockIdx, const uint3 gridDim) {
     const long inner = (long)p.d1 * p.d2 * p.d3, total = inner * p.k;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / inner);
@@ -4282,17 +4425,25 @@ __global__ __launch_bounds__(256) void k_gather(GatherParams p) {
         p.dst[i] = p.src[off + (long)p.idx[r] * p.s0 + (long)a * p.s1 + (long)b * p.s2 + (long)cidx * p.s3];
     }
 }
+__global__ __launch_bounds__(256) void k_gather(GatherParams p) { k_gather_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_gather_g(GroupArgs<GatherParams> a) { P4V_GROUP_ENTER(a); k_gather_body(a.p[m_], vb_, vg_); }
 
 // rows idx[0..k) of the im2col matrix of a conv input (PackParams' conv fields; flat layout, Z = 1), dense [k][K]
-__global__ __launch_bounds__(256) void k_gather_im2col(PackParams p, const int* idx, int k, float* dst) {
+struct GatherIm2colParams { PackParams p; const int* idx; int k; float* dst; };
+__device__ __forceinline__ void k_gather_im2col_body(const GatherIm2colParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [p, idx, k, dst] = a_;
     const long total = (long)k * p.K;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / p.K), kk = (int)(i - (long)r * p.K);
         dst[i] = pack_load(p, p.src, idx[r], kk);
     }
 }
+__global__ __launch_bounds__(256) void k_gather_im2col(GatherIm2colParams p) { k_gather_im2col_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_gather_im2col_g(GroupArgs<GatherIm2colParams> a) { P4V_GROUP_ENTER(a); k_gather_im2col_body(a.p[m_], vb_, vg_); }
 // conv output / gradient [b][oc][L] -> rows of the im2col GEMM [b * L][oc] (32 x 32 tiles through LDS; grid (L/32, oc/32, b))
-__global__ __launch_bounds__(256) void k_nchw_to_rows(const float* src, int oc, int L, float* dst) {
+struct NchwRowsParams { const float* src; int oc; int L; float* dst; };
+__device__ __forceinline__ void k_nchw_to_rows_body(const NchwRowsParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [src, oc, L, dst] = a_;
     __shared__ float t[32][33];
     const int l0 = blockIdx.x * 32, c0 = blockIdx.y * 32, bi = blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -4302,22 +4453,50 @@ __global__ __launch_bounds__(256) void k_nchw_to_rows(const float* src, int oc, 
     for (int i = ty; i < 32; i += 8)
         if (l0 + i < L && c0 + tx < oc) dst[((long)bi * L + l0 + i) * oc + c0 + tx] = t[tx][i];
 }
-__global__ void k_fill_f32(float* p, float v, int n) {
+__global__ __launch_bounds__(256) void k_nchw_to_rows(NchwRowsParams p) { k_nchw_to_rows_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_nchw_to_rows_g(GroupArgs<NchwRowsParams> a) { P4V_GROUP_ENTER(a); k_nchw_to_rows_body(a.p[m_], vb_, vg_); }
+// memset of a small device range as a kernel of this library (hipMemsetAsync is a runtime kernel of its own per call and cannot
+// join a grouped launch): flags, ordered-max accumulators, zero biases, partial-sum tables
+struct FillBytesParams { void* dst; int value; long bytes; };
+__device__ __forceinline__ void k_fill_bytes_body(const FillBytesParams& p, const uint3 blockIdx, const uint3 gridDim) {
+    const unsigned b = (unsigned)p.value & 0xffu;
+    if (((unsigned long long)p.dst & 3) == 0 && (p.bytes & 3) == 0) {
+        const unsigned w = b * 0x01010101u;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (p.bytes >> 2); i += (long)gridDim.x * 256) reinterpret_cast<unsigned*>(p.dst)[i] = w;
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.bytes; i += (long)gridDim.x * 256) reinterpret_cast<unsigned char*>(p.dst)[i] = (unsigned char)b;
+    }
+}
+__global__ __launch_bounds__(256) void k_fill_bytes(FillBytesParams p) { k_fill_bytes_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ __launch_bounds__(256) void k_fill_bytes_g(GroupArgs<FillBytesParams> a) { P4V_GROUP_ENTER(a); k_fill_bytes_body(a.p[m_], vb_, vg_); }
+struct FillParams { float* p; float v; int n; };
+__device__ __forceinline__ void k_fill_f32_body(const FillParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [p, v, n] = a_;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void k_fill_f32(FillParams p) { k_fill_f32_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_fill_f32_g(GroupArgs<FillParams> a) { P4V_GROUP_ENTER(a); k_fill_f32_body(a.p[m_], vb_, vg_); }
 // virt: the final table is stage B2's; where B2 did not run a block's winner (empty B2), the synthetic candidate's score stands in
-__global__ void k_merge_virtual(float* S2, const float* SB, const int* best, int nj) {
+struct MergeVirtParams { float* S2; const float* SB; const int* best; int nj; };
+__device__ __forceinline__ void k_merge_virtual_body(const MergeVirtParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [S2, SB, best, nj] = a_;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nj) return;
     float* d = S2 + (long)best[j] * nj + j;
     if (*d == -__builtin_inff()) *d = SB[j];
 }
+__global__ void k_merge_virtual(MergeVirtParams p) { k_merge_virtual_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_merge_virtual_g(GroupArgs<MergeVirtParams> a) { P4V_GROUP_ENTER(a); k_merge_virtual_body(a.p[m_], vb_, vg_); }
 // final score table of a pruned pass: stage B2's where it evaluated the candidate, stage B1's otherwise (the two agree bit for bit
 // where both did)
-__global__ void k_merge_scores(float* S2, const float* SB, int n) {
+struct MergeParams { float* S2; const float* SB; int n; };
+__device__ __forceinline__ void k_merge_scores_body(const MergeParams& a_, const uint3 blockIdx, const uint3 gridDim) {
+    const auto& [S2, SB, n] = a_;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && S2[i] == -__builtin_inff()) S2[i] = SB[i];
 }
+__global__ void k_merge_scores(MergeParams p) { k_merge_scores_body(p, P4V_BIDX, P4V_GDIM); }
+__global__ void k_merge_scores_g(GroupArgs<MergeParams> a) { P4V_GROUP_ENTER(a); k_merge_scores_body(a.p[m_], vb_, vg_); }
 
 }  // namespace p4v

@@ -33,10 +33,10 @@ def to_dev(t, dev):
     return t.detach().to(device=dev, dtype=torch.float32)
 
 
-def workspace(dev, nbytes):
-    """Scratch for one calibration call; one buffer per (device, stream) so that searches running on different
-    streams (utils/quant_calib.py runs two modules at a time) never share scratch."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+def workspace(dev, nbytes, slot=0):
+    """Scratch for one calibration call; one buffer per (device, stream, member of a group) so that searches running on
+    different streams, and the members of a p4v_calibrate_group call, never share scratch."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, slot)
     ws = _workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspace.pop(key, None)
@@ -87,10 +87,79 @@ def metric_id(name):
     return _lib.METRICS[name]
 
 
-def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
-                     n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False, memoize=True,
-                     prune=True):
-    """Run calibration_step2 of a (post-GELU) Linear on the GPU.  Returns (w_interval[n_V*n_H], a_interval[n_a], scores, best)."""
+class Job:
+    """One prepared p4v_*_calibrate call: descriptor, device tensors (kept alive until the results are taken), outputs,
+    workspace size.  `run_job` makes the call; `calibrate_group` makes the calls of many jobs as ONE p4v_calibrate_group."""
+    __slots__ = ("kind", "name", "desc", "inputs", "mult", "outputs", "need", "dev", "scores", "best")
+
+    def __init__(self, kind, name, desc, inputs, mult, outputs, need, dev, scores=None, best=None):
+        self.kind, self.name, self.desc, self.inputs, self.mult = kind, name, desc, inputs, mult
+        self.outputs, self.need, self.dev, self.scores, self.best = outputs, need, dev, scores, best
+
+
+def _need(fn, desc, what):
+    need = fn(C.byref(desc))
+    if need == 0:
+        _lib.check(-1 if not _lib.load().p4v_last_error() else -2, what)
+    return need
+
+
+def run_job(job):
+    """The single-module call (p4v_linear_calibrate / p4v_matmul_calibrate / p4v_conv_calibrate) on the current stream."""
+    lib = _lib.load()
+    ws = workspace(job.dev, job.need)
+    with torch.cuda.device(job.dev):
+        rc = getattr(lib, job.name)(C.byref(job.desc), *[ptr(t) for t in job.inputs], ptr(job.mult), *[ptr(t) for t in job.outputs],
+                                    ptr(job.scores), ptr(job.best), ptr(ws), ws.numel(), stream_ptr(job.dev))
+    _lib.check(rc, job.name)
+    return job
+
+
+def calibrate_group(jobs):
+    """calibration_step2 of all `jobs` in ONE p4v_calibrate_group call on the current stream: the members search in lock
+    step, every kernel launch of the same kind is issued once for all of them.  Results bit-identical to run_job on each."""
+    jobs = list(jobs)
+    if not jobs:
+        return jobs
+    lib = _lib.load()
+    dev = jobs[0].dev
+    arr = (_lib.GroupJob * len(jobs))()
+    keep = []
+    for i, job in enumerate(jobs):
+        if job.dev != dev:
+            raise ValueError("calibrate_group: every member must live on the same device")
+        if job.scores is not None:
+            raise ValueError("calibrate_group: score tables are only returned by the single-module calls")
+        ws = workspace(dev, job.need, slot=i)
+        keep.append(ws)
+        g = arr[i]
+        g.kind, g.status, g.desc = job.kind, 0, C.cast(C.pointer(job.desc), C.c_void_p)
+        ins = list(job.inputs) + [None] * (5 - len(job.inputs))
+        for k in range(5):
+            g.inp[k] = ins[k].data_ptr() if ins[k] is not None else None
+        g.mult = job.mult.data_ptr()
+        outs = list(job.outputs) + [None] * (3 - len(job.outputs))
+        for k in range(3):
+            g.out[k] = outs[k].data_ptr() if outs[k] is not None else None
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
+    with torch.cuda.device(dev):
+        rc = lib.p4v_calibrate_group(arr, len(jobs), stream_ptr(dev))
+    _lib.check(rc, "p4v_calibrate_group")
+    del keep
+    return jobs
+
+
+def launch_counters(reset=False):
+    """Process-wide launch counters (p4v_launch_counters): launches the calibration path asked for, launches issued to the
+    GPU (a grouped launch counts once), issue rounds of the groups, group calls."""
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.load().p4v_launch_counters(out, int(bool(reset))), "p4v_launch_counters")
+    return dict(zip(("asked", "issued", "rounds", "groups"), (int(v) for v in out)))
+
+
+def linear_job(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
+               n_V, n_H, n_a, init_layerwise=False, postgelu=False, want_scores=False, force_f32=False, memoize=True,
+               prune=True):
     lib = _lib.load()
     dev = device_of(x, weight)
     weight, bias, x, out, grad = (to_dev(t, dev) for t in (weight, bias, x, out, grad))
@@ -103,20 +172,19 @@ def linear_calibrate(*, weight, bias, x, out, grad, w_bit, a_bit, metric, eq_alp
     d = _lib.LinearDesc(batch, tokens, K, N, n_V, n_H, n_a, w_bit, a_bit, metric_id(metric), eq_n, search_round,
                         int(postgelu), int(init_layerwise), int(bias is not None),
                         int(force_f32) | (0 if memoize else 2) | (0 if prune else 8))
-    need = lib.p4v_linear_workspace_bytes(C.byref(d))
-    if need == 0:
-        _lib.check(-1 if not lib.p4v_last_error() else -2, "p4v_linear_workspace_bytes")
-    ws = workspace(dev, need)
+    need = _need(lib.p4v_linear_workspace_bytes, d, "p4v_linear_workspace_bytes")
     mult = candidate_multipliers(eq_alpha, eq_beta, eq_n, dev)
     w_iv = torch.empty(n_V * n_H, dtype=torch.float32, device=dev)
     a_iv = torch.empty(n_a, dtype=torch.float32, device=dev)
     scores = torch.zeros(search_round, 2, eq_n, n_V, dtype=torch.float32, device=dev) if want_scores else None
     best = torch.zeros(search_round, 2, n_V, dtype=torch.int32, device=dev) if want_scores else None
-    with torch.cuda.device(dev):
-        rc = lib.p4v_linear_calibrate(C.byref(d), ptr(weight), ptr(bias), ptr(x), ptr(out), ptr(grad), ptr(mult),
-                                      ptr(w_iv), ptr(a_iv), ptr(scores), ptr(best), ptr(ws), ws.numel(), stream_ptr(dev))
-    _lib.check(rc, "p4v_linear_calibrate")
-    return w_iv, a_iv, scores, best
+    return Job(_lib.JOB_LINEAR, "p4v_linear_calibrate", d, (weight, bias, x, out, grad), mult, (w_iv, a_iv), need, dev, scores, best)
+
+
+def linear_calibrate(**kw):
+    """Run calibration_step2 of a (post-GELU) Linear on the GPU.  Returns (w_interval[n_V*n_H], a_interval[n_a], scores, best)."""
+    job = run_job(linear_job(**kw))
+    return job.outputs[0], job.outputs[1], job.scores, job.best
 
 
 def linear_quant_forward(*, weight, bias, x, w_interval, a_interval, w_bit, a_bit, n_V, n_H, n_a, postgelu=False):
@@ -173,9 +241,8 @@ def matmul_quant_forward(*, A, B, A_interval, B_interval, split, A_bit, B_bit, s
     return out
 
 
-def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
-                     sos=False, init_layerwise=False, want_scores=False, prune=True):
-    """Run calibration_step2 of a MatMul (head-wise; optional split-of-softmax on A) on the GPU."""
+def matmul_job(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta, eq_n, search_round,
+               sos=False, init_layerwise=False, want_scores=False, prune=True):
     lib = _lib.load()
     dev = device_of(A, B)
     A, B, out, grad = (to_dev(t, dev) for t in (A, B, out, grad))
@@ -190,26 +257,24 @@ def matmul_calibrate(*, A, B, out, grad, A_bit, B_bit, metric, eq_alpha, eq_beta
         d.b_stride[i] = B.stride(i)
     d.A_bit, d.B_bit, d.metric, d.eq_n, d.search_round = A_bit, B_bit, metric_id(metric), eq_n, search_round
     d.sos, d.init_layerwise, d.reserved = int(sos), int(init_layerwise), (0 if prune else 8)
-    need = lib.p4v_matmul_workspace_bytes(C.byref(d))
-    if need == 0:
-        _lib.check(-2, "p4v_matmul_workspace_bytes")
-    ws = workspace(dev, need)
+    need = _need(lib.p4v_matmul_workspace_bytes, d, "p4v_matmul_workspace_bytes")
     mult = candidate_multipliers(eq_alpha, eq_beta, eq_n, dev)
     A_iv = torch.empty(1 if sos else H, dtype=torch.float32, device=dev)
     B_iv = torch.empty(H, dtype=torch.float32, device=dev)
     split = torch.empty(1, dtype=torch.float32, device=dev) if sos else None
     scores = torch.zeros(search_round, 2, eq_n, H, dtype=torch.float32, device=dev) if want_scores else None
     best = torch.zeros(search_round, 2, H, dtype=torch.int32, device=dev) if want_scores else None
-    with torch.cuda.device(dev):
-        rc = lib.p4v_matmul_calibrate(C.byref(d), ptr(A), ptr(B), ptr(out), ptr(grad), ptr(mult), ptr(A_iv), ptr(B_iv),
-                                      ptr(split), ptr(scores), ptr(best), ptr(ws), ws.numel(), stream_ptr(dev))
-    _lib.check(rc, "p4v_matmul_calibrate")
-    return A_iv, B_iv, split, scores, best
+    return Job(_lib.JOB_MATMUL, "p4v_matmul_calibrate", d, (A, B, out, grad), mult, (A_iv, B_iv, split), need, dev, scores, best)
 
 
-def conv_calibrate(*, weight, bias, x, out, grad, stride, padding, dilation, w_bit, a_bit, metric, eq_alpha, eq_beta,
-                   eq_n, search_round, channelwise=True, init_layerwise=False, want_scores=False, prune=True):
-    """Run calibration_step2 of the patch-embedding Conv2d on the GPU (prune=False: no exact candidate pruning)."""
+def matmul_calibrate(**kw):
+    """Run calibration_step2 of a MatMul (head-wise; optional split-of-softmax on A) on the GPU."""
+    job = run_job(matmul_job(**kw))
+    return job.outputs[0], job.outputs[1], job.outputs[2], job.scores, job.best
+
+
+def conv_job(*, weight, bias, x, out, grad, stride, padding, dilation, w_bit, a_bit, metric, eq_alpha, eq_beta,
+             eq_n, search_round, channelwise=True, init_layerwise=False, want_scores=False, prune=True):
     lib = _lib.load()
     dev = device_of(x, weight)
     weight, bias, x, out, grad = (to_dev(t, dev) for t in (weight, bias, x, out, grad))
@@ -220,21 +285,20 @@ def conv_calibrate(*, weight, bias, x, out, grad, stride, padding, dilation, w_b
     d = _lib.ConvDesc(b, ic, H, W, oc, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                       w_bit, a_bit, metric_id(metric), eq_n, search_round, int(channelwise), int(init_layerwise),
                       int(bias is not None), 0 if prune else 8)
-    need = lib.p4v_conv_workspace_bytes(C.byref(d))
-    if need == 0:
-        _lib.check(-2, "p4v_conv_workspace_bytes")
-    ws = workspace(dev, need)
+    need = _need(lib.p4v_conv_workspace_bytes, d, "p4v_conv_workspace_bytes")
     mult = candidate_multipliers(eq_alpha, eq_beta, eq_n, dev)
     nw = oc if channelwise else 1
     w_iv = torch.empty(nw, dtype=torch.float32, device=dev)
     a_iv = torch.empty(1, dtype=torch.float32, device=dev)
     scores = torch.zeros(search_round, 2, eq_n, nw, dtype=torch.float32, device=dev) if want_scores else None
     best = torch.zeros(search_round, 2, nw, dtype=torch.int32, device=dev) if want_scores else None
-    with torch.cuda.device(dev):
-        rc = lib.p4v_conv_calibrate(C.byref(d), ptr(weight), ptr(bias), ptr(x), ptr(out), ptr(grad), ptr(mult),
-                                    ptr(w_iv), ptr(a_iv), ptr(scores), ptr(best), ptr(ws), ws.numel(), stream_ptr(dev))
-    _lib.check(rc, "p4v_conv_calibrate")
-    return w_iv, a_iv, scores, best
+    return Job(_lib.JOB_CONV, "p4v_conv_calibrate", d, (weight, bias, x, out, grad), mult, (w_iv, a_iv), need, dev, scores, best)
+
+
+def conv_calibrate(**kw):
+    """Run calibration_step2 of the patch-embedding Conv2d on the GPU (prune=False: no exact candidate pruning)."""
+    job = run_job(conv_job(**kw))
+    return job.outputs[0], job.outputs[1], job.scores, job.best
 
 
 # ----------------------------------------------------------------------------------------------------------------

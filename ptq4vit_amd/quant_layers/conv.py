@@ -180,23 +180,29 @@ class _BatchingConv(PTQSLQuantConv2d):
         x_sim = self.quant_input(x) if self.a_bit < 32 else x
         return self._conv(x_sim, w_sim, bias_sim)
 
-    def calibration_step2(self):
-        """p4v_conv_calibrate: replaces conv.py:591-603 / :429-441."""
+    def calibration_job(self):
+        """The prepared p4v_conv_calibrate call (engine.Job): replaces conv.py:591-603 / :429-441."""
         if self.groups != 1 or self.padding_mode != "zeros":
             raise NotImplementedError("ptq4vit_amd: grouped / non-zero-padded convolutions are not implemented on the GPU")
         if self.metric == "hessian":
             assert self.raw_grad is not None, "raw_grad is None in _get_similarity!"
         self._initialize_calib_parameters()
-        w_iv, a_iv, _, _ = engine.conv_calibrate(
+        return engine.conv_job(
             weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=self.raw_input,
             out=self.raw_out, grad=self.raw_grad if self.metric == "hessian" else None, stride=self.stride,
             padding=self.padding, dilation=self.dilation, w_bit=self.w_bit, a_bit=self.a_bit, metric=self.metric,
             eq_alpha=self.eq_alpha, eq_beta=self.eq_beta, eq_n=self.eq_n, search_round=self.search_round,
             channelwise=self._channelwise, init_layerwise=self.init_layerwise)
+
+    def calibration_install(self, job):
+        w_iv, a_iv = job.outputs
         self.w_interval = w_iv.view(-1, 1, 1, 1) if self._channelwise else w_iv.reshape(1, 1, 1, 1)
         self.a_interval = a_iv if self.a_bit >= 32 else a_iv.reshape(())
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
+
+    def calibration_step2(self):
+        self.calibration_install(engine.run_job(self.calibration_job()))
 
     # ---- the reference's per-pass methods, ONE GPU pass each (SURVEY.md s8 rows a12/a13; C ABI p4v_amax_init_conv,
     # p4v_conv_search_w_channelwise / _layerwise, p4v_conv_search_a).  calibration_step2 runs them fused in one call. ----

@@ -125,19 +125,26 @@ class PTQSLQuantLinear(MinMaxQuantLinear):
         return F.linear(self.quant_input(x), w_sim, bias_sim)
 
     # ---- the GPU search ---------------------------------------------------------------------
-    def _search_on_gpu(self, x, raw_out, raw_grad):
-        """p4v_linear_calibrate: replaces linear.py:536-555 (and :235-260 for the non-batching classes)."""
+    def _search_job(self, x, raw_out, raw_grad):
+        """The prepared p4v_linear_calibrate call (engine.Job): replaces linear.py:536-555 (and :235-260 for the
+        non-batching classes).  engine.run_job makes it alone, engine.calibrate_group together with other modules'."""
         if self.metric == "hessian":
             assert raw_grad is not None, "raw_grad is None in _get_similarity!"
-        w_iv, a_iv, _, _ = engine.linear_calibrate(
+        return engine.linear_job(
             weight=self.weight.data, bias=None if self.bias is None else self.bias.data, x=x, out=raw_out,
             grad=raw_grad if self.metric == "hessian" else None, w_bit=self.w_bit, a_bit=self.a_bit,
             metric=self.metric, eq_alpha=self.eq_alpha, eq_beta=self.eq_beta, eq_n=self.eq_n,
             search_round=self.search_round, n_V=self.n_V, n_H=self.n_H, n_a=self.n_a,
             init_layerwise=self.init_layerwise, postgelu=self._postgelu)
+
+    def _search_install(self, job):
+        w_iv, a_iv = job.outputs
         dev = self.weight.device if self.weight.is_cuda else w_iv.device
         self.w_interval = w_iv.view(self.n_V, 1, self.n_H, 1).to(dev)
         self._set_a_interval(a_iv.view(self.n_a, 1).to(dev))
+
+    def _search_on_gpu(self, x, raw_out, raw_grad):
+        self._search_install(engine.run_job(self._search_job(x, raw_out, raw_grad)))
 
     def _set_a_interval(self, a_iv):
         self.a_interval = a_iv
@@ -179,11 +186,20 @@ class PTQSLBatchingQuantLinear(PTQSLQuantLinear):
         numel = 2 * (self.raw_input.numel() + self.raw_out.numel())
         self.calib_batch_size, self.parallel_eq_n, self.calib_need_batching = calib_parameters(numel, self.calib_size)
 
-    def calibration_step2(self):
+    def calibration_job(self):
+        """calibration_step2 in two halves, so that the calibrator can run the searches of many modules as one
+        p4v_calibrate_group call: the prepared engine call ..."""
         self._initialize_calib_parameters()
-        self._search_on_gpu(self.raw_input, self.raw_out, self.raw_grad)
+        return self._search_job(self.raw_input, self.raw_out, self.raw_grad)
+
+    def calibration_install(self, job):
+        """... and what follows it (reference linear.py:551-555: intervals set, calibrated, caches dropped)."""
+        self._search_install(job)
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
+
+    def calibration_step2(self):
+        self.calibration_install(engine.run_job(self.calibration_job()))
         return None
 
     # ---- the reference's per-pass methods, ONE GPU pass each (SURVEY.md s8 rows a4, a6-a8; C ABI p4v_amax_init_linear /

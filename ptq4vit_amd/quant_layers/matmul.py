@@ -124,9 +124,9 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
         return self.quant_input_A(A) @ self.quant_input_B(B)
 
     # ---- the GPU search --------------------------------------------------------------------------
-    def _search_on_gpu(self, A, B, raw_out, raw_grad):
-        """p4v_matmul_calibrate: replaces matmul.py:565-576 / :633-644.  The engine searches one interval per
-        head (the Batching classes force n_G = heads, matmul.py:411-417) with n_V = n_H = 1."""
+    def _search_job(self, A, B, raw_out, raw_grad):
+        """The prepared p4v_matmul_calibrate call (engine.Job): replaces matmul.py:565-576 / :633-644.  The engine searches
+        one interval per head (the Batching classes force n_G = heads, matmul.py:411-417) with n_V = n_H = 1."""
         if self.metric == "hessian":
             assert raw_grad is not None, "No raw_grad in PTQSLBatchingQuantMatMul!"
         if (self.n_V_A, self.n_H_A, self.n_V_B, self.n_H_B) != (1, 1, 1, 1):
@@ -134,16 +134,23 @@ class PTQSLQuantMatMul(MinMaxQuantMatMul):
         H = A.shape[1]
         self.n_G_A, self.n_G_B = H, H   # head-wise (matmul.py:415-416; also overrides the SoS constructor's n_G_A = 1)
         self._get_padding_parameters(A, B)
-        A_iv, B_iv, split, _, _ = engine.matmul_calibrate(
+        return engine.matmul_job(
             A=A, B=B, out=raw_out, grad=raw_grad if self.metric == "hessian" else None, A_bit=self.A_bit,
             B_bit=self.B_bit, metric=self.metric, eq_alpha=self.eq_alpha, eq_beta=self.eq_beta, eq_n=self.eq_n,
             search_round=self.search_round, sos=self._sos, init_layerwise=self.init_layerwise)
+
+    def _search_install(self, job):
+        A_iv, B_iv, split = job.outputs
+        H = B_iv.numel()
         self.B_interval = B_iv.view(1, H, 1, 1, 1, 1, 1)
         if self._sos:
             self.split = split.reshape(())
             self.A_interval = A_iv.reshape(())
         else:
             self.A_interval = A_iv.view(1, H, 1, 1, 1, 1, 1)
+
+    def _search_on_gpu(self, A, B, raw_out, raw_grad):
+        self._search_install(engine.run_job(self._search_job(A, B, raw_out, raw_grad)))
 
     @staticmethod
     def _per_head(interval, H, crb_groups):
@@ -252,11 +259,18 @@ class PTQSLBatchingQuantMatMul(PTQSLQuantMatMul):
         self.n_G_B = B.shape[1]
         super()._get_padding_parameters(A, B)
 
-    def calibration_step2(self):
+    def calibration_job(self):
+        """The prepared engine call of calibration_step2 (see PTQSLBatchingQuantLinear.calibration_job)."""
         self._initialize_calib_parameters()
-        self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
+        return self._search_job(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
+
+    def calibration_install(self, job):
+        self._search_install(job)
         self.calibrated = True
         del self.raw_input, self.raw_out, self.raw_grad
+
+    def calibration_step2(self):
+        self.calibration_install(engine.run_job(self.calibration_job()))
 
     # ---- the reference's per-pass methods, ONE GPU pass each (SURVEY.md s8 rows a10/a11; C ABI p4v_amax_init_matmul,
     # p4v_matmul_search_A / _B, p4v_sos_search_split).  calibration_step2 runs the same kernels fused in one call. ----
@@ -325,7 +339,4 @@ class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
 
     def calibration_step2(self):
         """Reference matmul.py:633-644 (caches are deleted at the end, :644)."""
-        self._initialize_calib_parameters()
-        self._search_on_gpu(self.raw_input[0], self.raw_input[1], self.raw_out, self.raw_grad)
-        self.calibrated = True
-        del self.raw_input, self.raw_out, self.raw_grad
+        self.calibration_install(engine.run_job(self.calibration_job()))

@@ -654,6 +654,93 @@ class HessianQuantCalibrator(QuantCalibrator):
         if errors:
             raise errors[0]
 
+    def _search_grouped(self, names, n_calls):
+        """Independent modules (sequential=False) searched TOGETHER: `n_calls` p4v_calibrate_group calls (one host thread + HIP
+        stream each), every call running the calibration_step2 of its modules in lock step with the kernel launches of the
+        same kind issued once for all of them (csrc/p4v_api.hip, Group).  Replaces the loop of the reference's calibrator
+        (utils/quant_calib.py:371-372).  Results do not depend on the partition: a grouped kernel runs every module's own
+        code on its own parameters and scratch."""
+        import threading
+        import time
+        from .. import engine
+        dev = _dev_of(self.net)
+        main = torch.cuda.current_stream(dev)
+        n_calls = max(1, min(n_calls, len(names)))
+        _warn_hw_queues(n_calls)
+        streams = engine.side_streams(dev, n_calls)
+        if not hasattr(self, "_module_ms"):
+            self._module_ms = {}
+        for s in streams:
+            s.wait_stream(main)                       # the captured tensors were produced on the current stream
+        keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
+        # modules of one kind are dealt over the calls, so that every call holds the same mixture (and its launches group)
+        def kind(n):
+            m = self.wrapped_modules[n]
+            ri = m.raw_input
+            shp = tuple(tuple(t.shape) for t in ri) if isinstance(ri, (list, tuple)) else tuple(ri.shape)
+            return (type(m).__name__, shp, tuple(m.raw_out.shape))
+        order = sorted(names, key=lambda n: (str(kind(n)), names.index(n)))
+        parts = [order[i::n_calls] for i in range(n_calls)]
+        budget = int(float(os.environ.get("P4V_GROUP_GIB", "150")) * (1 << 30)) // n_calls
+        errors = []
+
+        def cost(n, sizes):
+            return shard.module_cost_ms(self.wrapped_modules[n], sizes[n])
+
+        def worker(s, part):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(s), torch.no_grad():
+                    todo = list(part)
+                    while todo and not errors:
+                        t_grp = time.perf_counter()
+                        batch, jobs, sizes, acc = [], [], {}, 0
+                        while todo:
+                            n = todo[0]
+                            m = self.wrapped_modules[n]
+                            if not hasattr(m, "calibration_job"):        # a class without the two-step protocol: alone
+                                if batch:
+                                    break
+                                todo.pop(0)
+                                m.calibration_step2()
+                                m.mode = "raw"
+                                self._module_ms[n] = (time.perf_counter() - t_grp) * 1e3
+                                t_grp = time.perf_counter()
+                                continue
+                            ri = m.raw_input
+                            sizes[n] = 4 * (sum(t.numel() for t in ri) if isinstance(ri, (list, tuple)) else ri.numel()) + 8 * m.raw_out.numel()
+                            job = m.calibration_job()
+                            if batch and acc + job.need > budget:          # scratch of the members so far fills the budget: next call
+                                break
+                            todo.pop(0)
+                            batch.append(n); jobs.append(job); acc += job.need
+                        if not batch:
+                            continue
+                        engine.calibrate_group(jobs)
+                        for n, j in zip(batch, jobs):
+                            m = self.wrapped_modules[n]
+                            m.calibration_install(j)
+                            m.mode = "raw"
+                        ms = (time.perf_counter() - t_grp) * 1e3
+                        w = {n: cost(n, sizes) for n in batch}
+                        tot = sum(w.values()) or 1.0
+                        for n in batch:                     # (the call's wall time, shared out by the cost model: next LPT plan)
+                            self._module_ms[n] = ms * w[n] / tot
+            except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(s, p)) for s, p in zip(streams, parts)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for s in streams:
+            main.wait_stream(s)
+        torch.cuda.synchronize(dev)
+        del keep
+        if errors:
+            raise errors[0]
+
     def _estimate_cache_bytes(self, names):
         """One cheap probe forward of a single image to size the caches of `names` (kept with the network: the sizes depend
         on the architecture and the image geometry only; every rank of a sharded calibration needs them each time)."""
@@ -797,7 +884,12 @@ class HessianQuantCalibrator(QuantCalibrator):
             elif torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()
-            if concurrent:
+            grouped = getattr(self, "search_grouped", None)
+            if grouped is None:
+                grouped = os.environ.get("P4V_GROUPED", "1") != "0"
+            if concurrent and grouped:
+                self._search_grouped(grp, getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "1")))
+            elif concurrent:
                 self._search_concurrent(grp, n_streams)
                 if cap_done is not None:            # (everything is synchronised now) when the capture really ended
                     ref = torch.cuda.Event(enable_timing=True)
