@@ -353,10 +353,65 @@ class HessianQuantCalibrator(QuantCalibrator):
                 tuple(getattr(m, "mode", "raw") for m in self.wrapped_modules.values()),     # all "raw", see _capture_passes_graph
                 tuple(p.data_ptr() for p in self.net.parameters()))
 
-    def _build_graph(self, dev, bs, inp, raw_pred_softmax):
+    # ---- ... or with the ARCHITECTURE (round 6): a fresh network object replays the graph recorded for its architecture --------
+    # What the reference's driver times is a NEW network object calibrated once (example/test_all.py:24-34), and a process walks
+    # many of them (example/test_all.py:83-103: every bit setting re-creates the network).  A graph recorded on one network's
+    # parameter storage is useless for the next one -- but the kernel sequence of the raw sub-batch pass depends on the
+    # architecture only.  So the graph is recorded on a private copy of the network (the "shadow", own parameter storage, kept
+    # per architecture for the life of the process); a fresh network copies its parameters and buffers into the shadow's storage
+    # (one fused D2D copy, ~0.35 GB for ViT-B: 0.2 ms) and replays: the same kernels on the same values as its own eager pass --
+    # the captured tensors are bit-identical (tests/test_hip_model.py) -- without the ~110 ms of Python / dispatcher time of eight
+    # eager passes.  Built at the SECOND sighting of an architecture (a process that calibrates one network once never pays for
+    # it); P4V_ARCH_GRAPHS=0 switches it off, `use_graph` = True builds at the first.
+    _ARCH = {}            # architecture key -> {"seen": n, "net", "mods", "lanes", "src": [...], "dst": [...]}
+
+    def _arch_key(self, dev, bs, inp):
+        sig = tuple((n, tuple(p.shape), str(p.dtype)) for n, p in self.net.named_parameters()) + \
+            tuple((n, tuple(b.shape), str(b.dtype)) for n, b in self.net.named_buffers())
+        kinds = tuple((n, type(m).__name__) for n, m in self.wrapped_modules.items())
+        return (str(dev), int(bs), tuple(inp.shape[1:]), str(inp.dtype), type(self.net).__name__, sig, kinds)
+
+    def _arch_shadow(self, dev, bs, inp, build):
+        """The shadow of this network's architecture with this network's parameter VALUES in it, or None."""
+        if os.environ.get("P4V_ARCH_GRAPHS", "1") == "0":
+            return None
+        key = self._arch_key(dev, bs, inp)
+        rec = HessianQuantCalibrator._ARCH.setdefault(key, {"seen": 0, "nets": set()})
+        if id(self.net) not in rec["nets"]:
+            rec["nets"].add(id(self.net))
+            rec["seen"] += 1
+        if "net" not in rec:
+            if not (build or rec["seen"] >= 2):
+                return None
+            import copy
+            try:
+                with torch.no_grad():
+                    net2, mods2 = copy.deepcopy((self.net, dict(self.wrapped_modules)))
+            except Exception as e:  # noqa: BLE001 - a network that cannot be copied keeps its own graphs
+                print(f"[ptq4vit_amd] architecture graph unavailable ({type(e).__name__}: {e})")
+                rec["net"] = None
+                return None
+            for m in mods2.values():
+                for a in ("raw_input", "raw_out", "raw_grad"):
+                    m.__dict__.pop(a, None)
+                m.mode = "raw"
+            for p in net2.parameters():
+                p.requires_grad_(False)
+            rec.update(net=net2, mods=mods2, lanes=[])
+        if rec.get("net") is None:
+            return None
+        src = [p.data for p in self.net.parameters()] + [b for b in self.net.buffers()]
+        dst = [p.data for p in rec["net"].parameters()] + [b for b in rec["net"].buffers()]
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+        return rec
+
+    def _build_graph(self, dev, bs, inp, raw_pred_softmax, shadow=None):
         """Record ONE sub-batch forward + KL backward with hooks on EVERY wrapped module (so that any group of modules, on
-        any later calibration, can be served from it).  Returns the cache entry or None when graph capture is unavailable."""
-        mods = self.wrapped_modules
+        any later calibration, can be served from it).  Returns the cache entry or None when graph capture is unavailable.
+        `shadow`: record on the architecture's private copy of the network instead of on this one."""
+        mods = self.wrapped_modules if shadow is None else shadow["mods"]
+        net = self.net if shadow is None else shadow["net"]
         # (a module whose step 2 has run -- here, or on its owner rank before the interval exchange -- has had its cache
         # attributes DELETED, reference linear.py:554; the hooks below expect them to exist)
         missing = object()
@@ -372,7 +427,7 @@ class HessianQuantCalibrator(QuantCalibrator):
 
         def one_pass(x, tgt):
             x.grad = None
-            self._kl_loss(self.net(x), tgt, inv_n).backward()
+            self._kl_loss(net(x), tgt, inv_n).backward()
 
         hooks = []
         for m in mods.values():
@@ -462,6 +517,19 @@ class HessianQuantCalibrator(QuantCalibrator):
         cache = self.net.__dict__.setdefault("_p4v_capture_graphs", {})
         key = self._graph_key(dev, bs, inp)
         lanes = cache.get(key)
+        shadow = None
+        if lanes is None:
+            seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
+            shadow = self._arch_shadow(dev, bs, inp, build=bool(use_graph or n_sub >= 24 or seen_before))
+            if shadow is not None:
+                lanes = shadow["lanes"]
+                if not lanes:
+                    entry = self._build_graph(dev, bs, inp, raw_pred_softmax, shadow)
+                    if entry is None:
+                        shadow["net"] = None
+                        lanes = shadow = None
+                    else:
+                        lanes.append(entry)
         if lanes is None:
             seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
             if not (use_graph or n_sub >= 24 or seen_before):
@@ -476,7 +544,7 @@ class HessianQuantCalibrator(QuantCalibrator):
         # streams at the same time; every sub-batch still runs exactly the recorded kernels, so the caches do not change.
         want = int(getattr(self, "capture_lanes", None) or os.environ.get("P4V_CAPTURE_LANES", "3"))
         while len(lanes) < max(1, min(want, n_sub)):
-            entry = self._build_graph(dev, bs, inp, raw_pred_softmax)
+            entry = self._build_graph(dev, bs, inp, raw_pred_softmax, shadow)
             if entry is None:
                 break
             lanes.append(entry)
@@ -865,7 +933,12 @@ class HessianQuantCalibrator(QuantCalibrator):
         def run_group(grp):
             t1 = time.time()
             n_streams = getattr(self, "search_streams", None) or int(os.environ.get("P4V_SEARCH_STREAMS", "4"))
-            concurrent = batching and not self.sequential and n_streams > 1 and _dev_of(self.net).type == "cuda" and len(grp) > 1
+            grouped = getattr(self, "search_grouped", None)
+            if grouped is None:
+                grouped = os.environ.get("P4V_GROUPED", "1") != "0"
+            # (the grouped search is one call however many streams the per-module search would use: search_streams = 1 selects ONE
+            # group call, the launch order bench.py's roofline records describe)
+            concurrent = batching and not self.sequential and (n_streams > 1 or grouped) and _dev_of(self.net).type == "cuda" and len(grp) > 1
             # The search streams wait for the capture ON THE DEVICE (wait_stream): the host does not -- its threads prepare and
             # enqueue the first searches while the last capture passes still run (a host synchronisation here left the GPU idle
             # for ~2 ms per calibration: thread start, descriptors, workspace planning).  The capture / search split of the
@@ -884,13 +957,12 @@ class HessianQuantCalibrator(QuantCalibrator):
             elif torch.cuda.is_available():
                 torch.cuda.synchronize()
             t2 = time.time()
-            grouped = getattr(self, "search_grouped", None)
-            if grouped is None:
-                grouped = os.environ.get("P4V_GROUPED", "1") != "0"
-            if concurrent and grouped:
-                self._search_grouped(grp, getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "1")))
-            elif concurrent:
-                self._search_concurrent(grp, n_streams)
+            if concurrent:
+                if grouped:
+                    calls = 1 if n_streams == 1 else (getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "3")))
+                    self._search_grouped(grp, calls)
+                else:
+                    self._search_concurrent(grp, n_streams)
                 if cap_done is not None:            # (everything is synchronised now) when the capture really ended
                     ref = torch.cuda.Event(enable_timing=True)
                     ref.record(torch.cuda.current_stream(_dev_of(self.net)))

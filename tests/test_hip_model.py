@@ -412,6 +412,56 @@ def test_graph_capture_equals_eager_capture(model, side, kw):
             assert a.shape == b.shape and torch.equal(a, b), n
 
 
+def test_fresh_networks_replay_the_graph_of_their_architecture_with_their_own_weights(monkeypatch):
+    """Round 6: the sub-batch passes of a FRESH network object replay the HIP graph recorded for its architecture on a private copy
+    (utils/quant_calib.py, _arch_shadow) after its parameters have been copied into the graph's storage.  Three networks of one
+    architecture with DIFFERENT weights: the third one's captured tensors -- taken through the architecture's graph, which was
+    recorded with the second one's weights -- are bit-identical to its own eager capture."""
+    import contextlib, io
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+
+    class L:
+        def __init__(self, x):
+            self.x, self.batch_size = x, x.shape[0]
+
+        def __iter__(self):
+            yield self.x, None
+
+    dev = torch.device("cuda:0")
+    x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+    kw = dict(img_size=64, patch_size=16, embed_dim=96, depth=2, num_heads=3, num_classes=10)
+    HessianQuantCalibrator._ARCH.clear()
+
+    def capture(seed, arch_graphs):
+        monkeypatch.setenv("P4V_ARCH_GRAPHS", "1" if arch_graphs else "0")
+        net = models.get_net("vit_tiny_patch16_224", seed=seed, device=dev, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+        cal = HessianQuantCalibrator(net, wrapped, L(x), sequential=False, batch_size=2)
+        sm = cal._raw_pred_softmax()
+        cal._capture(list(wrapped), sm, True)
+        torch.cuda.synchronize()
+        cap = {}
+        for n, m in wrapped.items():
+            ri = m.raw_input if isinstance(m.raw_input, list) else [m.raw_input]
+            cap[n] = [t.clone() for t in ri] + [m.raw_out.clone(), m.raw_grad.clone()]
+        return cap, bool(net.__dict__.get("_p4v_capture_graphs"))
+
+    capture(1, True)                                  # first sighting of the architecture: eager
+    assert not any("net" in r and r["net"] is not None for r in HessianQuantCalibrator._ARCH.values())
+    capture(2, True)                                  # second sighting: the shadow and its graph are built (weights of seed 2)
+    assert any(r.get("lanes") for r in HessianQuantCalibrator._ARCH.values())
+    got, own = capture(3, True)                       # a third network, other weights, through the architecture's graph
+    assert not own                                    # (no graph of its own was recorded)
+    want, _ = capture(3, False)                       # its own eager passes
+    for n in want:
+        for a, b in zip(got[n], want[n]):
+            assert a.shape == b.shape and torch.equal(a, b), n
+    HessianQuantCalibrator._ARCH.clear()
+
+
 def test_int8_quant_forward_matches_fake_quant_forward():
     """Row f-2: quant_forward on the int8 MFMA path (integer accumulation, scales in the epilogue) against the
     reference's fake-quant fp32 formulation, for every wrapped module of the calibrated mini ViT.

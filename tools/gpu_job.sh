@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parametrised GPU-box job (replaces the per-call scripts of rounds 1-2).  Usage, from the repo root on the box:
 #   tools/gpu_job.sh <tag> <step> [<step> ...]        results under gpurun_out/<tag>/
-# steps: tests | tests:<pytest -k expr> | bench[:steps] | kstats1 | kstats3 | prodprof[:stem] | pmc:<layer> | layer:<bench_layer args> |
+# steps: tests | tests:<pytest -k expr> | bench[:steps] | kstats1 | kstats3 | kstatsg[:calls] | prodprof[:stem] | pmc:<layer> | layer:<bench_layer args> |
 #        forward | modules:<net> | sh:<command>
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp
 TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -19,6 +19,12 @@ for step in "$@"; do
              python tools/kstats_db.py "$O/prof$n/*.db" > $O/bench_${n}stream_kernel_stats.txt
              [ $n != 1 ] && python tools/kstats_db.py --busy "$O/prof$n/*.db" >> $O/bench_${n}stream_kernel_stats.txt
              head -24 $O/bench_${n}stream_kernel_stats.txt | cut -c1-180; rm -rf $O/prof$n ;;
+    kstatsg) # kernel statistics of the grouped search with <arg> concurrent group calls
+             n=${arg:-1}
+             ( cd /tmp && P4V_GROUP_CALLS=$n timeout 600 rocprofv3 --kernel-trace -d $O/profg$n -o b -- python $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1 )
+             KSTATS_TOP=45 python tools/kstats_db.py "$O/profg$n/*.db" > $O/bench_group${n}_kernel_stats.txt
+             python tools/kstats_db.py --busy "$O/profg$n/*.db" >> $O/bench_group${n}_kernel_stats.txt
+             head -52 $O/bench_group${n}_kernel_stats.txt | cut -c1-170; tail -8 $O/bench_group${n}_kernel_stats.txt | cut -c1-200; rm -rf $O/profg$n ;;
     prodprof) # profile of the production step, joined with the engine's launch records (tools/prof_join.py); arg = output stem
              stem=${arg:-r5_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
              ( cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $T/trace -o t -- python $R/bench.py --profile --steps 3 --warmup 2 --dump-launches $T/launches.json > $O/prodprof_bench.json 2> $O/prodprof_bench.err )
