@@ -290,3 +290,7 @@ class QuantileQuantConv2d(MinMaxQuantConv2d):
         self.a_interval = (self._quantile(x.abs(), self.a_quantile) / (self.a_qmax - 0.5)).detach()
         self.calibrated = True
         return self.quant_forward(x)
+
+
+# (utils/quant_calib.py::_groupable, see quant_layers/linear.py)
+_BatchingConv.calibration_step2._p4v_grouped = True

@@ -259,3 +259,8 @@ class PostGeluPTQSLBatchingQuantLinear(PTQSLBatchingQuantLinear):
         x_pos = fake_quant(xg, self.a_interval, 0, self.a_qmax - 1)
         x_neg = fake_quant(xg, self.a_neg_interval, -self.a_qmax, 0)
         return (x_pos + x_neg).reshape(x.shape)
+
+
+# (utils/quant_calib.py::_groupable: the calibrator may run these modules' searches as one p4v_calibrate_group call -- only while
+# calibration_step2 is THIS method, not a user's override)
+PTQSLBatchingQuantLinear.calibration_step2._p4v_grouped = True

@@ -340,3 +340,8 @@ class SoSPTQSLBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
     def calibration_step2(self):
         """Reference matmul.py:633-644 (caches are deleted at the end, :644)."""
         self.calibration_install(engine.run_job(self.calibration_job()))
+
+
+# (utils/quant_calib.py::_groupable, see quant_layers/linear.py)
+PTQSLBatchingQuantMatMul.calibration_step2._p4v_grouped = True
+SoSPTQSLBatchingQuantMatMul.calibration_step2._p4v_grouped = True

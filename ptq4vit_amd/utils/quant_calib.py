@@ -150,6 +150,15 @@ def _same_dense_block(cache, t):
     return span == t.numel() and t.stride(0) == max(t.stride())
 
 
+def _groupable(m):
+    """May the calibrator replace this module's calibration_step2() by calibration_job() / p4v_calibrate_group / calibration_install()?
+    Only while calibration_step2 IS the library's own method: an instance attribute or a subclass override (a user's hook around
+    the search, a test's recorder) is called as the reference calls it, alone."""
+    if "calibration_step2" in m.__dict__ or not hasattr(m, "calibration_job"):
+        return False
+    return getattr(getattr(type(m), "calibration_step2", None), "_p4v_grouped", False)
+
+
 class QuantCalibrator:
     """Reference quant_calib.py:9-171: forward-mode calibration (calibration_step1 / calibration_step2(x))."""
 
@@ -766,7 +775,7 @@ class HessianQuantCalibrator(QuantCalibrator):
                         while todo:
                             n = todo[0]
                             m = self.wrapped_modules[n]
-                            if not hasattr(m, "calibration_job"):        # a class without the two-step protocol: alone
+                            if not _groupable(m):        # calibration_step2 overridden / a class without the two-step protocol: alone
                                 if batch:
                                     break
                                 todo.pop(0)
@@ -797,11 +806,14 @@ class HessianQuantCalibrator(QuantCalibrator):
             except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=worker, args=(s, p)) for s, p in zip(streams, parts)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        if n_calls == 1:
+            worker(streams[0], parts[0])          # on the calling thread (p4v_stats_* are per calling thread: bench.py's roofline step)
+        else:
+            threads = [threading.Thread(target=worker, args=(s, p)) for s, p in zip(streams, parts)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
         for s in streams:
             main.wait_stream(s)
         torch.cuda.synchronize(dev)
