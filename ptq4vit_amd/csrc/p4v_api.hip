@@ -168,7 +168,9 @@ struct QOp {
     void* dst = nullptr; const void* src = nullptr; size_t bytes = 0; int value = 0;
     size_t dpitch = 0, spitch = 0, width = 0, height = 0;
     std::vector<char> payload;      // H2D: the host data (the caller's buffer may be gone when the operation is issued)
-    bool timed = false; StatInfo si{};
+    bool timed = false;             // record the launch (bench.py roofline)
+    bool heavy = false;             // a sweep: the issuer holds it back until no light operation is left at any member's head, so that
+    StatInfo si{};                  // members that lag a few small launches behind join the same grouped launch
 };
 inline hipError_t lds_attr(const void* fn, unsigned lds, std::atomic<bool>& done) {
     if (lds <= 48 * 1024 || done.load(std::memory_order_acquire)) return hipSuccess;
@@ -245,6 +247,8 @@ struct Group {
     bool stat_on = false;
     std::vector<StatRec>* stat_recs = nullptr;      // the CALLING thread's launch records: one per grouped launch
     long n_ops = 0, n_launches = 0, n_rounds = 0;
+    int last_par[16] = {};               // members in the last grouped launch of each sweep family (StatInfo.kind): what the members'
+                                         // launch heuristics plan for (written by the issuer while every member is blocked)
     int issue_kernels(std::vector<const QOp*>& ops);
     int issue_round();                   // (mu held, every member blocked)
     int sync(int slot);
@@ -284,6 +288,7 @@ int issue_plain(hipStream_t st, const QOp& op) {
 int Group::issue_kernels(std::vector<const QOp*>& ops) {
     const KernelDesc* kd = ops[0]->kd;
     const int total = (int)ops.size();
+    if (ops[0]->heavy && ops[0]->si.kind >= 0 && ops[0]->si.kind < 16) last_par[ops[0]->si.kind] = total;
     if (!kd->many || total == 1) {
         for (const QOp* op : ops) { CHK(enqueue_now(st, *op, op->timed && stat_recs, stat_recs)); ++n_launches; }
         return 0;
@@ -317,16 +322,19 @@ int Group::issue_round() {
     g_launch_cnt[2].fetch_add(1, std::memory_order_relaxed);
     std::vector<const QOp*> bucket;
     for (;;) {
-        // the most common head operation over the members (kernel entry point + block shape; plain operations go one by one)
+        // the most common head operation over the members (kernel entry point + block shape; plain operations go one by one);
+        // light operations first: a sweep waits until every member that can still reach one has
         int best = -1, best_n = 0;
+        bool best_heavy = true;
         for (int i = 0; i < n; ++i) {
             if (q[i].empty()) continue;
             const QOp& h = q[i].front();
             if (h.type != QOp::KERNEL) { best = i; best_n = 0; break; }        // fills / copies: at once, in member order
+            if (h.heavy && !best_heavy) continue;
             int cnt = 0;
             for (int j = i; j < n; ++j)
                 if (!q[j].empty()) { const QOp& o = q[j].front(); cnt += o.type == QOp::KERNEL && o.kd == h.kd && o.block.x == h.block.x && o.block.y == h.block.y && o.block.z == h.block.z; }
-            if (cnt > best_n) { best = i; best_n = cnt; }
+            if ((best_heavy && !h.heavy) || cnt > best_n) { best = i; best_n = cnt; best_heavy = h.heavy; }
         }
         if (best < 0) break;
         const QOp& h = q[best].front();
@@ -390,10 +398,10 @@ template <typename P> int enqueue(Ctx& c, const KernelDesc* kd, dim3 grid, dim3 
     op.type = QOp::KERNEL; op.kd = kd; op.grid = grid; op.block = block; op.lds = (unsigned)lds;
     static_assert(sizeof(P) <= QOP_PARAM_BYTES, "parameter block too large");
     std::memcpy(op.params, &p, sizeof(P));
-    if (si) { op.timed = true; op.si = *si; }
+    if (si) { op.heavy = true; op.timed = g_stat_on; op.si = *si; }
     g_launch_cnt[0].fetch_add(1, std::memory_order_relaxed);
     if (c.grp) { c.grp->q[c.slot].push_back(std::move(op)); return 0; }
-    return enqueue_now(c.st, op, si != nullptr, &g_stat_recs);
+    return enqueue_now(c.st, op, op.timed, &g_stat_recs);
 }
 int q_fill(Ctx& c, void* dst, int value, size_t bytes) {        // (k_fill_bytes: a kernel of this library, so that fills join the grouped launches)
     if (c.dry || bytes == 0) return 0;
@@ -553,6 +561,15 @@ template <typename T> int launch_pack(Ctx& c, const PackParams& p_) {
     return enqueue(c, KERN_T(PackParams, k_pack, T), dim3(blocks, cdiv(p.C, PACK_CG)), dim3(256), 0, p);
 }
 
+// (inside a group the lock-step members share the chip: each plans for its share of the workgroup slots)
+// `kind`: the sweep family (StatInfo.kind) -- what the group's last launch of that family held is the better estimate of how many
+// members are in lock step than the number of same-shaped members
+inline int lockstep(const Ctx& c, int kind) {
+    if (!c.grp) return 1;
+    const int seen = (kind >= 0 && kind < 16) ? c.grp->last_par[kind] : 0;
+    return std::max(1, seen > 0 ? seen : c.par);
+}
+inline int cu_slots(const Ctx& c, int slots, int kind) { return std::max(8, slots / lockstep(c, kind)); }
 // epilogue dispatch of a kernel family: E = the metric's epilogue as a template argument
 #define P4V_EPI4(epi, X)                                   \
     switch (epi) {                                         \
@@ -643,7 +660,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 #endif
     const StatInfo si = stat_info(5, (double)p.stiles * 128 * (double)p.ttiles * 128 * (double)p.ldk * (p.c1 - p.c0), g_alg_macs_cand * (p.c1 - p.c0),
                                   (int)grid.x, (int)grid.z, g_alg_bytes);
-    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    const StatInfo* sp = &si;
     if (pair) { P4V_EPI4(epi, CHK(enqueue(c, KERN_T(Sweep3Params, k_sweep5, E), grid, block, lds, p, sp)); break) }
     else { P4V_EPI4(epi, CHK(enqueue(c, KERN_T(Sweep3Params, k_sweep4, E), grid, block, lds, p, sp)); break) }
 #ifdef P4V_TRACE
@@ -678,7 +695,7 @@ int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups, int nc_mo
     const double P = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
     auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
     int q_best = 0;
-    if (rem > 0 && full > 0 && !(g_variant & 16384) && c.par <= 1) {
+    if (rem > 0 && full > 0 && !(g_variant & 16384) && lockstep(c, 2) <= 1) {
         double best = waves((long)tiles * cgroups) * (P + cdiv(nc, cgroups) * t_c) * 0.97;   // the uniform plan
         for (int q = 1; q <= std::min(nc, 12); ++q) {
             const double t = waves(full) * (P + nc * t_c) + waves((long)rem * q) * (P + cdiv(nc, q) * t_c);
@@ -716,7 +733,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
     const StatInfo si = stat_info(2, share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0),
                                   share * g_alg_macs_cand * (p.c1 - p.c0), (int)grid.x, (int)grid.z, share * g_alg_bytes);
-    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    const StatInfo* sp = &si;
     int r;
 #define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds, sp) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds, sp))
     switch (p.ktiles) {
@@ -797,7 +814,7 @@ int launch_sweep7(Ctx& c, const Sweep7Params& p, int twin, int epi, int cgroups)
     // (twin: 128 samples x 2 planes)
     const StatInfo si = stat_info(twin ? 4 : 3, (double)p.rtiles * 256 * (double)p.ctiles * 256 * (double)p.ldk * nc, g_alg_macs_cand * nc,
                                   (int)grid.x, (int)grid.z, g_alg_bytes);
-    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    const StatInfo* sp = &si;
     return twin == 2 ? launch_sweep7_epi<2>(c, q, epi, grid, lds, sp) : twin ? launch_sweep7_epi<1>(c, q, epi, grid, lds, sp) : launch_sweep7_epi<0>(c, q, epi, grid, lds, sp);
 }
 
@@ -810,7 +827,7 @@ int launch_sweep(Ctx& c, const SweepParams& p, bool i8, bool twin, int epi, bool
     const StatInfo si = stat_info(kind, (double)p.mtiles * SW_BM * (double)p.ntiles * SW_BN * kelems * p.Z * (p.c1 - p.c0) * (twin ? 2 : 1),
                                   g_alg_macs_cand * (p.c1 - p.c0),
                                   (fast && p.bound) ? p.mtiles * p.ntiles * 2 : (fast && p.halves > 0) ? p.halves : p.mtiles * p.ntiles, cgroups, g_alg_bytes);
-    const StatInfo* sp = g_stat_on ? &si : nullptr;
+    const StatInfo* sp = &si;
     if (fast && p.bound) {
         const dim3 grid(p.mtiles * p.ntiles * 2), block(256);      // 128 x 64 workgroup tiles
         P4V_EPI4(epi, return enqueue(c, KERN_T(SweepParams, k_bound, E), grid, block, 0, p, sp))
@@ -936,8 +953,6 @@ static const long PLANE_BUDGET_DEFAULT = 6L << 30;  // bytes of candidate-expand
 // 256 CUs / evens out the last round) but every workgroup pays its prologue (raw_out/raw_grad tile, stationary
 // operand) again.  Cost model in microseconds, constants measured on MI355X (profiles/): minimise
 // rounds * (prologue + candidates_per_group * ktiles * tile_time).
-// (inside a group the lock-step members share the chip: each plans for its share of the workgroup slots)
-inline int cu_slots(const Ctx& c, int slots) { return std::max(8, slots / std::max(1, c.par)); }
 int choose_cgroups(long wgs, int ncand, int ktiles, int slots, double prologue_us, double tile_us, int cg_max = 25) {
     int best = 1;
     double best_t = 1e30;
@@ -1205,7 +1220,7 @@ int run_pass(Ctx& c, Pass& ps) {
                         qq.tile0 = tt0 * q.stiles; qq.ntile = (tt1 - tt0) * q.stiles;
                         const int ncr = std::max(1, hi - lo);
                         g_exec_frac = fsum / ((double)(j1 - j) * nc);
-                        int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, cu_slots(c, 256), P6, 0.14);
+                        int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, cu_slots(c, 256, 2), P6, 0.14);
                         if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(ncr, tune(TUNE_CG6)));
                         if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 open blocks [%d, %d): tiles %d x %d ktiles %d cand %d -> cgroups %d\n", j, j1, q.stiles, tt1 - tt0, q.ktiles, ncr, cg6);
                         if (hi > lo && qq.ntile > 0) CHK(launch_sweep6(c, qq, ps.epi, cg6, ncr));
@@ -1213,14 +1228,14 @@ int run_pass(Ctx& c, Pass& ps) {
                     }
                     continue;
                 }
-                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, cu_slots(c, 256), P6, 0.14);
+                int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, cu_slots(c, 256, 2), P6, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d (%d known) -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, nc_known, cg6);
                 CHK(launch_sweep6(c, q, ps.epi, cg6, known ? nc_known : 0));
                 continue;
             }
             const long wgs = (long)q.stiles * q.ttiles;
-            const int cgroups = choose_cgroups(wgs, nc, q.ktiles, cu_slots(c, 256), 30.0, 0.15);
+            const int cgroups = choose_cgroups(wgs, nc, q.ktiles, cu_slots(c, 256, 5), 30.0, 0.15);
             CHK(launch_sweep4(c, q, ps.epi, cgroups, pairs));
             continue;
         }
@@ -1241,7 +1256,7 @@ int run_pass(Ctx& c, Pass& ps) {
             // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
             // (up to one candidate per workgroup: stage A of a pruned pass is 3 tiles x 100 candidates -- with the 25 groups of the
             // other sweeps 75 workgroups on 256 CUs, 140-160 us per launch)
-            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, cu_slots(c, 256), 6.0, 0.62, 100);
+            int cg7 = choose_cgroups((long)q.rtiles * q.ctiles, nc, q.ktiles + 3, cu_slots(c, 256, ps.twin ? 4 : 3), 6.0, 0.62, 100);
             if (tune(TUNE_CG7) > 0) cg7 = std::max(1, std::min(nc, tune(TUNE_CG7)));
             q.order = tune(TUNE_ORDER7) > 0 ? tune(TUNE_ORDER7) - 1 : 1;
             if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep7 tiles %d x %d ktiles %d cand %d twin %d -> cgroups %d\n", q.rtiles, q.ctiles, q.ktiles, nc, (int)ps.twin, cg7);
@@ -1280,12 +1295,12 @@ int run_pass(Ctx& c, Pass& ps) {
             // generic sweep: 2 workgroups per CU; per k-tile step ~2.6 us with fp32 operands (8 x mfma_f32_32x32x2 per
             // 32x32 block), ~1.6 us on the int8 grid (measured on the patch-embedding search)
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
-            cgroups = choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, 512), 20.0, ps.i8 ? 1.6 : 2.6);
+            cgroups = choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, 512, ps.i8 ? 0 : 1), 20.0, ps.i8 ? 1.6 : 2.6);
         }
         if (fast || fast_cos) {
             const long wgs = (long)sp.mtiles * sp.ntiles * ps.Z;
             cgroups = (g_variant & 128) ? (int)std::max<long>(1, std::min<long>(std::min(nc, 10), (2048 + wgs - 1) / wgs))
-                                        : choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, ps.twin ? 256 : 512), ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
+                                        : choose_cgroups(wgs, nc, sp.ktiles, cu_slots(c, ps.twin ? 256 : 512, 9), ps.twin ? 40.0 : 25.0, ps.twin ? 0.45 : 0.40);
         }
         sp.bound = bound ? 1 : 0;
         if (bound) sp.dbg = tune(TUNE_B1_PATH) >= 16 ? (tune(TUNE_B1_PATH) >> 4) : 0;   // (tuning 12 = 16 / 32: k_bound timing ablations)
@@ -1297,7 +1312,7 @@ int run_pass(Ctx& c, Pass& ps) {
                 sp.rows_p_stream = sp.a_cs == 0 ? Np : Mp;
                 sp.p_zs = (long)h9 * SW9_NW; sp.p_cs = sp.p_zs * ps.Z;
                 nine_halves = h9;
-                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, cu_slots(c, SW9_NW == 4 ? 512 : 256), 12.0, 0.9);
+                cgroups = choose_cgroups((long)h9 * ps.Z, nc, 1, cu_slots(c, SW9_NW == 4 ? 512 : 256, 6), 12.0, 0.9);
             }
         }
         if (fast && !ps.store_out) {
@@ -1529,18 +1544,18 @@ int run_slice_b(Ctx& c, Pass& a, float* SA) {
         // k_slice_b: >= 1024 workgroups, >= 4 candidates each (one per wave); k_slice_b2: every wave runs every candidate of its
         // workgroup, the prologue (B -> registers) is paid per workgroup: >= 512 workgroups of >= 10 candidates
         // (k_slice_b2 keeps 3 workgroups per CU -- 2 with the twin's second accumulator set, 250 registers: whole rounds of 256 x that)
-        const int slots = std::max(8, 256 * (a.twin ? 2 : 3) / std::max(1, c.par));
-        int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(std::max(1, 512 / std::max(1, c.par)), Z)));
+        const int slots = std::max(8, 256 * (a.twin ? 2 : 3) / lockstep(c, 13));
+        int g2 = std::max(1, std::min(a.eq_n / 10, cdiv(std::max(1, 512 / lockstep(c, 13)), Z)));
         // no mostly-empty last round -- where the rounds are few (ViT: 384 batch entries; with tens of thousands of them, Swin's
         // windows, the tail does not matter and more groups only repeat the prologue)
         while ((long)Z * g2 < 4L * slots && g2 < a.eq_n / 10 && ((long)Z * g2) % slots != 0 && ((long)Z * g2) % slots < slots * 3 / 4) ++g2;
         if (tune(TUNE_CG2) > 0) g2 = std::max(1, std::min(a.eq_n, tune(TUNE_CG2)));
-        const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / std::max(1, c.par)), Z)));
+        const int groups = v2 ? g2 : std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / lockstep(c, 13)), Z)));
         const dim3 grid(Z, groups), block(256);
         const float qbias = (v2 && b.lo == -128 && b.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c) : 0.0f;   // 12 = 11: quant_fast1 in k_slice_b2 (A/B)
         const StatInfo si{13, 16.0 * nb * 16 * Kp * Z * a.eq_n * (a.twin ? 2 : 1), (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n, g_stage, Z, groups,
                           4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z};
-        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        const StatInfo* sp = &si;
         int r_ = 0;
         if (v2) {
             SliceB2Params kp2{kp, qbias};
@@ -1601,11 +1616,11 @@ int run_slice_a(Ctx& c, Pass& a, float* SA) {
         kp.O = a.O; kp.Wt = a.G ? a.G : a.O; kp.wt_mode = a.wt_mode;
         kp.Z = Z; kp.M = a.Mrows; kp.K = a.K; kp.N = a.Ncols; kp.C = a.eq_n; kp.part = part;
         kp.qbias = (r.lo == -128 && r.hi == 127 && tune(TUNE_B1_PATH) != 11) ? cvt_bias(c) : 0.0f;
-        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / std::max(1, c.par)), Z)));
+        const int groups = std::max(1, std::min(a.eq_n / 4, cdiv(std::max(1, 1024 / lockstep(c, 14)), Z)));
         const dim3 grid(Z, groups), block(256);
         const StatInfo si{14, 16.0 * nb * 16 * 64 * Z * a.eq_n, (double)a.Mrows * a.Ncols * a.K * Z * a.eq_n, g_stage, Z, groups,
                           4.0 * ((double)a.Mrows * a.K * Z + (double)a.Ncols * a.K * Z) + (a.G ? 8.0 : 4.0) * (double)a.Mrows * a.Ncols * Z};
-        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        const StatInfo* sp = &si;
         P4V_EPI4(a.epi, CHK(enqueue(c, KERN_T(SliceAParams, k_slice_a, 13, E), grid, block, 0, kp, sp)); break)
     }
     FinishParams fp{part, (long)Z, 1L, 1, 1, Z, 1, a.eq_n, a.j_mode, std::max(1, a.j_div), a.nj, a.norm, SA, nullptr};
@@ -1873,7 +1888,7 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
         }
         const StatInfo si{11, frac * (double)kp.Z * kp.halves * 128 * (2.0 * KS) * 64 * kp.C, frac * (double)kp.Z * kp.M * kp.K * kp.N * kp.C, g_stage, kp.halves, kp.Z,
                           4.0 * ((double)kp.Z * kp.M * kp.K + (double)kp.Z * kp.K * kp.N) + 8.0 * (double)kp.Z * kp.M * kp.N};
-        const StatInfo* sp = g_stat_on ? &si : nullptr;
+        const StatInfo* sp = &si;
         if (KS == 32) CHK(launch_sos_split_ks<32>(c, kp, j.epi, sp));
         else if (KS == 72) CHK(launch_sos_split_ks<72>(c, kp, j.epi, sp));
         else CHK(launch_sos_split_ks<100>(c, kp, j.epi, sp));

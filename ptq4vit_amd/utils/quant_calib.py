@@ -409,11 +409,15 @@ class HessianQuantCalibrator(QuantCalibrator):
             rec.update(net=net2, mods=mods2, lanes=[])
         if rec.get("net") is None:
             return None
+        self._sync_shadow(rec)
+        return rec
+
+    def _sync_shadow(self, rec):
+        """This network's parameter / buffer VALUES into the storage the architecture's graphs replay on."""
         src = [p.data for p in self.net.parameters()] + [b for b in self.net.buffers()]
         dst = [p.data for p in rec["net"].parameters()] + [b for b in rec["net"].buffers()]
         with torch.no_grad():
             torch._foreach_copy_(dst, src)
-        return rec
 
     def _build_graph(self, dev, bs, inp, raw_pred_softmax, shadow=None):
         """Record ONE sub-batch forward + KL backward with hooks on EVERY wrapped module (so that any group of modules, on
@@ -526,7 +530,11 @@ class HessianQuantCalibrator(QuantCalibrator):
         cache = self.net.__dict__.setdefault("_p4v_capture_graphs", {})
         key = self._graph_key(dev, bs, inp)
         lanes = cache.get(key)
-        shadow = None
+        shadow = self.net.__dict__.get("_p4v_capture_shadow") if lanes is not None else None
+        if shadow is not None and lanes is shadow.get("lanes"):
+            self._sync_shadow(shadow)          # (the graphs are the architecture's: this network's values into their storage, every time)
+        else:
+            shadow = None
         if lanes is None:
             seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
             shadow = self._arch_shadow(dev, bs, inp, build=bool(use_graph or n_sub >= 24 or seen_before))
@@ -539,6 +547,10 @@ class HessianQuantCalibrator(QuantCalibrator):
                         lanes = shadow = None
                     else:
                         lanes.append(entry)
+            if shadow is not None:
+                cache.clear()
+                cache[key] = lanes
+                self.net.__dict__["_p4v_capture_shadow"] = shadow
         if lanes is None:
             seen_before = self.net.__dict__.get("_p4v_calibrations", 0) > 0
             if not (use_graph or n_sub >= 24 or seen_before):

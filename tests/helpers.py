@@ -127,11 +127,14 @@ CAPTURE_TOL = 1.2e-6
 MAX_GRID_STEPS = 1       # a differing interval lies at most this many entries of the candidate table from the reference's
 
 
-def assert_on_candidate_grid(got, ref, mult, what="", tol=GRID_TOL, max_steps=MAX_GRID_STEPS):
+def assert_on_candidate_grid(got, ref, mult, what="", tol=GRID_TOL, max_steps=MAX_GRID_STEPS, ref_scores=None, tie_rtol=TIE_RTOL):
     """Every interval is bit-identical to the reference's, or -- where the search settled on a different (near-tied)
     candidate -- it is another entry of the SAME candidate table: got / ref = mult[a] / mult[b] for some a, b (both are
-    mult[.] * initial interval in fp32) with |a - b| <= max_steps (a near-tie sits next to the maximum of a smooth score curve;
-    a caller that knows better -- flat optima over several entries, shown by the oracle's own table -- passes its bound).
+    mult[.] * initial interval in fp32) with |a - b| <= max_steps: a near-tie sits next to the maximum of a smooth score curve.
+    Further away only where the ORACLE's own table says so: `ref_scores` [candidates][blocks] is the reference's score table of
+    the pass that selected `ref`; the entry `got` corresponds to must be within `tie_rtol` (relative) of that table's maximum --
+    a flat optimum (the cosine metric on a handful of samples ties over many entries).  `max_steps=None`: no bound (callers
+    comparing searches whose INPUTS differ -- tensors captured on other hardware -- say so at the call).
     Returns the number of blocks that differ; nothing else is tolerated."""
     got = np.asarray(got, dtype=np.float64).reshape(-1)
     ref = np.asarray(ref, dtype=np.float64).reshape(-1)
@@ -148,6 +151,17 @@ def assert_on_candidate_grid(got, ref, mult, what="", tol=GRID_TOL, max_steps=MA
         assert rel.min() <= tol, f"{what}: block {j}: interval {g!r} vs reference {r!r} is not on the candidate grid (off by {rel.min():.2e})"
         steps = int(dist[rel <= tol].min())
         record_margin("grid_steps", steps)
+        if max_steps is not None and steps > max_steps and ref_scores is not None:
+            tab = np.asarray(ref_scores, dtype=np.float64)
+            tab = tab.reshape(tab.shape[0], -1)[: m.size]
+            col = tab[:, j if tab.shape[1] > 1 else 0]
+            ri = int(np.argmax(col))
+            mine = int(np.argmin(np.abs(m / m[ri] - g / r)))
+            gap = abs(col[ri] - col[mine]) / max(abs(col[ri]), 1e-300)
+            record_margin("tie_gap_far", gap)
+            assert gap <= tie_rtol, (f"{what}: block {j}: interval {g!r} vs reference {r!r}: {steps} entries of the candidate table apart and not "
+                                     f"a tie by the oracle's own scores (candidate {mine} vs {ri}: gap {gap:.2e} > {tie_rtol})")
+            continue
         assert max_steps is None or steps <= max_steps, (f"{what}: block {j}: interval {g!r} vs reference {r!r}: {steps} entries of the candidate "
                                                          f"table apart (bound {max_steps})")
     record_margin(None, None, {"intervals": int(got.size), "differing_intervals": differ})

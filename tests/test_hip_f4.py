@@ -258,7 +258,10 @@ def test_calibrator_entry_points_vs_reference(run):
                 assert float(got) in [2.0 ** -i for i in range(20)] or a == "A_interval"
                 continue
             total += want.size
-            assert_on_candidate_grid(got, want, mult, f"{n}.{a}", tol=CAPTURE_TOL)
+            # (no step bound: the tensors these searches ran on were captured on THIS GPU, the reference's on its CPU -- raw_grad of a
+            # non-sequential calibration is rounding noise, DESIGN.md s9, so the two searches optimise different objectives; what is
+            # asserted is that every interval is an entry of the candidate table and, below, how many moved)
+            assert_on_candidate_grid(got, want, mult, f"{n}.{a}", tol=CAPTURE_TOL, max_steps=None)
             for x, y in zip(got.reshape(-1), want.reshape(-1)):
                 if x != y:
                     # 0 steps: the SAME candidate of a table whose initial interval differs in the last bits

@@ -18,7 +18,7 @@ from tests.helpers import CAPTURE_TOL, assert_on_candidate_grid, assert_scores_c
 pytestmark = pytest.mark.gpu
 
 
-def _interval_parity(m, name, attr, got, want):
+def _interval_parity(m, name, attr, got, want, ref_scores=None):
     """Bit-identical, or -- a near-tie resolved differently by a different summation order -- another entry of the SAME
     candidate table (exact fp32 ratio); returns (intervals, intervals that moved).  The split-of-softmax split and the
     A_interval derived from it must be equal."""
@@ -27,7 +27,7 @@ def _interval_parity(m, name, attr, got, want):
     assert got.shape == want.shape, (name, attr)
     if attr == "split" or (attr == "A_interval" and getattr(m, "_sos", False)):
         return want.size, int((got != want).sum())
-    moved = assert_on_candidate_grid(got, want, candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n), f"{name}.{attr}")
+    moved = assert_on_candidate_grid(got, want, candidate_grid(m.eq_alpha, m.eq_beta, m.eq_n), f"{name}.{attr}", ref_scores=ref_scores)
     return want.size, moved
 
 
@@ -105,8 +105,13 @@ def _calibrate_and_compare_with_oracle(net, wrapped, images, min_exact=0.95, fla
         else:
             o = MatMulOracle(A_bit=8, B_bit=8, sos=type(m).__name__.startswith("SoS"), **hp)
             res = o.calibration_step2(ri[0], ri[1], ro, rg)
+        # the oracle's LAST table of each operand (a selection further than one entry from the oracle's must be a tie by it)
+        last = {}
+        for tag, tab in o.trace:
+            last[tag[0]] = tab
+        tabs = {"w_interval": last.get("w"), "a_interval": last.get("a"), "A_interval": last.get("A"), "B_interval": last.get("B")}
         for a, want in res.items():
-            k, mv = _interval_parity(m, n, a, getattr(m, a), want)
+            k, mv = _interval_parity(m, n, a, getattr(m, a), want, ref_scores=tabs.get(a))
             if n in flat:
                 continue      # counted separately below: a handful of samples and a flat metric tie to the last bit
             total += k
@@ -211,9 +216,9 @@ def test_deit_tiny_224_baseptq_4_images_vs_the_reference_itself():
             if a not in tabs:                                       # the conv's a_interval: a_bit = 32, min-max of the images
                 np.testing.assert_array_equal(got, want)
                 continue
-            assert_on_candidate_grid(got, want, grid, f"{n}.{a}", tol=CAPTURE_TOL)
             ref_tab = g[f"{key}::scores_{tabs[a]}"].astype(np.float64).reshape(m.eq_n, -1)
             assert ref_tab.shape[1] == want.size, (n, a, ref_tab.shape)
+            assert_on_candidate_grid(got, want, grid, f"{n}.{a}", tol=CAPTURE_TOL, ref_scores=ref_tab, tie_rtol=TIE)
             total += want.size
             for j, (x, y) in enumerate(zip(got, want)):
                 if x == y:
@@ -447,7 +452,7 @@ def test_fresh_networks_replay_the_graph_of_their_architecture_with_their_own_we
         for n, m in wrapped.items():
             ri = m.raw_input if isinstance(m.raw_input, list) else [m.raw_input]
             cap[n] = [t.clone() for t in ri] + [m.raw_out.clone(), m.raw_grad.clone()]
-        return cap, bool(net.__dict__.get("_p4v_capture_graphs"))
+        return cap, bool(net.__dict__.get("_p4v_capture_graphs")) and net.__dict__.get("_p4v_capture_shadow") is None
 
     capture(1, True)                                  # first sighting of the architecture: eager
     assert not any("net" in r and r["net"] is not None for r in HessianQuantCalibrator._ARCH.values())
