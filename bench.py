@@ -573,6 +573,46 @@ def main():
         except torch.cuda.OutOfMemoryError:
             qf = None
 
+    # N > 1: both capture plans measured side by side (three fresh networks each, the fastest; max over ranks), the all_to_all
+    # rate the automatic choice was made on, and what tools/predict_scale.py predicted for this world size from one-GPU
+    # measurements -- a first SCALE run needs no re-run to be interpreted
+    capture_modes = predicted = None
+    if world > 1 and not args.profile:
+        from ptq4vit_amd.utils import shard as _shard
+        capture_modes = {"automatic_choice": getattr(cals[-1], "capture_mode", None), "a2a_gbps_per_peer_measured": _shard.a2a_rate_gbps()}
+        for mode_name, flag in (("replicated", False), ("sharded", True)):
+            best_t, tm_ = None, None
+            for _ in range(3):
+                with quiet:
+                    n_, w_ = fresh_pair()
+                    cal_m = HessianQuantCalibrator(n_, w_, loader, sequential=False, batch_size=4)
+                    cal_m.shard_capture = flag
+                    sync()
+                    t_m = time.time()
+                    cal_m.batching_quant_calib()
+                    sync()
+                    dt_m = time.time() - t_m
+                tt_m = torch.tensor([dt_m], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt_m, op=dist.ReduceOp.MAX)
+                if best_t is None or float(tt_m.item()) < best_t:
+                    best_t, tm_ = float(tt_m.item()), dict(cal_m.timings, capture_mode=cal_m.capture_mode)
+                del n_, w_, cal_m
+            capture_modes[mode_name] = {"step_s": best_t, "layers_per_s": n_mod / best_t, "mode_that_ran": tm_["capture_mode"],
+                                        "capture_s": tm_["capture_s"], "search_s": tm_["search_s"], "exchange_s": tm_.get("exchange_s")}
+        import glob
+        preds = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scale_prediction.json")))
+        if preds:
+            try:
+                pd_ = json.load(open(preds[-1]))
+                for cfg_ in pd_.values():
+                    if cfg_["measured"]["model"] == args.model and cfg_["measured"]["calib_images"] == args.calib and cfg_["measured"]["bits"] == args.bits:
+                        row_ = next((r for r in cfg_["prediction"]["rows"] if r["world"] == world), None)
+                        if row_:
+                            predicted = {"source": os.path.relpath(preds[-1], ROOT), "layers_per_s": row_["layers_per_s"], "step_s": row_["step_s"],
+                                         "capture_mode": row_["capture_mode"]}
+            except Exception:      # noqa: BLE001 - a stale or foreign file must not break the bench line
+                predicted = None
+
     per_rank = None
     if world > 1:
         # first SCALE run diagnosable: every rank's share of the last timed step
@@ -676,7 +716,8 @@ def main():
             # a first SCALE run is self-diagnosing: what the ranks talked through, which capture mode the calibrator chose
             "distributed": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                             "rccl_version": _rccl_version(), "capture_mode": getattr(cals[-1], "capture_mode", None),
-                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                            "capture_modes_measured": capture_modes, "predicted_from_one_gpu": predicted},
             "imbalance": (max(r["search_s"] for r in per_rank) / (sum(r["search_s"] for r in per_rank) / len(per_rank))) if per_rank else None,
             "roofline": roof, "cpu_baseline": cpu,
         }

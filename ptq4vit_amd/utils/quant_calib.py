@@ -925,9 +925,10 @@ class HessianQuantCalibrator(QuantCalibrator):
             env = os.environ.get("P4V_SHARD_CAPTURE", "auto")
             want_shard = True if env == "1" else False if env == "0" else None
         if want_shard is None:
+            # (auto: the cost model with the all_to_all rate MEASURED on this process group -- replicated, north_star's plan,
+            # unless the measurement says the transfer pays; P4V_SHARD_CAPTURE=0 never touches the collective)
             want_shard = (world > 1 and not self.sequential and with_grad and all_sizes is not None
-                          and shard.choose_capture_mode(self.wrapped_modules, all_sizes, world, n_sub) == "sharded"
-                          and shard.all_to_all_available())
+                          and shard.choose_capture_mode(self.wrapped_modules, all_sizes, world, n_sub, shard.a2a_rate_gbps()) == "sharded")
         self.capture_mode = "replicated"
         shard_cap = False
         dev_ = _dev_of(self.net)

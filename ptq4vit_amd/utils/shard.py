@@ -96,67 +96,81 @@ def _pack(module):
     return vals, meta
 
 
-def exchange_intervals(wrapped_modules, owner):
-    """All ranks end up with every module's calibrated intervals.  Two tiny collectives: the per-module slot
-    sizes (all_reduce MAX) so that the layout is fixed, then one all_gather of the interval vector."""
+_HDR = 9 * len(INTERVAL_ATTRS)        # per module: for each attribute (1 + ndim, up to 8 dims), as exactly representable floats
+
+
+def _slot_capacity(module):
+    """Interval scalars a module can produce at most -- from attributes EVERY rank knows before any search (no communication):
+    Linear n_V * n_H + n_a, Conv2d one per output channel + 1, MatMul one per head and operand + the split (the head count is
+    only known to the owner, after its capture: 128 heads unless the module carries `_p4v_interval_slots`; exceeding a slot raises)."""
+    w = getattr(module, "weight", None)
+    if w is None:
+        return int(getattr(module, "_p4v_interval_slots", 2 * 128 + 2))
+    if w.dim() == 4:
+        return int(w.shape[0]) + 2
+    return int(getattr(module, "n_V", 1)) * int(getattr(module, "n_H", 1)) + int(getattr(module, "n_a", 1)) + 2
+
+
+def exchange_intervals(wrapped_modules, owner, install_own=False):
+    """All ranks end up with every module's calibrated intervals: ONE all_gather of a fixed-layout fp32 vector (BASELINE.json's
+    north_star: "RCCL over xGMI only for the final scale gather").  The layout -- per module a header with the attributes'
+    shapes, then `_slot_capacity(module)` value slots -- follows from the module list alone, so no rank has to be told
+    anything before the gather (rounds 2-5 ran an all_reduce of the slot table first).  `install_own`: also install this rank's
+    own modules from the gathered buffer (tools/measure_exchange.py: with one rank there is nobody else's module to install, and
+    installing is most of the host-side cost)."""
     rank, world = rank_world()
     names = list(wrapped_modules)
     dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
-    # slot shapes: 5 attrs x (1 + ndim, up to 8 dims) per module, encoded as ints (0 = absent)
-    # (plain Python lists on the host, ONE tensor each way: element-wise tensor indexing was 6 of the 8 ms this function took)
-    tab = [[[0] * 9 for _ in INTERVAL_ATTRS] for _ in names]
-    packed = {}
-    for i, n in enumerate(names):
+    base, total = {}, 0
+    for n in names:
+        base[n] = total
+        total += _HDR + _slot_capacity(wrapped_modules[n])
+    import numpy as np
+    host = np.zeros(total, dtype=np.float32)  # (assembled on the host, ONE tensor each way: element-wise tensor indexing is slow)
+    pieces, where = [], []
+    for n in names:
         if owner[n] != rank:
             continue
         vals, meta = _pack(wrapped_modules[n])
-        packed[n] = vals
-        for (a, shp) in meta:
-            row = tab[i][INTERVAL_ATTRS.index(a)]
-            row[0] = 1 + len(shp)
-            for k, s in enumerate(shp[:8]):
-                row[1 + k] = int(s)
-    shape_tab = torch.tensor(tab, dtype=torch.int64).to(dev)
-    dist.all_reduce(shape_tab, op=dist.ReduceOp.MAX)
-    tab = shape_tab.cpu().tolist()
-    offsets, total = {}, 0
-    for i, n in enumerate(names):
-        for j, a in enumerate(INTERVAL_ATTRS):
-            nd = tab[i][j][0]
-            if nd == 0:
-                continue
-            shp = tuple(tab[i][j][1:nd])
-            numel = 1
-            for s in shp:
-                numel *= s
-            offsets[(n, a)] = (total, numel, shp)
-            total += numel
-    vec = torch.zeros(total, dtype=torch.float32, device=dev)
-    mine, where = [], []                       # this rank's values and their positions: one cat + one index_copy_
-    for n, vals in packed.items():
-        k = 0
-        for a in INTERVAL_ATTRS:
-            if (n, a) in offsets and getattr(wrapped_modules[n], a, None) is not None:
-                off, numel, _ = offsets[(n, a)]
-                mine.append(vals[k].to(dev).reshape(-1)[:numel])
-                where.append(torch.arange(off, off + numel))
-                k += 1
-    if mine:
-        vec.index_copy_(0, torch.cat(where).to(dev), torch.cat(mine))
+        off, used = base[n] + _HDR, 0
+        for (a, shp), v in zip(meta, vals):
+            if len(shp) > 8:
+                raise ValueError(f"{n}.{a}: interval tensors of more than 8 dimensions are not exchanged")
+            h = base[n] + 9 * INTERVAL_ATTRS.index(a)
+            host[h] = float(1 + len(shp))
+            for k, d in enumerate(shp):
+                host[h + 1 + k] = float(int(d))
+            if used + v.numel() > _slot_capacity(wrapped_modules[n]):
+                raise ValueError(f"{n}: {used + v.numel()} interval scalars exceed the exchange slot of {_slot_capacity(wrapped_modules[n])}")
+            pieces.append(v.to(dev).reshape(-1))
+            where.append((off + used, v.numel()))
+            used += v.numel()
+    vec = torch.from_numpy(host).to(dev)
+    if pieces:
+        idx = torch.cat([torch.arange(o, o + k) for o, k in where]).to(dev)
+        vec.index_copy_(0, idx, torch.cat(pieces))
     parts = [torch.empty(total, dtype=torch.float32, device=dev) for _ in range(world)]
-    dist.all_gather(parts, vec)        # one collective: a few KB per rank (RCCL over xGMI on the GPU box, gloo in tests)
+    dist.all_gather(parts, vec)        # THE collective: ~100 KB per rank (RCCL over xGMI on the GPU box, gloo in tests)
     gathered = torch.stack(parts)
+    hdr = gathered.cpu() if gathered.device.type != "cpu" else gathered      # headers are read on the host (a few thousand ints)
     for n in names:
         r = owner[n]
-        if r == rank:
+        if r == rank and not install_own:
             continue
         m = wrapped_modules[n]
         mdev = next((p.device for p in m.parameters()), dev) if hasattr(m, "parameters") else dev
-        vals = {}
-        for a in INTERVAL_ATTRS:
-            if (n, a) in offsets:
-                off, numel, shp = offsets[(n, a)]
-                vals[a] = gathered[r, off:off + numel].reshape(shp)
+        row = hdr[r, base[n]: base[n] + _HDR].tolist()
+        vals, off = {}, base[n] + _HDR
+        for j, a in enumerate(INTERVAL_ATTRS):
+            nd = int(row[9 * j])
+            if nd == 0:
+                continue
+            shp = tuple(int(d) for d in row[9 * j + 1: 9 * j + nd])
+            numel = 1
+            for d in shp:
+                numel *= d
+            vals[a] = gathered[r, off: off + numel].reshape(shp)
+            off += numel
         # the state the owner's calibration_step2 left behind (utils/intervals.py); views of `gathered`, which belongs to this
         # call alone: no copy kernel per attribute (74 modules x 2 attributes of tiny launches were most of the exchange's time)
         install_intervals(m, vals, mdev, clone=(gathered.device != torch.device(mdev)))
@@ -287,13 +301,16 @@ def capture_cost_ms(wrapped_modules, sizes):
     return 2.0 * macs / 21.5e9
 
 
-def choose_capture_mode(wrapped_modules, sizes, world, n_sub, gb_per_s_per_peer=40.0):
+def choose_capture_mode(wrapped_modules, sizes, world, n_sub, gb_per_s_per_peer=None):
     """"sharded" when running 1/world of the capture passes per rank and moving the pieces to the module owners is predicted
-    to beat every rank running all passes, else "replicated".  Every input is the same on every rank (module list, captured
-    sizes from the shape probe, world size), so all ranks take the same branch -- required: the sharded path is a collective.
-    xGMI is point to point: a GPU receives from its world - 1 peers over as many links at once (conservative 40 GB/s
-    each), and pays two extra passes over its share in HBM for packing and reassembly."""
-    if world < 2 or n_sub < 2:
+    to beat every rank running all passes, else "replicated" -- the DEFAULT, BASELINE.json's plan (no data-path collective).
+    `gb_per_s_per_peer`: the all_to_all_single rate per peer MEASURED on this process group (`a2a_rate_gbps()`: a 4 MB-per-peer
+    exchange at the first calibration); None = not measured = "replicated" (rounds 3-5 assumed 40 GB/s and switched to the
+    GB-scale collective at >= 4 ranks on that guess).  Every input is the same on every rank (module list, captured sizes from
+    the shape probe, world size, the rate agreed by all_reduce), so all ranks take the same branch -- required: the sharded path
+    is a collective.  A GPU receives from its world - 1 peers over as many xGMI links at once, and pays two extra passes over its
+    share in HBM for packing and reassembly."""
+    if world < 2 or n_sub < 2 or not gb_per_s_per_peer or gb_per_s_per_peer <= 0:
         return "replicated"
     t_cap = capture_cost_ms(wrapped_modules, sizes)
     share = sum(float(v) for v in sizes.values()) / world              # bytes a rank ends up owning (LPT: about equal)
@@ -301,6 +318,44 @@ def choose_capture_mode(wrapped_modules, sizes, world, n_sub, gb_per_s_per_peer=
     t_xfer = moved / (gb_per_s_per_peer * 1e6 * (world - 1)) + 3.0 * share / 2.0e9 + 2.0      # ms
     passes_saved = 1.0 - float(-(-n_sub // world)) / n_sub
     return "sharded" if t_cap * passes_saved > 1.5 * t_xfer + 5.0 else "replicated"
+
+
+_A2A_RATE = None
+
+
+def a2a_rate_gbps(mb_per_peer=4):
+    """GB/s per peer of all_to_all_single on this process group, measured once (a `mb_per_peer` MB block to every peer, best of
+    three after a warm-up) and AGREED between the ranks (all_reduce MIN: the slowest rank's figure, the same on all of them).
+    0.0 when the collective is unavailable.  Only called when the sharded capture is a candidate (world >= 2, auto mode)."""
+    global _A2A_RATE
+    if _A2A_RATE is not None:
+        return _A2A_RATE
+    import time
+    rank, world = rank_world()
+    if world < 2 or not all_to_all_available():
+        _A2A_RATE = 0.0
+        return _A2A_RATE
+    on_gpu = torch.cuda.is_available() and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    n = mb_per_peer * (1 << 20) // 4
+    send = torch.ones(world * n, dtype=torch.float32, device=dev)
+    recv = torch.empty_like(send)
+    best = float("inf")
+    for i in range(4):
+        if on_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        dist.all_to_all_single(recv, send, output_split_sizes=[n] * world, input_split_sizes=[n] * world)
+        if on_gpu:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if i > 0:
+            best = min(best, dt)
+    rate = torch.tensor([4.0 * n / best / 1e9], dtype=torch.float64, device=dev)
+    dist.all_reduce(rate, op=dist.ReduceOp.MIN)
+    _A2A_RATE = float(rate.item())
+    return _A2A_RATE
 
 
 _A2A_OK = None

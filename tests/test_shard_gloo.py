@@ -383,6 +383,8 @@ def _world8_worker(rank, world, port, q, specs, owner):
         m = _Slot()
         for a in shard.INTERVAL_ATTRS:
             setattr(m, a, None)
+        # (a stand-in has no weight / n_V / n_a to size its exchange slot from: what the real module classes derive from those)
+        m._p4v_interval_slots = 2 + sum(int(torch.tensor(shp).prod()) if shp else 1 for shp in spec.values())
         if owner[n] == rank:
             _fill(n, spec, m)
         mods[n] = m
@@ -424,8 +426,10 @@ def test_world8_lpt_balance_and_interval_exchange_on_vit_base_and_swin_base():
         owner = shard.assign_modules(wrapped, 8, costs)
         load = [sum(costs[n] for n in wrapped if owner[n] == r) for r in range(8)]
         assert min(load) > 0 and max(load) <= 1.10 * (sum(load) / 8), (model, load)
-        assert shard.choose_capture_mode(wrapped, sizes, 8, calib // 4) == "sharded"        # 7/8 of the passes saved > the transfer
-        assert shard.choose_capture_mode(wrapped, sizes, 1, calib // 4) == "replicated"
+        assert shard.choose_capture_mode(wrapped, sizes, 8, calib // 4, 40.0) == "sharded"  # 7/8 of the passes saved > the transfer at 40 GB/s per peer
+        assert shard.choose_capture_mode(wrapped, sizes, 8, calib // 4) == "replicated"      # no measured rate: north_star's plan, no data-path collective
+        assert shard.choose_capture_mode(wrapped, sizes, 8, calib // 4, 0.5) == "replicated"  # a slow fabric: the transfer does not pay
+        assert shard.choose_capture_mode(wrapped, sizes, 1, calib // 4, 40.0) == "replicated"
         # heads of the matmul modules (the interval shapes): from a probe forward
         hooks = [m.register_forward_hook(lambda mod, inp, out: setattr(mod, "_p4v_heads", inp[0].shape[1]))
                  for m in wrapped.values() if not hasattr(m, "weight")]

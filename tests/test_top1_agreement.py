@@ -98,7 +98,7 @@ def test_int8_quant_forward_and_engine_calibration_against_the_reference_top1_on
     hooks = [m.register_forward_hook(lambda mod, inp, out, _n=n: seen.__setitem__(_n, ([t.detach().clone() for t in inp], out.detach().clone())))
              for n, m in wr_c.items()]
     with torch.no_grad():
-        net_c(ev[:4])
+        net_c(ev[:32])                      # (32 images: 6 304 token rows per Linear, 96 (image, head) matrices per attention matmul)
     for h in hooks:
         h.remove()
     worst = (0.0, "")
@@ -135,7 +135,48 @@ def test_int8_quant_forward_and_engine_calibration_against_the_reference_top1_on
           f"run: {100 * float((pred == ref_pred).mean()):.1f} % / {100 * float((mine == ref_pred).mean()):.1f} % of the images "
           f"({100 * float((pred == ref_pred)[wide].mean()):.1f} % / {100 * float((mine == ref_pred)[wide].mean()):.1f} % of the {int(wide.sum())} with a margin above "
           f"5 % of the logit range); raw predictions GPU vs CPU {int((raw_gpu == raw_label).sum())}/1000; modules alone: worst {worst[0]:.1e} ({worst[1]})")
-    assert (raw_gpu == raw_label).mean() >= 0.99
-    assert abs(acc_gpu - acc_ref) <= 0.03 and abs(acc_eng - acc_ref) <= 0.03, (acc_ref, acc_gpu, acc_eng)
-    assert (pred == ref_pred).mean() >= 0.85 and (mine == ref_pred).mean() >= 0.85
-    assert (pred == ref_pred)[wide].mean() >= 0.97 and (mine == ref_pred)[wide].mean() >= 0.97
+    # thresholds = what this measures on MI355X (reference run 93.3 %, this GPU 92.4 % / 92.5 %; same prediction as the reference's
+    # run on 92.4 % / 93.7 % of the images, on 100 % of the wide-margin ones) minus a small slack: a regression of a dozen
+    # images in the int8 forward or in the engine's calibration fails here
+    assert (raw_gpu == raw_label).mean() >= 0.995
+    assert abs(acc_gpu - acc_ref) <= 0.012 and abs(acc_eng - acc_ref) <= 0.012, (acc_ref, acc_gpu, acc_eng)
+    assert (pred == ref_pred).mean() >= 0.915 and (mine == ref_pred).mean() >= 0.925
+    assert (pred == ref_pred)[wide].mean() >= 0.99 and (mine == ref_pred)[wide].mean() >= 0.99
+
+
+@pytest.mark.gpu
+def test_the_int8_path_against_the_fp32_fake_quant_path_on_the_same_gpu_isolates_the_engine():
+    """What the cross-machine comparison above cannot separate: the ENGINE's contribution to a prediction.  Same GPU, same
+    intervals (the reference's), same LayerNorm / softmax / GELU kernels -- the only difference between the two networks is the
+    arithmetic of the wrapped modules: `quant_forward` on the int8 MFMA path (integer accumulation, one fp32 scale) against the
+    reference's fp32 fake-quant formulation F.linear(quant_input(x), *quant_weight_bias()) (reference linear.py:62-67,
+    matmul.py:140-145), which the modules run when `int8_forward` is off.  The integer path is EXACT where the fp32 GEMM of
+    fake-quantised operands rounds, so the two differ by fp32 rounding per module (<= 1e-5 of the output range, test above) and --
+    through the next module's re-quantisation -- by an occasional grid step.  1 000 images: the predictions must agree on
+    >= 99.5 % and the logits to a small fraction of the quantisation error itself."""
+    fx = np.load(EVAL, allow_pickle=False)
+    ev = _eval_images(fx)
+    rng = float(fx["logit_range"])
+    net, wrapped = _net_with_reference_intervals("cuda")
+    for m in wrapped.values():
+        assert getattr(m, "int8_forward", True)
+    q_int = _predict(net, ev, "cuda", 100)
+    for m in wrapped.values():
+        m.int8_forward = False                      # instance attribute: the class default stays
+    q_f32 = _predict(net, ev, "cuda", 100)
+    for m in wrapped.values():
+        m.mode = "raw"
+    raw = _predict(net, ev, "cuda", 100)
+    same = (q_int.argmax(1) == q_f32.argmax(1)).numpy()
+    d = (q_int - q_f32).abs()
+    noise = float((q_f32 - raw).abs().max()) / rng                 # the quantisation error itself, in logit ranges
+    worst, med = float(d.max()) / rng, float(d.median()) / rng
+    top2 = q_f32.topk(2, dim=1).values
+    margin = ((top2[:, 0] - top2[:, 1]) / rng).numpy()
+    flipped_margin = float(margin[~same].max()) if (~same).any() else 0.0
+    print(f"[top1] int8 quant_forward vs fp32 fake-quant forward, same GPU, same (reference) intervals, 1000 images: same prediction on "
+          f"{int(same.sum())}/1000 (largest fp32-path margin among the others: {flipped_margin:.1e} of the logit range); logits differ by "
+          f"{med:.1e} (median) / {worst:.1e} (max) of the logit range -- the quantisation error itself is {noise:.1e}")
+    assert same.mean() >= 0.995, int(same.sum())
+    assert worst <= 0.25 * noise and med <= 0.02 * noise, (worst, med, noise)
+    assert flipped_margin <= 2.0 * worst                            # a flipped prediction is a near-tie of the fp32 path itself

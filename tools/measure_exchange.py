@@ -1,8 +1,10 @@
-"""What the final interval exchange of a sharded calibration costs (utils/shard.py::exchange_intervals: one all_reduce of the slot
-table + ONE all_gather of the fp32 interval vector), measured where it can be: RCCL with one rank on the GPU box (the launch +
-synchronisation floor of the two collectives; a one-GPU box cannot show xGMI), gloo with 2 ranks on the host (another transport:
-an upper bound for a latency-bound KB-sized message).  74 calibrated modules of DeiT-tiny/224 (the reference's intervals, 434
-scalars; ViT-B: 1 334 -- both far below one packet).  tools/predict_scale.py reads the result instead of assuming 1.5 ms.
+"""What the final interval exchange of a sharded calibration costs (utils/shard.py::exchange_intervals: ONE all_gather of a
+fixed-layout fp32 vector, round 6), measured where it can be: RCCL with one rank on the GPU box (the launch + synchronisation
+floor of the collective; a one-GPU box cannot show xGMI), gloo with 2 ranks on the host (another transport: an upper bound for a
+latency-bound message of ~100 KB).  74 calibrated modules of DeiT-tiny/224 (the reference's intervals).  With ONE rank nobody
+else's module is installed -- and installing is most of the host-side cost -- so the one-rank run also times the exchange with
+every module installed from the gathered buffer (`install_own`): at world W a rank installs (W - 1) / W of the modules, which is
+what tools/predict_scale.py adds to the one-rank figure.
 
   python tools/measure_exchange.py --backend nccl            (GPU box)
   python tools/measure_exchange.py --backend gloo --world 2  (anywhere)
@@ -33,26 +35,29 @@ def worker(rank, world, backend, port, iters, out):
     for _ in range(3):
         total = shard.exchange_intervals(wrapped, owner)
     sync(); dist.barrier()
-    ts = []
+    ts, ti = [], []
     for _ in range(iters):
         t0 = time.perf_counter()
         shard.exchange_intervals(wrapped, owner)
         sync()
         ts.append(time.perf_counter() - t0)
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        shard.exchange_intervals(wrapped, owner, install_own=True)      # every module installed from the gathered buffer
+        sync()
+        ti.append(time.perf_counter() - t0)
     # the collectives alone (the rest of exchange_intervals is host-side packing / installing of 74 modules)
     dev = torch.device("cuda", 0) if backend == "nccl" else torch.device("cpu")
     vec = torch.zeros(total, dtype=torch.float32, device=dev)
-    tab = torch.zeros(len(names), 5, 9, dtype=torch.int64, device=dev)
     parts = [torch.empty_like(vec) for _ in range(world)]
     cs = []
     for _ in range(iters):
         sync(); t0 = time.perf_counter()
-        dist.all_reduce(tab, op=dist.ReduceOp.MAX)
         dist.all_gather(parts, vec)
         sync()
         cs.append(time.perf_counter() - t0)
     if rank == 0:
-        ts.sort(); cs.sort()
+        ts.sort(); cs.sort(); ti.sort()
         ver = None
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
@@ -60,6 +65,7 @@ def worker(rank, world, backend, port, iters, out):
             pass
         res = {"backend": backend, "world": world, "scalars": int(total), "modules": len(names), "iters": iters, "rccl_version": ver,
                "exchange_intervals_ms": {"median": 1e3 * ts[len(ts) // 2], "min": 1e3 * ts[0], "max": 1e3 * ts[-1]},
+               "exchange_installing_every_module_ms": {"median": 1e3 * ti[len(ti) // 2], "min": 1e3 * ti[0], "max": 1e3 * ti[-1]},
                "collectives_only_ms": {"median": 1e3 * cs[len(cs) // 2], "min": 1e3 * cs[0], "max": 1e3 * cs[-1]}}
         print(json.dumps(res))
         if out:

@@ -51,7 +51,12 @@ def measured_exchange_s():
     d = json.load(open(paths[-1]))
     for key in ("nccl_world1", "gloo_world2"):
         if key in d:
-            return d[key]["exchange_intervals_ms"]["median"] * 1e-3, f"{key} ({os.path.basename(paths[-1])})"
+            base = d[key]["exchange_intervals_ms"]["median"] * 1e-3
+            # (one rank installs nobody else's module; the run with EVERY module installed from the gathered buffer bounds what a
+            # rank of a larger world does -- it installs (W - 1) / W of them)
+            if key == "nccl_world1" and "exchange_installing_every_module_ms" in d[key]:
+                base = d[key]["exchange_installing_every_module_ms"]["median"] * 1e-3
+            return base, f"{key} ({os.path.basename(paths[-1])})"
     return EXCHANGE_S, "assumed"
 
 
