@@ -2484,7 +2484,9 @@ struct Sweep3Params {
     float* part; long p_cs; int NG;     // part[c*p_cs + (st*2+wr)*NG + tt*4+wc]
     int stiles, ttiles;
     int dbg;
-    int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them)
+    int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them; whole
+                                        // rows of `stiles` tiles: tile0 and ntile are multiples of stiles)
+    int tpw;                            // k_sweep6: streaming tiles (of one stationary slab) a workgroup walks, >= 1
     const float* E;                     // k_sweep6: epilogue operands in fragment order (k_prep_epi6); S is in fragment order too
     const int* crange_blk;              // k_sweep6: optional per-score-block candidate ranges (block = scale block of the tile)
 #ifdef P4V_TRACE
@@ -2982,17 +2984,16 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
 
-    const int nwg = p.ntile > 0 ? p.ntile : p.stiles * p.ttiles;
-    const int t = p.tile0 + xcd_remap(blockIdx.x, nwg);
-    const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
-    const int s0 = st * 256 + wid * (32 * RB), t0 = tt * 64;
+    // Round 6: a workgroup is PERSISTENT over `tpw` consecutive streaming tiles of ONE stationary slab: the slab's fragments
+    // (196 KB at K = 768, 60 % of what a tile's prologue loaded) stay in the registers, only the tile's epilogue operands and
+    // its candidate stream change.  A pruned stage leaves a tile ~8-35 candidates (19-80 us of MFMA work): the per-tile
+    // prologue was a third of such a launch.  blockIdx.x = chunk * stiles + slab: neighbours share their streaming tiles.
+    const int bx = xcd_remap(blockIdx.x, gridDim.x);
+    const int st = bx % p.stiles, chunk = bx / p.stiles;
+    const int tt_lo = p.ntile > 0 ? p.tile0 / p.stiles : 0, tt_n = p.ntile > 0 ? p.ntile / p.stiles : p.ttiles;
+    const int tt_begin = tt_lo + chunk * p.tpw, tt_end = min(tt_lo + tt_n, tt_begin + p.tpw);
+    const int s0 = st * 256 + wid * (32 * RB);
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
-    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
-    clip_crange(p.crange, c_lo_, c_hi_);
-    if (p.crange_blk) clip_crange_blk(p.crange_blk, min((p.sb_on_t ? tt * 64 : st * 256) / p.sb_div, p.s_cs - 1), c_lo_, c_hi_);
-    const int c_lo = c_lo_, c_hi = c_hi_;
-    if (c_lo >= c_hi) return;
-    const int ncand = c_hi - c_lo;
 
     // ---- streaming operand [row][candidate][K]: wave w moves rows w*16 .. w*16+15 of every k-tile ----------------
     // a candidate's tile = 4 * KT pieces of 1 KB (16 rows x 64 B); wave w moves pieces w, w + NW, ...: piece q is
@@ -3001,9 +3002,8 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     constexpr int PPW = (NPC + NW - 1) / NW;             // pieces per wave
     const int ld_row = (wid & 3) * 16 + (lane >> 2);
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
-    const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
     const int kt_w = wid >> 2;                           // first k-tile of this wave's pieces (NW = 8: 0 or 1)
-    curT += kt_w * SW_BKB;                               // (NW = 8: the odd waves start one k-tile in)
+    const char* curT = nullptr;                          // (set per tile)
     auto piece = [&](const char* src, int stage_off, auto j_c) __attribute__((always_inline)) {
         // j-th piece of this wave: k-tile j * (NW / 4) + kt_w; the compile-time part of the k offset rides in the
         // instruction (it is added to the LDS address as well, hence the "- OFF" on the destination)
@@ -3019,8 +3019,6 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         }(std::make_integer_sequence<int, PPW>{});
         curT += p.ldk;
     };
-    issue(0);
-    issue(STG);      // always two candidates ahead (slack behind the plane; stale stages are never consumed)
 
     // ---- stationary operand: 64 rows x K bytes of this wave, MFMA A-fragments, registers for the whole kernel -----
     v4i sfr[KT][RB][2];   // [k-tile][32-row block][32-byte half]
@@ -3039,9 +3037,28 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
                 }
     }
 
+    float u[RB][2][16], w[RB][2][16];
+    bool first_tile = true;
+    for (int tt = tt_begin; tt < tt_end; ++tt) {
+    const int t = tt * p.stiles + st, t0 = tt * 64;
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, min((p.sb_on_t ? tt * 64 : st * 256) / p.sb_div, p.s_cs - 1), c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
+    if (c_lo >= c_hi) continue;                          // (uniform over the workgroup: the ranges are workgroup-wide values)
+    const int ncand = c_hi - c_lo;
+    if (!first_tile) {
+        // the previous tile's over-issued ring pieces have landed and every wave has read its results / scale table
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
+    first_tile = false;
+    curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16 + kt_w * SW_BKB;
+    issue(0);
+    issue(STG);      // always two candidates ahead (slack behind the plane; stale stages are never consumed)
+
     // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming), in
     // fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in) ---------------------
-    float u[RB][2][16], w[RB][2][16];
     if (p.E) {
         const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
 #pragma unroll
@@ -3276,6 +3293,7 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         const float v = (RB == 2) ? r[wv * 2 + cb] : r[(2 * wv) * 2 + cb] + r[(2 * wv + 1) * 2 + cb];
         p.part[(long)(c_lo + ci) * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = v;
     }
+    }   // (next streaming tile of this workgroup)
 #undef P4V_DSR
 #ifdef P4V_TRACE
     if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)ncand; trc[9] = __builtin_amdgcn_s_memtime(); }
