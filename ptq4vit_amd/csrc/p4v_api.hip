@@ -1085,9 +1085,10 @@ int run_pass(Ctx& c, Pass& ps) {
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
     // k_sweep6: epilogue operands in fragment order, one image per 256 x 64 tile (8 bytes per output element)
     const int s6_stiles = (a_search ? Np : Mp) / 256, s6_ttiles = (int)cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
-    // (only where the in-place gather is uncoalesced: the activation search, whose tile is transposed; in the weight search the
-    // lanes of a load already read consecutive features)
-    const bool epi6_on = regs6 && (a_search || tune(TUNE_EPI6W) == 1);
+    // (round 6: in BOTH searches -- the persistent k_sweep6 requests the next tile's operands while the current tile's last
+    // candidate runs, as plain 1 KB loads into the registers the epilogue reads; the weight search's in-place gather, 128 dword
+    // loads per lane and tile, was 7-19 us of a 40-70 us workgroup)
+    const bool epi6_on = regs6;
     const size_t epi6_bytes = epi6_on ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
     EpiCache* ec = (epi6_on && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
     if (ec && !ec->assigned) {

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--tune", default="", help="key=value,... launch-heuristic overrides (p4v_debug_set_tuning)")
     ap.add_argument("--metric", default="hessian", help="similarity metric (hessian, cosine, L2_norm, ...)")
     ap.add_argument("--kernel-stats", action="store_true", help="per-launch time of the sweep kernels (HIP events)")
+    ap.add_argument("--vit-grad", action="store_true", help="raw_grad with the profile of a ViT under the reference's KL loss: magnitude 1e-10, "
+                    "class-token rows > 99 %% of grad^2 (tests/test_hip_production_path.py::vit_like_grad) -- the pruned passes engage as in production")
     a = ap.parse_args()
     if "," in a.layer:
         for name in a.layer.split(","):
@@ -61,7 +63,11 @@ def one(a):
         b = torch.randn(N, generator=g) * 0.02
         x, w, b = x.to(dev), w.to(dev), b.to(dev)
         out = torch.nn.functional.linear(x, w, b)
-        grad = (torch.randn(out.shape, generator=g) * 1e-3).to(dev)
+        grad = (torch.randn(out.shape, generator=g) * 1e-3)
+        if a.vit_grad:
+            grad = torch.randn(out.shape, generator=g) * 1e-10
+            grad[:, 0] *= 300.0 * torch.exp(torch.randn(out.shape[0], generator=g)).view(-1, 1)
+        grad = grad.to(dev)
         run = lambda: engine.linear_calibrate(weight=w, bias=b, x=x, out=out, grad=grad, w_bit=a.bits, a_bit=a.bits,
                                               n_V=nV, n_H=1, n_a=1, postgelu=gelu, **hp)
         macs = 2.0 * 100 * a.rounds * a.batch * a.tokens * K * N
