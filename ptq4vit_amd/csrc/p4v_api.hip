@@ -103,7 +103,7 @@ std::atomic<long long> g_prune_cnt[4];
 // Kernel-variant switches for A/B measurements and kernel-vs-kernel agreement tests (p4v_debug_set_variant; 0 in
 // production).  One relaxed atomic word, read once per pass:
 //   4   no stationary-operand sweeps (everything on k_sweep2)      8   k_sweep4 instead of k_sweep5 (one candidate per pass)
-//   16  no k_sweep6 (stationary operand in LDS instead of registers)  32  (rounds 2-5: k_sweep6 with 8 waves; no longer built)
+//   16  no k_sweep6 (stationary operand in LDS instead of registers)  32  k_sweep6 with 8 waves (two per SIMD)
 //   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
 //   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
 //   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
@@ -125,7 +125,7 @@ std::atomic<int> g_variant_word{0};
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[16];
 enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8,
-       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11, TUNE_B1_PATH = 12, TUNE_TIER2 = 13, TUNE_TIER2_DIV = 14, TUNE_TPW6 = 15 };   // TPW6: streaming tiles per k_sweep6 workgroup   // TIER2: 1 = no second slice tier; >= 2: minimum survivor count that triggers it   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11, TUNE_B1_PATH = 12, TUNE_TIER2 = 13, TUNE_TIER2_DIV = 14 };   // TIER2: 1 = no second slice tier; >= 2: minimum survivor count that triggers it   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 // TUNE_B1_PATH (key 12) doubles as the A/B switch of the round-4 / round-5 paths: 1 / 2 the bound pass on k_sweep2 / k_sweep4,
 // 3 the bound pass on the sweep kernels, 5 padded 64-column planes, 6 no slice kernels, 7 cosine on the generic kernel,
 // 8 read-backs by copy (no mapped host memory), 9 no per-score-block candidate ranges, 10 k_slice_b instead of k_slice_b2,
@@ -207,13 +207,6 @@ template <typename P, void (*K1)(P), void (*KG)(GroupArgs<P>)> struct Kern {
     }
     static const KernelDesc* desc() { static const KernelDesc d{&one, &many, GroupArgs<P>::CAP}; return &d; }
 };
-template <typename P, void (*KG)(GroupArgs<P>)> struct KernG {      // kernels launched through their grouped entry point only, also
-    static hipError_t many(const QOp* const* ops, int n, hipStream_t st) {      // alone (k_sweep6: its one-module entry point has the
-        return Kern<P, nullptr, KG>::many(ops, n, st);                             // parameter block in SGPRs for the whole persistent
-    }                                                                              // loop and spills; the grouped one re-reads it)
-    static hipError_t one(const QOp& op, hipStream_t st) { const QOp* o = &op; return many(&o, 1, st); }
-    static const KernelDesc* desc() { static const KernelDesc d{&one, &many, GroupArgs<P>::CAP}; return &d; }
-};
 template <typename P, void (*K1)(P)> struct Kern1 {      // kernels off the grouped path (generic fallbacks, API helpers)
     static_assert(sizeof(P) <= QOP_PARAM_BYTES, "kernel parameter block larger than a queued operation holds");
     static hipError_t one(const QOp& op, hipStream_t st) {
@@ -229,7 +222,6 @@ template <typename P, void (*K1)(P)> struct Kern1 {      // kernels off the grou
 #define KERN(P, NAME) (Kern<P, NAME, NAME##_g>::desc())
 #define KERN_T(P, NAME, ...) (Kern<P, NAME<__VA_ARGS__>, NAME##_g<__VA_ARGS__>>::desc())
 #define KERN1_T(P, NAME, ...) (Kern1<P, NAME<__VA_ARGS__>>::desc())
-#define KERNG_T(P, NAME, ...) (KernG<P, NAME##_g<__VA_ARGS__>>::desc())
 
 constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
 constexpr size_t MIRROR_BYTES = 128 + sizeof(float) * MIR_SLOT * MIR_SLOTS;
@@ -679,7 +671,7 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 
 template <int KT, int RB>
 int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds, const StatInfo* si) {
-    P4V_EPI4(epi, return enqueue(c, KERNG_T(Sweep3Params, k_sweep6, E, KT, RB), grid, dim3(512 / RB), lds, p, si))
+    P4V_EPI4(epi, return enqueue(c, KERN_T(Sweep3Params, k_sweep6, E, KT, RB), grid, dim3(512 / RB), lds, p, si))
 }
 
 // k_sweep6 (stationary operand in registers): K = 192 / 256 / 384 / 512 / 768 bytes -- the Linear layers of
@@ -688,61 +680,62 @@ bool sweep6_supported(int ktiles) { return ktiles == 3 || ktiles == 4 || ktiles 
 
 int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups);
 
-// One workgroup per CU (512 registers per wave).  Round 6: a workgroup is persistent over `tpw` consecutive streaming tiles of one
-// stationary slab (the slab's fragments stay in its registers) and runs `per` = ceil(candidates / cgroups) candidates on each.
-// The plan -- (tiles per workgroup, candidate groups) -- minimises rounds x workgroup time for the CU slots this member can
-// count on (all 256 alone, 256 / lock-step members inside a group).  Cost model in microseconds: slab prologue (stationary
-// fragments, once per workgroup), tile prologue (epilogue operands + ring warm-up, once per tile), one candidate of one tile.
+// One workgroup per CU (512 registers per wave): `tiles` equal workgroups run in ceil(tiles / 256) waves and the last
+// one is mostly empty (ViT-B qkv: 900 tiles = 3.5 waves).  The tiles of the last, partial wave are launched separately
+// with their candidates split over q groups, so that it takes a fraction of a full wave's time; every group pays
+// the workgroup prologue (stationary operand + raw_out / raw_grad tile) again.  Cost model in microseconds.
+// (Inside a group the other members' tiles fill the last wave: no split.)
 int launch_sweep6(Ctx& c, const Sweep3Params& p, int epi, int cgroups, int nc_model = 0) {
     if (c.dry) return 0;
-    // (p.ntile > 0: only the tiles [p.tile0, p.tile0 + p.ntile) -- whole rows of stiles tiles: the open score blocks of a pruned
-    // pass; nc_model: the number of candidates the device-side range leaves, when the host knows it)
-    if (p.ntile > 0 && (p.ntile % p.stiles || p.tile0 % p.stiles)) return fail(P4V_ERR_INVALID, "k_sweep6: partial tile rows");
-    const int ntt = p.ntile > 0 ? p.ntile / p.stiles : p.ttiles;
-    const int nc = std::max(1, nc_model > 0 ? nc_model : p.c1 - p.c0);
-    const int slots = cu_slots(c, 256, 2);
-    const double P_slab = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 6.0, P_tile = 4.0, t_c = 0.196 * p.ktiles;
-    int best_tpw = 1, best_cg = 1;
-    double best = 1e30;
-    for (int chunks = 1; chunks <= ntt; ++chunks) {
-        const int tpw = cdiv(ntt, chunks);
-        if (chunks > 1 && cdiv(ntt, chunks - 1) == tpw) continue;             // same tiles per workgroup as the previous count
-        for (int cg = 1; cg <= std::min(nc, 25); ++cg) {
-            const long wgs = (long)p.stiles * cdiv(ntt, tpw) * cg;
-            const double t = (double)cdiv(wgs, slots) * (P_slab + tpw * (P_tile + cdiv(nc, cg) * t_c));
-            if (t < best * 0.999) { best = t; best_tpw = tpw; best_cg = cg; }
+    // (p.ntile > 0: only the tiles [p.tile0, p.tile0 + p.ntile) -- the open score blocks of a pruned pass; nc_model: the number of
+    // candidates the device-side range leaves, when the host knows it)
+    const int tiles = p.ntile > 0 ? p.ntile : p.stiles * p.ttiles, base = p.ntile > 0 ? p.tile0 : 0;
+    const int nc = nc_model > 0 ? nc_model : p.c1 - p.c0;
+    const int full = tiles / 256 * 256, rem = tiles - full;
+    const double P = tune(TUNE_P6) > 0 ? 0.1 * tune(TUNE_P6) : 20.0, t_c = 0.196 * p.ktiles;        // prologue, one candidate of one tile
+    auto waves = [](long wgs) { return (double)((wgs + 255) / 256); };
+    int q_best = 0;
+    if (rem > 0 && full > 0 && !(g_variant & 16384) && lockstep(c, 2) <= 1) {
+        double best = waves((long)tiles * cgroups) * (P + cdiv(nc, cgroups) * t_c) * 0.97;   // the uniform plan
+        for (int q = 1; q <= std::min(nc, 12); ++q) {
+            const double t = waves(full) * (P + nc * t_c) + waves((long)rem * q) * (P + cdiv(nc, q) * t_c);
+            if (t < best) { best = t; q_best = q; }
         }
     }
-    if (tune(TUNE_CG6) > 0) best_cg = std::max(1, std::min(nc, tune(TUNE_CG6)));
-    if (tune(TUNE_TPW6) > 0) best_tpw = std::max(1, std::min(ntt, tune(TUNE_TPW6)));
-    (void)cgroups;
-    if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 slabs %d x tile rows %d, %d candidates, %d slots -> %d tiles per workgroup, %d candidate groups\n", p.stiles, ntt, nc, slots, best_tpw, best_cg);
-    Sweep3Params a = p;
-    a.tpw = best_tpw;
-    return launch_sweep6_part(c, a, epi, best_cg);
+    if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d: full %d rem %d -> q %d (uniform cg %d)\n", tiles, full, rem, q_best, cgroups);
+    if (q_best > 0) {
+        Sweep3Params a = p, b = p;
+        a.tile0 = base; a.ntile = full;
+        b.tile0 = base + full; b.ntile = rem;
+        CHK(launch_sweep6_part(c, a, epi, 1));
+        CHK(launch_sweep6_part(c, b, epi, q_best));
+    } else {
+        Sweep3Params a = p;
+        a.tile0 = base; a.ntile = p.ntile > 0 ? tiles : 0;
+        CHK(launch_sweep6_part(c, a, epi, cgroups));
+    }
+    return 0;
 }
 
 int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     const int per = cdiv(p.c1 - p.c0, cgroups);
-    // 32-row blocks per wave: 2 = 4 waves, one per SIMD (bound by its own VALU + MFMA issue, LDS-light).  (The kernel template
-    // also instantiates with 1 = 8 waves, two per SIMD -- it hides the VALU work but doubles the fragment reads, LDS-bound: both
-    // measured 3.33 ms per fc1 search round in round 2; with the persistent tile loop of round 6 that instance no longer fits
-    // its 256 registers, so it is not built: variant 32 is a no-op.)
-    const int rb = 2;
+    // 32-row blocks per wave: 2 = 4 waves, one per SIMD (default: bound by its own VALU + MFMA issue, LDS-light);
+    // 1 = 8 waves, two per SIMD (A/B variant 32: hides the VALU work but doubles the fragment reads -> LDS-bound;
+    // both measure 3.33 ms per fc1 search round on MI355X)
+    const int rb = (g_variant & 32) ? 1 : 2;
     const int nw = 8 / rb;
     const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 2 * nw * sizeof(float) + (size_t)per * nw * sizeof(float) + 64 * sizeof(float) + 256;
-    const int ntt = p.ntile > 0 ? p.ntile / p.stiles : p.ttiles;
-    dim3 grid(p.stiles * cdiv(ntt, std::max(1, p.tpw)), 1, cgroups);
+    dim3 grid(p.ntile > 0 ? p.ntile : p.stiles * p.ttiles, 1, cgroups);
 #ifdef P4V_TRACE
     CHK(trace_attach(const_cast<Sweep3Params&>(p)));
 #endif
-    // one record per kernel launch; a sweep over some of the tile rows books its work (and the pass's bytes) in proportion
-    const double share = (double)ntt / (double)p.ttiles;
+    // one record per kernel launch; a split sweep books its work (and the pass's bytes) in proportion to the tiles of each part
+    const double share = (double)grid.x / ((double)p.stiles * p.ttiles);
     const StatInfo si = stat_info(2, share * (double)p.stiles * 256 * (double)p.ttiles * 64 * (double)p.ldk * (p.c1 - p.c0),
                                   share * g_alg_macs_cand * (p.c1 - p.c0), (int)grid.x, (int)grid.z, share * g_alg_bytes);
     const StatInfo* sp = &si;
     int r;
-#define P4V_KT(K) launch_sweep6_kt<K, 2>(c, p, epi, grid, lds, sp)
+#define P4V_KT(K) (rb == 2 ? launch_sweep6_kt<K, 2>(c, p, epi, grid, lds, sp) : launch_sweep6_kt<K, 1>(c, p, epi, grid, lds, sp))
     switch (p.ktiles) {
         case 12: r = P4V_KT(12); break;
         case 8: r = P4V_KT(8); break;
@@ -1085,10 +1078,9 @@ int run_pass(Ctx& c, Pass& ps) {
     float* epi7 = big7 ? c.ws.get<float>((size_t)Mp * Np * 2) : nullptr;   // k_sweep7: epilogue operands in fragment order
     // k_sweep6: epilogue operands in fragment order, one image per 256 x 64 tile (8 bytes per output element)
     const int s6_stiles = (a_search ? Np : Mp) / 256, s6_ttiles = (int)cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
-    // (round 6: in BOTH searches -- the persistent k_sweep6 requests the next tile's operands while the current tile's last
-    // candidate runs, as plain 1 KB loads into the registers the epilogue reads; the weight search's in-place gather, 128 dword
-    // loads per lane and tile, was 7-19 us of a 40-70 us workgroup)
-    const bool epi6_on = regs6;
+    // (only where the in-place gather is uncoalesced: the activation search, whose tile is transposed; in the weight search the
+    // lanes of a load already read consecutive features)
+    const bool epi6_on = regs6 && (a_search || tune(TUNE_EPI6W) == 1);
     const size_t epi6_bytes = epi6_on ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
     EpiCache* ec = (epi6_on && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
     if (ec && !ec->assigned) {

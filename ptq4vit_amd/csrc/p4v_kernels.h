@@ -2484,9 +2484,7 @@ struct Sweep3Params {
     float* part; long p_cs; int NG;     // part[c*p_cs + (st*2+wr)*NG + tt*4+wc]
     int stiles, ttiles;
     int dbg;
-    int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them; whole
-                                        // rows of `stiles` tiles: tile0 and ntile are multiples of stiles)
-    int tpw;                            // k_sweep6: streaming tiles (of one stationary slab) a workgroup walks, >= 1
+    int tile0, ntile;                   // k_sweep6: this launch covers tiles [tile0, tile0 + ntile) (ntile == 0: all of them)
     const float* E;                     // k_sweep6: epilogue operands in fragment order (k_prep_epi6); S is in fragment order too
     const int* crange_blk;              // k_sweep6: optional per-score-block candidate ranges (block = scale block of the tile)
 #ifdef P4V_TRACE
@@ -2974,9 +2972,6 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P4V_TRACE
     unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
-    // per workgroup (thread 0): [0] start, [1] sum of the tile prologues, [2] sum of the candidate loops, [3] end, [4] sum of the tile
-    // tails (last epilogue + result write), [5] hardware id, [6] slab prologue (start .. first tile), [7] candidates run, [10] tiles run
-    unsigned long long tr_pro = 0, tr_loop = 0, tr_tail = 0, tr_steps = 0, tr_tiles = 0, tr_a = 0, tr_b = 0, tr_first = 0;
     if (threadIdx.x == 0) { trc[0] = __builtin_amdgcn_s_memrealtime(); trc[8] = __builtin_amdgcn_s_memtime(); trc[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 #endif
     constexpr int KT_TILE = 64 * 64;                     // bytes of one k-tile of the 64-row streaming tile
@@ -2987,16 +2982,17 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
 
-    // Round 6: a workgroup is PERSISTENT over `tpw` consecutive streaming tiles of ONE stationary slab: the slab's fragments
-    // (196 KB at K = 768, 60 % of what a tile's prologue loaded) stay in the registers, only the tile's epilogue operands and
-    // its candidate stream change.  A pruned stage leaves a tile ~8-35 candidates (19-80 us of MFMA work): the per-tile
-    // prologue was a third of such a launch.  blockIdx.x = chunk * stiles + slab: neighbours share their streaming tiles.
-    const int bx = xcd_remap(blockIdx.x, gridDim.x);
-    const int st = bx % p.stiles, chunk = bx / p.stiles;
-    const int tt_lo = p.ntile > 0 ? p.tile0 / p.stiles : 0, tt_n = p.ntile > 0 ? p.ntile / p.stiles : p.ttiles;
-    const int tt_begin = tt_lo + chunk * p.tpw, tt_end = min(tt_lo + tt_n, tt_begin + p.tpw);
-    const int s0 = st * 256 + wid * (32 * RB);
+    const int nwg = p.ntile > 0 ? p.ntile : p.stiles * p.ttiles;
+    const int t = p.tile0 + xcd_remap(blockIdx.x, nwg);
+    const int st = t % p.stiles, tt = t / p.stiles;    // neighbours share the streaming tile
+    const int s0 = st * 256 + wid * (32 * RB), t0 = tt * 64;
     const int per = (p.c1 - p.c0 + gridDim.z - 1) / gridDim.z;
+    int c_lo_ = p.c0 + blockIdx.z * per, c_hi_ = min(p.c1, c_lo_ + per);
+    clip_crange(p.crange, c_lo_, c_hi_);
+    if (p.crange_blk) clip_crange_blk(p.crange_blk, min((p.sb_on_t ? tt * 64 : st * 256) / p.sb_div, p.s_cs - 1), c_lo_, c_hi_);
+    const int c_lo = c_lo_, c_hi = c_hi_;
+    if (c_lo >= c_hi) return;
+    const int ncand = c_hi - c_lo;
 
     // ---- streaming operand [row][candidate][K]: wave w moves rows w*16 .. w*16+15 of every k-tile ----------------
     // a candidate's tile = 4 * KT pieces of 1 KB (16 rows x 64 B); wave w moves pieces w, w + NW, ...: piece q is
@@ -3005,7 +3001,9 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     constexpr int PPW = (NPC + NW - 1) / NW;             // pieces per wave
     const int ld_row = (wid & 3) * 16 + (lane >> 2);
     const int ld_chunk = (lane & 3) ^ ((ld_row >> 2) & 3);
+    const char* curT = (const char*)p.T + (long)(t0 + ld_row) * p.t_rs + (long)(c_lo - p.c0) * p.ldk + ld_chunk * 16;
     const int kt_w = wid >> 2;                           // first k-tile of this wave's pieces (NW = 8: 0 or 1)
+    curT += kt_w * SW_BKB;                               // (NW = 8: the odd waves start one k-tile in)
     auto piece = [&](const char* src, int stage_off, auto j_c) __attribute__((always_inline)) {
         // j-th piece of this wave: k-tile j * (NW / 4) + kt_w; the compile-time part of the k offset rides in the
         // instruction (it is added to the LDS address as well, hence the "- OFF" on the destination)
@@ -3015,49 +3013,14 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         if (NPC % NW == 0 || NW * j + wid < NPC)
             glds16_imm<OFF>(src, smem + stage_off + kt * KT_TILE + (wid & 3) * 1024 - OFF);
     };
-    auto issue_all = [&](const char* src, int stage_off) __attribute__((always_inline)) {
+    auto issue = [&](int stage_off) __attribute__((always_inline)) {
         [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
-            (piece(src, stage_off, std::integral_constant<int, J>{}), ...);
+            (piece(curT, stage_off, std::integral_constant<int, J>{}), ...);
         }(std::make_integer_sequence<int, PPW>{});
+        curT += p.ldk;
     };
-
-    // ---- the workgroup's tiles and the candidate sequence over them --------------------------------------------------
-    // A tile's candidate range is this launch's group of the device-side range, clipped to the range of the tile's score block;
-    // tiles whose range is empty are skipped (workgroup-uniform: the ranges are workgroup-wide values).  The LDS-DMA ring
-    // runs over the CONCATENATED candidates of all the workgroup's tiles: while a tile's last two candidates are multiplied,
-    // the first two of the next tile stream in -- no ring warm-up per tile, nothing fetched past the end of a tile's plane
-    // (behind the last tile the ring re-reads the workgroup's first candidate: L2-resident, never consumed).
-    auto tile_range = [&](int tt_, int& lo, int& hi) __attribute__((always_inline)) {
-        lo = p.c0 + blockIdx.z * per; hi = min(p.c1, lo + per);
-        clip_crange(p.crange, lo, hi);
-        if (p.crange_blk) clip_crange_blk(p.crange_blk, min((p.sb_on_t ? tt_ * 64 : st * 256) / p.sb_div, p.s_cs - 1), lo, hi);
-    };
-    auto next_tile = [&](int from, int& lo, int& hi) __attribute__((always_inline)) -> int {
-        for (int tt_ = from; tt_ < tt_end; ++tt_) { tile_range(tt_, lo, hi); if (lo < hi) return tt_; }
-        return -1;
-    };
-    // (workgroup-uniform byte offsets into the plane -- scalar registers -- plus ONE per-lane offset: the lane's row and 16-byte
-    // chunk of a piece)
-    auto tile_base = [&](int tt_, int lo) __attribute__((always_inline)) -> long {
-        return (long)tt_ * 64 * p.t_rs + (long)(lo - p.c0) * p.ldk;
-    };
-    const long lane_off = (long)ld_row * p.t_rs + ld_chunk * 16 + kt_w * SW_BKB;
-    int c_lo, c_hi;
-    int tt = next_tile(tt_begin, c_lo, c_hi);
-    if (tt < 0) return;
-    int f_tt = tt, f_left = c_hi - c_lo;
-    long f_off = tile_base(tt, c_lo);
-    const long dummy_off = f_off;
-    auto fetch_next = [&]() __attribute__((always_inline)) -> const char* {
-        if (f_left == 0 && f_tt >= 0) {
-            int lo, hi;
-            f_tt = next_tile(f_tt + 1, lo, hi);
-            if (f_tt >= 0) { f_left = hi - lo; f_off = tile_base(f_tt, lo); }
-        }
-        long o = dummy_off;
-        if (f_tt >= 0) { o = f_off; f_off += p.ldk; --f_left; }
-        return (const char*)p.T + (__builtin_amdgcn_readfirstlane((int)(o >> 32)) * (1L << 32) + (unsigned)__builtin_amdgcn_readfirstlane((int)o)) + lane_off;
-    };
+    issue(0);
+    issue(STG);      // always two candidates ahead (slack behind the plane; stale stages are never consumed)
 
     // ---- stationary operand: 64 rows x K bytes of this wave, MFMA A-fragments, registers for the whole kernel -----
     v4i sfr[KT][RB][2];   // [k-tile][32-row block][32-byte half]
@@ -3076,38 +3039,69 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
                 }
     }
 
-    // ---- candidate-invariant epilogue operands of a tile: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming),
-    // in fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in; 1 KB contiguous per load;
-    // round 6: also in the weight search, whose in-place gather of raw_out / raw_grad -- 128 dword loads per lane and tile --
-    // was 7-19 us of a tile's 40-70).  load_uw(tile, cb) ISSUES the loads of one column block: the next tile's, as soon as this
-    // tile's last candidate has read the registers for the last time.
+    // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming), in
+    // fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in) ---------------------
     float u[RB][2][16], w[RB][2][16];
-    auto load_uw = [&](int tt_, auto cb_c) __attribute__((always_inline)) {
-        constexpr int cb = decltype(cb_c)::value;
-        const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)(tt_ * p.stiles + st) * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
+    if (p.E) {
+        const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4f u4, w4;
-                if constexpr ((P4V_SW6_DBG & 16) != 0) { u4 = v4f{(float)lane, 1.f, 2.f, 3.f}; w4 = v4f{1.f, 1.f, 1.f, 1.f}; }
-                else {
-                    u4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 0) * 64];
-                    w4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 1) * 64];
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f u4, w4;
+                    if constexpr ((P4V_SW6_DBG & 16) != 0) { u4 = v4f{(float)lane, 1.f, 2.f, 3.f}; w4 = v4f{1.f, 1.f, 1.f, 1.f}; }
+                    else {
+                        u4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 0) * 64];
+                        w4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 1) * 64];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = u4[e]; w[i][cb][q * 4 + e] = w4[e]; }
+                }
+    } else {
+        // in place (weight search: the streaming rows are the output features, the contiguous dimension of raw_out, so the 32
+        // lanes of a half wave read 128 contiguous bytes per load): every load issued unconditionally at clamped addresses,
+        // then branch-free masking / weight selection
+        const unsigned m_g = p.wt_mode == 1 ? 0xffffffffu : 0u;
+        const unsigned m_o = p.wt_mode == 2 ? 0xffffffffu : p.wt_mode == 3 ? 0x7fffffffu : 0u;
+        const unsigned m_1 = p.wt_mode == 0 ? 0x3f800000u : 0u;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int tr = t0 + cb * 32 + l31;
+            const long toff = (long)min(tr, p.TR - 1) * p.o_ts;
+            const float bias_t = p.bias[p.bias_on_t ? min(tr, p.TR - 1) : 0];
+            const bool t_ok = tr < p.TR;
+            float bs[RB][16];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int src = min(s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, p.SR - 1);
+                    const long idx = toff + (long)src * p.o_ss;
+                    u[i][cb][r] = p.O[idx];
+                    w[i][cb][r] = p.Wt[idx];
+                    bs[i][r] = p.bias[p.bias_on_t ? 0 : src];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { u[i][cb][q * 4 + e] = u4[e]; w[i][cb][q * 4 + e] = w4[e]; }
-            }
-    };
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = t_ok && (s0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) < p.SR;
+                    const float o = u[i][cb][r], gw = w[i][cb][r];
+                    const float b = p.bias_on_t ? bias_t : bs[i][r];
+                    const unsigned wbits = (__builtin_bit_cast(unsigned, gw) & m_g) | (__builtin_bit_cast(unsigned, o) & m_o) | m_1;
+                    u[i][cb][r] = ok ? o - b : 0.0f;
+                    w[i][cb][r] = ok ? __builtin_bit_cast(float, wbits) : 0.0f;
+                }
+        }
+    }
+    const int blk_row = p.sb_on_t ? t0 : s0;
+    const int sb = __builtin_amdgcn_readfirstlane(min(blk_row / p.sb_div, p.s_cs - 1));
     // LDS behind the ring: res [(per + 1) candidates][8] (slot 0 is a dump for the warm-up epilogue), s1tab [per][4],
     // dump [64] (target of the lanes that do not hold the wave sum)
     float* s1tab = res + (per + 1) * (2 * NW);
-    auto fill_s1tab = [&](int tt_, int lo, int n) __attribute__((always_inline)) {
-        const int sb = __builtin_amdgcn_readfirstlane(min((p.sb_on_t ? tt_ * 64 : s0) / p.sb_div, p.s_cs - 1));
-        for (int i = lane; i < n; i += 64) s1tab[i * NW + wid] = p.S1 ? p.S1[(lo + i) * p.s_cs + sb] : 1.0f;
-    };
-    const char* fillT = nullptr;                          // candidate being streamed in (warm-up: the second one again)
-    int fill_stage = STG;
+    for (int i = lane; i < ncand; i += 64) s1tab[i * NW + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
     // ---- main loop ----------------------------------------------------------------------------------------------
     // One candidate = 2 phases (column block cb = 0, then 1) of KT steps; a step = 2 fragment reads + 4 MFMAs.  With a
@@ -3181,6 +3175,8 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
             *dst = ered;
         }
     };
+    const char* fillT = curT - p.ldk;                     // candidate being streamed in (warm-up: candidate 1 again)
+    int fill_stage = STG;
     // one step: prefetch the fragments of step s+2, wait for those of step s, 4 MFMAs, one epilogue slice
     auto step = [&](auto s_c, unsigned ad0, unsigned ad1, unsigned adn0, unsigned adn1, int ci) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
@@ -3229,44 +3225,22 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue of the workgroup: the first two candidates of its sequence, the first tile's epilogue operands -------------
-    int stage = 0;                                        // byte offset of the stage holding the current candidate
-    {
-        const char* f0 = fetch_next();
-        issue_all(f0, 0);
-        fillT = fetch_next();
-        issue_all(fillT, STG);
-    }
-    load_uw(tt, std::integral_constant<int, 0>{});
-    load_uw(tt, std::integral_constant<int, 1>{});
-    fill_s1tab(tt, c_lo, c_hi - c_lo);
-    bool first_tile = true;
-    for (;;) {
-    const int ncand = c_hi - c_lo;
-    int lo_n = 0, hi_n = 0;
-    const int tt_n = next_tile(tt + 1, lo_n, hi_n);      // the tile after this one (its epilogue operands are requested at the end of this one)
-#ifdef P4V_TRACE
-    if (threadIdx.x == 0) { tr_a = __builtin_amdgcn_s_memrealtime(); if (first_tile) tr_first = tr_a; }
-#endif
-    // the ring's first two candidates of this tile, its epilogue operands and scale table have landed / are visible to every wave;
-    // every wave has written the previous tile's results
+    // both prologue candidates (and the register operands) have landed; make them visible to every wave
     wait_vmcnt<0>();
-    __syncthreads();
-    if (first_tile) {
-        auto pro_read = [&](auto s_c) __attribute__((always_inline)) {
-            constexpr int S = decltype(s_c)::value;
-            TF2& d = tf[S];
-            const unsigned b0 = tbase0, b1 = tbase1;
-            P4V_DSR(d.f[0], b0, (S % KT) * KT_TILE + (S / KT) * 2048);
-            P4V_DSR(d.f[1], b1, (S % KT) * KT_TILE + (S / KT) * 2048);
-        };
-        [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
-            (pro_read(std::integral_constant<int, S>{}), ...);
-        }(std::make_integer_sequence<int, PD>{});
-    }   // (later tiles: the previous tile's last candidate prefetched these fragments, as every candidate does for its successor)
-    first_tile = false;
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;                                        // byte offset of the stage holding the current candidate
+    auto pro_read = [&](auto s_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_c)::value;
+        TF2& d = tf[S];
+        const unsigned b0 = tbase0, b1 = tbase1;
+        P4V_DSR(d.f[0], b0, (S % KT) * KT_TILE + (S / KT) * 2048);
+        P4V_DSR(d.f[1], b1, (S % KT) * KT_TILE + (S / KT) * 2048);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
+        (pro_read(std::integral_constant<int, S>{}), ...);
+    }(std::make_integer_sequence<int, PD>{});
 #ifdef P4V_TRACE
-    if (threadIdx.x == 0) { tr_b = __builtin_amdgcn_s_memrealtime(); tr_pro += tr_b - tr_a; }
+    if (threadIdx.x == 0) { trc[1] = __builtin_amdgcn_s_memrealtime(); trc[6] = trc[1]; }
 #endif
     for (int ci = 0; ci < ncand; ++ci) {
         const int stage_n = (stage + STG == 3 * STG) ? 0 : stage + STG;
@@ -3279,47 +3253,32 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         };
         constexpr int SB = SBAR;                          // the ring barrier sits in the middle of phase 1
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, SB>{});
-        wait_vmcnt<0>();                                  // own pieces of the next candidate (issued one candidate ago)
-        __builtin_amdgcn_s_barrier();                     // next candidate visible to all; nobody reads the stage of the previous one any more
-        fill_stage = (stage_n + STG == 3 * STG) ? 0 : stage_n + STG;   // the candidate after next -> stage of the previous one, piece by piece
-        fillT = fetch_next();
+        wait_vmcnt<0>();                                  // own pieces of candidate ci+1 (issued one candidate ago)
+        __builtin_amdgcn_s_barrier();                     // ci+1 visible to all; nobody reads the stage of ci-1 any more
+        fill_stage = (stage_n + STG == 3 * STG) ? 0 : stage_n + STG;   // candidate ci+2 -> stage of ci-1, piece by piece
+        fillT = curT;
+        curT += p.ldk;
         run(std::integral_constant<int, SB>{}, std::integral_constant<int, NSTEP>{});
         stage = stage_n;
     }
-    // column block 0 of the epilogue operands is not read again: the next tile's, into the same registers
-    if (tt_n >= 0) load_uw(tt_n, std::integral_constant<int, 0>{});
     // block 1 of the last candidate
     [&]<int... S>(std::integer_sequence<int, S...>) __attribute__((always_inline)) {
         (epi_slice(std::integral_constant<int, S>{}, std::integral_constant<int, 1>{}, ncand), ...);
     }(std::make_integer_sequence<int, KT>{});
-    if (tt_n >= 0) load_uw(tt_n, std::integral_constant<int, 1>{});
 #ifdef P4V_TRACE
-    if (threadIdx.x == 0) { tr_a = __builtin_amdgcn_s_memrealtime(); tr_loop += tr_a - tr_b; }
+    if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();   // every wave's results of this tile are in the LDS; nobody reads the scale table any more
-    if (tt_n >= 0) fill_s1tab(tt_n, lo_n, hi_n - lo_n);
+    __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
     // part[c][64-row slab][32-column group]; with RB = 1 two waves share a slab: fixed-order sum of their results
-    // (the thread index is rebuilt from the lane count: keeping the launch's thread-id register alive across the candidate loop
-    // for these few stores would cost a spill)
-    for (int i = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); i < ncand * 8; i += 64 * NW) {
+    for (int i = tid; i < ncand * 8; i += 64 * NW) {
         const int ci = i / 8, wv = (i % 8) >> 1, cb = i & 1;
         const float* r = res + (ci + 1) * (2 * NW);
         const float v = (RB == 2) ? r[wv * 2 + cb] : r[(2 * wv) * 2 + cb] + r[(2 * wv + 1) * 2 + cb];
         p.part[(long)(c_lo + ci) * p.p_cs + (long)(st * 4 + wv) * p.NG + tt * 2 + cb] = v;
     }
-#ifdef P4V_TRACE
-    if (threadIdx.x == 0) { tr_tail += __builtin_amdgcn_s_memrealtime() - tr_a; tr_steps += ncand; ++tr_tiles; }
-#endif
-    if (tt_n < 0) break;
-    tt = tt_n; c_lo = lo_n; c_hi = hi_n;
-    }   // (next streaming tile of this workgroup)
-    wait_vmcnt<0>();   // the ring pieces issued behind the last candidate have landed before the LDS is released
 #undef P4V_DSR
 #ifdef P4V_TRACE
-    if (threadIdx.x == 0) {
-        trc[1] = tr_pro; trc[2] = tr_loop; trc[4] = tr_tail; trc[6] = tr_first ? tr_first - trc[0] : 0; trc[7] = tr_steps; trc[10] = tr_tiles;
-        trc[3] = __builtin_amdgcn_s_memrealtime(); trc[9] = __builtin_amdgcn_s_memtime();
-    }
+    if (threadIdx.x == 0) { trc[3] = __builtin_amdgcn_s_memrealtime(); trc[7] = (unsigned long long)ncand; trc[9] = __builtin_amdgcn_s_memtime(); }
 #endif
 }
 template <int EPI, int KT, int RB>

@@ -33,8 +33,7 @@ def test_no_kernel_uses_scratch(resources):
 
 
 def test_register_stationary_sweep_fits_one_wave_per_simd(resources):
-    # (k_sweep6 is launched through its grouped entry point only: p4v_api.hip, KernG)
-    k6 = {k: v for k, v in resources.items() if "k_sweep6_g<" in k and k.split("k_sweep6_g<")[1].split(">")[0].endswith(", 2")}
+    k6 = {k: v for k, v in resources.items() if "k_sweep6<" in k and k.rstrip(")").split("<")[1].split(">")[0].endswith(", 2")}
     assert len(k6) == 20                                     # 4 epilogues x KT in {3, 4, 6, 8, 12}
     for k, v in k6.items():
         assert v["NumVgprs"] + v["NumAgprs"] <= 512, (k, v)
