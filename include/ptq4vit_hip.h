@@ -178,7 +178,7 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
  *   P4V_JOB_CONV    desc = p4v_conv_desc     in = {weight, bias, x, raw_out, raw_grad}   out = {w_interval, a_interval, NULL}
  * `status` receives the member's own status; the call returns the first non-zero one (p4v_last_error() has its message).
  * ---------------------------------------------------------------------------------------- */
-enum p4v_job_kind { P4V_JOB_LINEAR = 0, P4V_JOB_MATMUL = 1, P4V_JOB_CONV = 2 };
+enum p4v_job_kind_ { P4V_JOB_LINEAR = 0, P4V_JOB_MATMUL = 1, P4V_JOB_CONV = 2 };
 typedef struct p4v_group_job {
     int32_t kind;
     int32_t status;
@@ -189,7 +189,14 @@ typedef struct p4v_group_job {
     void* workspace;
     size_t workspace_bytes;
 } p4v_group_job;
-int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream);
+ *
+ * `inputs_ready_event` (hipEvent_t, may be NULL): the members' CAPTURED tensors (x / raw_out / raw_grad, A / B) are complete once
+ * this event has fired -- the caller recorded it behind its capture passes, which may still be running on other streams.  The
+ * call then starts at once: what needs no captured tensor (weight abs-max, candidate tables, the 100 candidate planes of every
+ * Linear's weights) is issued first, and `stream` waits for the event exactly once, when every member has reached the point
+ * where it reads a captured tensor.  NULL: the tensors are ready (stream-ordered before the call, as for the single calls).
+ */
+int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream, void* inputs_ready_event);
 
 /* PROCESS-WIDE launch counters since the last reset: out4[0] kernel launches the calibration path asked for (one module at a
  * time these are the launches made), out4[1] kernel launches issued to the GPU (grouped ones count once), out4[2] issue
@@ -401,7 +408,8 @@ typedef struct p4v_launch_record {
                          13 k_slice_b / 14 k_slice_a (stage A of a MatMul B / A search) */
     int32_t stage;    /* 0 full sweep (pass not pruned) | 1 stage A (all candidates, sample slice) | 2 stage B1 (the bound) |
                          3 stage B2 (survivors, all samples) | 4 stage A2 (survivors of a loose first slice on the larger second one) */
-    int32_t grid_x, grid_z;
+    int32_t grid_x, grid_z;   /* a grouped launch (p4v_calibrate_group): grid_x = its flat grid (all members' blocks, each member padded to a
+                                 multiple of 8), grid_z = the number of members; ops / bytes are the members' sums */
     double ms;        /* HIP events around the launch on its stream */
     double ops;       /* 2 x integer / fp MACs issued (padded tiles, both twin planes), candidates outside a device-side range excluded */
     double alg_ops;   /* 2 x MACs of the reference GEMMs the launch stands for (unpadded, one plane); 0: empty candidate range */

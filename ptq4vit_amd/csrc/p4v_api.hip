@@ -159,7 +159,7 @@ struct KernelDesc {
 };
 constexpr int QOP_PARAM_BYTES = 480;
 struct QOp {
-    enum Type : int { KERNEL, FILL, D2H, H2D, COPY2D };
+    enum Type : int { KERNEL, FILL, D2H, H2D, COPY2D, WAIT };
     int type = KERNEL;
     const KernelDesc* kd = nullptr;
     dim3 grid, block;
@@ -247,6 +247,8 @@ struct Group {
     bool stat_on = false;
     std::vector<StatRec>* stat_recs = nullptr;      // the CALLING thread's launch records: one per grouped launch
     long n_ops = 0, n_launches = 0, n_rounds = 0;
+    hipEvent_t inputs_ready = nullptr;   // the members' captured tensors are complete once this event has fired (nullptr: they are)
+    bool waited = false;                 // ... and the stream already waits for it
     int last_par[16] = {};               // members in the last grouped launch of each sweep family (StatInfo.kind): what the members'
                                          // launch heuristics plan for (written by the issuer while every member is blocked)
     int issue_kernels(std::vector<const QOp*>& ops);
@@ -309,9 +311,15 @@ int Group::issue_kernels(std::vector<const QOp*>& ops) {
         ++n_launches;
         if (timed) {      // ONE record per kernel launch (1:1 with a kernel trace): the members' work added up
             HIPCHK(hipEventRecord(rec.b, st));
+            // (grid_x = the flat grid of the grouped launch -- every member's blocks, padded to a multiple of 8 --, as a kernel trace
+            // shows it; grid_z = the number of members)
             const StatInfo& s0 = ops[i0]->si;
-            rec.kind = s0.kind; rec.stage = s0.stage; rec.gz = s0.gz;
-            for (int i = 0; i < m; ++i) { const StatInfo& s = ops[i0 + i]->si; rec.macs += s.macs; rec.alg += s.alg; rec.bytes += s.bytes; rec.gx += s.gx; }
+            rec.kind = s0.kind; rec.stage = s0.stage; rec.gz = m;
+            for (int i = 0; i < m; ++i) {
+                const QOp& o = *ops[i0 + i];
+                rec.macs += o.si.macs; rec.alg += o.si.alg; rec.bytes += o.si.bytes;
+                rec.gx += (int)rup((long)o.grid.x * o.grid.y * o.grid.z, 8);
+            }
             stat_recs->push_back(rec);
         }
     }
@@ -326,15 +334,27 @@ int Group::issue_round() {
         // light operations first: a sweep waits until every member that can still reach one has
         int best = -1, best_n = 0;
         bool best_heavy = true;
+        int n_wait = 0, n_live = 0;
         for (int i = 0; i < n; ++i) {
             if (q[i].empty()) continue;
+            ++n_live;
             const QOp& h = q[i].front();
+            if (h.type == QOp::WAIT) { ++n_wait; continue; }                    // (last: see below)
             if (h.type != QOp::KERNEL) { best = i; best_n = 0; break; }        // fills / copies: at once, in member order
             if (h.heavy && !best_heavy) continue;
             int cnt = 0;
             for (int j = i; j < n; ++j)
                 if (!q[j].empty()) { const QOp& o = q[j].front(); cnt += o.type == QOp::KERNEL && o.kd == h.kd && o.block.x == h.block.x && o.block.y == h.block.y && o.block.z == h.block.z; }
             if ((best_heavy && !h.heavy) || cnt > best_n) { best = i; best_n = cnt; best_heavy = h.heavy; }
+        }
+        if (best < 0 && n_wait > 0) {
+            // Every member that still has work stands before the point where it needs its captured tensors: only now does the
+            // stream wait for the capture -- what the members queued before (weight abs-max, candidate tables, the candidate
+            // planes of the weights) ran while the capture passes were still on the GPU.
+            if (!waited && inputs_ready) { HIPCHK(hipStreamWaitEvent(st, inputs_ready, 0)); waited = true; }
+            for (int i = 0; i < n; ++i)
+                if (!q[i].empty() && q[i].front().type == QOp::WAIT) q[i].pop_front();
+            continue;
         }
         if (best < 0) break;
         const QOp& h = q[best].front();
@@ -425,6 +445,14 @@ int q_h2d(Ctx& c, void* dev, const void* host, size_t bytes) {       // (callers
 int q_copy2d(Ctx& c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
     if (!c.grp) { HIPCHK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, c.st)); return 0; }
     QOp op; op.type = QOp::COPY2D; op.dst = dst; op.src = src; op.dpitch = dpitch; op.spitch = spitch; op.width = width; op.height = height;
+    c.grp->q[c.slot].push_back(std::move(op));
+    return 0;
+}
+// from here on the call reads its captured tensors (raw_input / raw_out / raw_grad): inside a group whose caller handed over a
+// "capture done" event, the stream waits for it -- once, when every member has reached this point
+int q_wait_inputs(Ctx& c) {
+    if (c.dry || !c.grp || !c.grp->inputs_ready) return 0;
+    QOp op; op.type = QOp::WAIT;
     c.grp->q[c.slot].push_back(std::move(op));
     return 0;
 }
@@ -943,6 +971,8 @@ struct Pass {
                               // the 8-byte survivor range back and skip the launches of an empty stage B2
     PlaneCache* cache;        // optional: keeps the candidate-expanded plane across the rounds of one call
     EpiCache* ecache;         // optional: keeps k_sweep6's fragment-order epilogue operands across the rounds of one call
+    bool pack_only;           // plan the pass and pack its candidate-expanded operand into `cache`, nothing else (linear_impl: the
+                              // candidate planes of the WEIGHTS depend on no captured tensor -- packed while the capture still runs)
 };
 
 static const long PLANE_BUDGET_DEFAULT = 6L << 30;  // bytes of candidate-expanded plane kept resident per chunk
@@ -1089,6 +1119,34 @@ int run_pass(Ctx& c, Pass& ps) {
     }
     float* epi6 = !epi6_on ? nullptr : ec ? reinterpret_cast<float*>(ec->buf) : c.ws.get<float>(epi6_bytes / 4);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
+    auto pack = [&](Operand& op, char* buf, int Rp, bool shared, int c0, int nc) -> int {
+        PackParams pk = op.pk;
+        pk.Rp = Rp; pk.Kp = Kp; pk.dst = buf;
+        pk.Z = shared ? 1 : ps.Z;
+        pk.C = op.expanded ? nc : 1;
+        pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
+        if (regs6 && !op.expanded) pk.c_inner = 3;                     // k_sweep6: stationary operand in MFMA-fragment order
+        if (bound) pk.c_inner = 3;                                     // k_bound: both operands (one candidate each) in fragment order
+        if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
+        if (op.expanded && ps.crange) {       // pruned pass: only the candidate groups in range, and not the ones already kept
+            pk.crange = ps.crange; pk.c_base = c0;
+            pk.done = (pc && pc->done) ? pc->done : nullptr;
+        }
+        CHK(ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk));
+        return 0;      // (the finish of this pass flags the groups as packed: FinishParams.mark_done)
+    };
+    if (ps.pack_only) {
+        // every candidate of the expanded operand into the module's plane cache, in the layout this pass's sweep streams; the
+        // pass itself (and every later one of the module) then finds the plane packed
+        if (pc && !pc->valid && ps.row.expanded != ps.col.expanded && !ps.crange) {
+            if (ps.row.expanded) CHK(pack(ps.row, rowbuf, Mp, ps.row_zs_shared, 0, ps.eq_n));
+            else CHK(pack(ps.col, colbuf, NpB, ps.col_zs_shared, 0, ps.eq_n));
+            pc->valid = true;
+            if (!c.dry && pc->done) CHK(q_fill(c, pc->done, 1, (size_t)ps.eq_n));
+        }
+        c.ws.off = mark;
+        return 0;
+    }
     if (epi6_on && !c.dry && !(ec && ec->valid)) {
         PrepEpi6Params pe{};
         pe.O = ps.O; pe.Wt = ps.G ? ps.G : ps.O; pe.bias = ps.bias ? ps.bias : zero_bias;
@@ -1114,22 +1172,6 @@ int run_pass(Ctx& c, Pass& ps) {
         CHK(launch_scale(c, ps.s1));
         if (ps.twin) { ps.s2.S = S2; ps.s2.C = ps.eq_n; ps.s2.nblk = ps.s_cs; CHK(launch_scale(c, ps.s2)); }
     }
-    auto pack = [&](Operand& op, char* buf, int Rp, bool shared, int c0, int nc) -> int {
-        PackParams pk = op.pk;
-        pk.Rp = Rp; pk.Kp = Kp; pk.dst = buf;
-        pk.Z = shared ? 1 : ps.Z;
-        pk.C = op.expanded ? nc : 1;
-        pk.c_inner = (stat_ok && op.expanded) ? (pairs ? 2 : 1) : 0;   // k_sweep4 / k_sweep5 stream [row][candidate][K]
-        if (regs6 && !op.expanded) pk.c_inner = 3;                     // k_sweep6: stationary operand in MFMA-fragment order
-        if (bound) pk.c_inner = 3;                                     // k_bound: both operands (one candidate each) in fragment order
-        if (op.expanded && pk.scales) pk.scales += (long)c0 * pk.sc_cs;
-        if (op.expanded && ps.crange) {       // pruned pass: only the candidate groups in range, and not the ones already kept
-            pk.crange = ps.crange; pk.c_base = c0;
-            pk.done = (pc && pc->done) ? pc->done : nullptr;
-        }
-        CHK(ps.i8 ? launch_pack<int8_t>(c, pk) : launch_pack<float>(c, pk));
-        return 0;      // (the finish of this pass flags the groups as packed: FinishParams.mark_done)
-    };
     // fixed planes once
     if (merged7) {
         Operand both = ps.row;              // positive range: scale + upper clamp; negative range: fixed scale + lower clamp
@@ -2079,16 +2121,26 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     float* w_mix = c.ws.get<float>((size_t)ncand * nV * nH);   // general path: candidates of block column h only
     float* a_mix = c.ws.get<float>((size_t)ncand * nA);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small");
+    // (the weight side first: it depends on no captured tensor -- inside a group that was handed a "capture done" event it runs,
+    // with the candidate planes of the weights further down, while the capture passes are still on the GPU)
     if (!fwd_out && (sg.mask & ST_INIT)) {
         const long stw[4] = {0, 0, K, 1};
         CHK(launch_absmax(c, W, stw, 1, 1, N, K, nV, nH, crb_rows, crb_cols, 0, enc_w));
         CHK(launch_interval(c, enc_w, nV * nH, (float)(wq - 0.5), d->init_layerwise, w_iv));
-        CHK(launch_absmax(c, X, stw, 1, 1, M, K, 1, nA, M, crb_acts, d->twin_postgelu ? 1 : 0, enc_a));
-        CHK(launch_interval(c, enc_a, nA, (float)(aq - 0.5), d->init_layerwise, a_iv));
-        if (sg.searches()) {
-            CHK(launch_cands(c, mult, w_iv, ncand, nV * nH, w_cands_ws));
-            CHK(launch_cands(c, mult, a_iv, ncand, nA, a_cands_ws));
+        if (sg.searches()) CHK(launch_cands(c, mult, w_iv, ncand, nV * nH, w_cands_ws));
+    }
+    auto init_activation_side = [&]() -> int {
+        if (!fwd_out && (sg.mask & ST_INIT)) {
+            const long stw[4] = {0, 0, K, 1};
+            CHK(launch_absmax(c, X, stw, 1, 1, M, K, 1, nA, M, crb_acts, d->twin_postgelu ? 1 : 0, enc_a));
+            CHK(launch_interval(c, enc_a, nA, (float)(aq - 0.5), d->init_layerwise, a_iv));
+            if (sg.searches()) CHK(launch_cands(c, mult, a_iv, ncand, nA, a_cands_ws));
         }
+        return 0;
+    };
+    if (fwd_out || !sg.full()) {                 // (quant_forward, the granular entry points: no capture to overlap with)
+        CHK(q_wait_inputs(c));
+        CHK(init_activation_side());
     }
     if (!fwd_out && !sg.searches()) return 0;
 
@@ -2158,6 +2210,57 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     bool host_w_ok = false, host_a_ok = false;
     const int n_rounds = sg.full() ? d->search_round : 1;
     auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
+    // the weight search pass of (round, column block h): reference linear.py:455-495
+    auto w_search_pass = [&](int round, int h, const float* wc, int wc_cs, bool memo_w_on) -> Pass {
+        Pass ps{};
+        ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
+        ps.cache = (keep_planes && nH == 1) ? &plane_w : nullptr;   // (n_H > 1: the table mixes in the current interval)
+        ps.ecache = keep_planes ? &epi_w : nullptr;
+        ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
+        ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
+        ps.scores_out = scores_out ? scores_out + ((long)slot(round, 0) * d->eq_n) * nV : nullptr;
+        ps.scores_out_ld = nV;
+        ps.best_out = best_out ? best_out + (long)slot(round, 0) * nV : nullptr;
+        if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
+        if (!cosm) {
+            ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
+            ps.row = x_operand(false, a_iv, 0);
+            if (twin) { ps.row2 = xneg_operand(); ps.twin_disjoint = true; }    // linear.py:605-606: clamp(.,0,q-1) / clamp(.,-q,0)
+            ps.col = w_operand(true, wc, wc_cs, false);
+            ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 1; ps.sb_div = crb_rows;
+            ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+            ps.s2 = ScaleParams{nullptr, 0, 0, a_neg, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+            ps.bias = bias; ps.bias_axis = 0; ps.bias_zs = 0;
+            ps.O = O; ps.G = G; ps.o_zs = 0; ps.o_bs = 0; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
+            ps.j_mode = 1; ps.j_div = crb_rows;
+            ps.norm = 1.0 / ((double)d->tokens * crb_rows);
+            ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.scache2 = &slice2; ps.host_sync_ok = memo_w_on;
+        } else {
+            // swapped: rows = features of V block z, cols = samples
+            ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
+            ps.row = w_operand(true, wc, wc_cs, true);
+            ps.col = x_operand(false, a_iv, 0);
+            ps.col_zs_shared = 1;
+            ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
+            ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
+            ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
+            ps.O = O; ps.G = nullptr; ps.o_zs = crb_rows; ps.o_bs = 0; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
+            ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 1;
+            ps.norm = 1.0 / (double)d->tokens;
+        }
+        return ps;
+    };
+    if (sg.full()) {
+        // The 100 candidate planes of the weights (8.5 GB per ViT-B calibration over its 48 Linear layers) need the weights and
+        // their candidate table, nothing captured: packed here, before the call waits for its captured tensors.
+        if (keep_planes && nH == 1 && !cosm && (sg.mask & ST_S1)) {
+            Pass pp = w_search_pass(0, 0, w_cands, nV * nH, memo_on);
+            pp.pack_only = true;
+            CHK(run_pass(c, pp));
+        }
+        CHK(q_wait_inputs(c));
+        CHK(init_activation_side());
+    }
     for (int round = 0; round < n_rounds; ++round) {
         // ================= weight search (linear.py:455-495) =================
         // With n_H > 1 the weight search is a coordinate descent over the column blocks: block h is swept with the other
@@ -2171,8 +2274,6 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             if (const auto* hit = memo_w.find(key)) { CHK(write_dev(c, w_iv, *hit)); skip_w = true; g_memo_hits++; host_w = *hit; host_w_ok = true; }
         }
         for (int h = 0; h < nH && !skip_w && (sg.mask & ST_S1); ++h) {
-            Pass ps{};
-            ps.i8 = i8; ps.twin = twin; ps.epi = epi; ps.wt_mode = wt_mode; ps.eq_n = d->eq_n; ps.K = K;
             const float* wc = w_cands;
             int wc_cs = nV * nH;
             if (general && nH > 1) {
@@ -2186,40 +2287,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                 }
                 wc = w_mix;
             }
-            ps.cache = (keep_planes && nH == 1) ? &plane_w : nullptr;   // (n_H > 1: the table mixes in the current interval)
-            ps.ecache = keep_planes ? &epi_w : nullptr;
-            ps.nj = nV; ps.cands = w_cands; ps.cand_cs = nV * nH; ps.cand_js = nH; ps.cand_off = h;
-            ps.interval = w_iv; ps.out_js = nH; ps.out_off = h;
-            ps.scores_out = scores_out ? scores_out + ((long)slot(round, 0) * d->eq_n) * nV : nullptr;
-            ps.scores_out_ld = nV;
-            ps.best_out = best_out ? best_out + (long)slot(round, 0) * nV : nullptr;
-            if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
-            if (!cosm) {
-                ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
-                ps.row = x_operand(false, a_iv, 0);
-                if (twin) { ps.row2 = xneg_operand(); ps.twin_disjoint = true; }    // linear.py:605-606: clamp(.,0,q-1) / clamp(.,-q,0)
-                ps.col = w_operand(true, wc, wc_cs, false);
-                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 1; ps.sb_div = crb_rows;
-                ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
-                ps.s2 = ScaleParams{nullptr, 0, 0, a_neg, w_cands, nV, 1, 0.f, 0, 0, nullptr};
-                ps.bias = bias; ps.bias_axis = 0; ps.bias_zs = 0;
-                ps.O = O; ps.G = G; ps.o_zs = 0; ps.o_bs = 0; ps.o_ms = N; ps.o_ns = 1; ps.o_inner = INT_MAX;
-                ps.j_mode = 1; ps.j_div = crb_rows;
-                ps.norm = 1.0 / ((double)d->tokens * crb_rows);
-                ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.scache2 = &slice2; ps.host_sync_ok = memo_w_on;
-            } else {
-                // swapped: rows = features of V block z, cols = samples
-                ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
-                ps.row = w_operand(true, wc, wc_cs, true);
-                ps.col = x_operand(false, a_iv, 0);
-                ps.col_zs_shared = 1;
-                ps.use_s1 = i8; ps.s_cs = nV; ps.sb_mode = 2; ps.sb_div = nV;
-                ps.s1 = ScaleParams{a_iv, 0, 0, 0.f, w_cands, nV, 1, 0.f, 0, 0, nullptr};
-                ps.bias = bias; ps.bias_axis = 1; ps.bias_zs = crb_rows;
-                ps.O = O; ps.G = nullptr; ps.o_zs = crb_rows; ps.o_bs = 0; ps.o_ms = 1; ps.o_ns = N; ps.o_inner = INT_MAX;
-                ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = 1;
-                ps.norm = 1.0 / (double)d->tokens;
-            }
+            Pass ps = w_search_pass(round, h, wc, wc_cs, memo_w_on);
             CHK(run_pass_pruned(c, ps));
         }
         if (memo_w_on && !skip_w) { CHK(read_dev(c, w_iv, nV * nH, val)); memo_w.entries.push_back({key, val}); g_memo_misses++; host_w = val; host_w_ok = true; }
@@ -2320,6 +2388,7 @@ int matmul_impl(const p4v_matmul_desc* d, const float* A, const float* B, const 
     if (wt_mode == 1 && !G && !fwd_out && sg.searches()) return fail(P4V_ERR_INVALID, "matmul: hessian metric needs raw_grad");
     if (d->sos && !split) return fail(P4V_ERR_INVALID, "matmul: sos needs d_split");
     cvt_bias(c);     // (first call of the process: probe the conversion quant16_sat8 relies on)
+    CHK(q_wait_inputs(c));     // (inside a group with a "capture done" event: everything below reads captured tensors)
     const int ncand = d->eq_n + 1;
     const int NSPLIT = 20;  // matmul.py:636
 
@@ -2540,6 +2609,7 @@ int conv_impl(const p4v_conv_desc* d, const float* W, const float* bias, const f
     const int aq = aquant ? (1 << (d->a_bit - 1)) : 0;
     if (aquant && !d->channelwise) return fail(P4V_ERR_UNSUPPORTED, "conv: the layer-wise class cannot search activations (reference conv.py:420 raises IndexError); use a_bit=32");
     cvt_bias(c);     // (first call of the process: probe the conversion quant16_sat8 relies on)
+    CHK(q_wait_inputs(c));     // (inside a group with a "capture done" event: everything below reads captured tensors)
     int epi, wt_mode;
     metric_epi(d->metric, &epi, &wt_mode);
     const bool cosm = epi == EPI_COS;
@@ -2838,7 +2908,7 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
 }
 
 
-int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream) {
+int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream, void* inputs_ready_event) {
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(P4V_ERR_INVALID, "p4v_calibrate_group: bad job list");
     if (n_jobs == 0) return 0;
     for (int i = 0; i < n_jobs; ++i) {
@@ -2854,6 +2924,7 @@ int p4v_calibrate_group(p4v_group_job* jobs, int32_t n_jobs, void* stream) {
     for (int i = 0; i < n_jobs; ++i) g.mirrors[i] = tune(TUNE_B1_PATH) == 8 ? nullptr : group_mirror(g.st, dev, i);
     g.stat_on = g_stat_on;
     g.stat_recs = g_stat_on ? &g_stat_recs : nullptr;
+    g.inputs_ready = (hipEvent_t)inputs_ready_event;
     g_launch_cnt[3].fetch_add(1, std::memory_order_relaxed);
     std::vector<std::string> errs(n_jobs);
     std::atomic<long> memo_hits{0}, memo_misses{0};

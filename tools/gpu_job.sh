@@ -26,7 +26,7 @@ for step in "$@"; do
              python tools/kstats_db.py --busy "$O/profg$n/*.db" >> $O/bench_group${n}_kernel_stats.txt
              head -52 $O/bench_group${n}_kernel_stats.txt | cut -c1-170; tail -8 $O/bench_group${n}_kernel_stats.txt | cut -c1-200; rm -rf $O/profg$n ;;
     prodprof) # profile of the production step, joined with the engine's launch records (tools/prof_join.py); arg = output stem
-             stem=${arg:-r5_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
+             stem=${arg:-r6_production_by_stage}; T=/tmp/pp_$TAG; rm -rf $T; mkdir -p $T
              ( cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $T/trace -o t -- python $R/bench.py --profile --steps 3 --warmup 2 --dump-launches $T/launches.json > $O/prodprof_bench.json 2> $O/prodprof_bench.err )
              for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
                tag=$(echo $pass | cut -d' ' -f1)
