@@ -178,7 +178,7 @@ int p4v_conv_calibrate(const p4v_conv_desc* desc, const float* d_weight, const f
  *   P4V_JOB_CONV    desc = p4v_conv_desc     in = {weight, bias, x, raw_out, raw_grad}   out = {w_interval, a_interval, NULL}
  * `status` receives the member's own status; the call returns the first non-zero one (p4v_last_error() has its message).
  * ---------------------------------------------------------------------------------------- */
-enum p4v_job_kind_ { P4V_JOB_LINEAR = 0, P4V_JOB_MATMUL = 1, P4V_JOB_CONV = 2 };
+enum p4v_job_kind { P4V_JOB_LINEAR = 0, P4V_JOB_MATMUL = 1, P4V_JOB_CONV = 2 };
 typedef struct p4v_group_job {
     int32_t kind;
     int32_t status;
@@ -189,7 +189,7 @@ typedef struct p4v_group_job {
     void* workspace;
     size_t workspace_bytes;
 } p4v_group_job;
- *
+/*
  * `inputs_ready_event` (hipEvent_t, may be NULL): the members' CAPTURED tensors (x / raw_out / raw_grad, A / B) are complete once
  * this event has fired -- the caller recorded it behind its capture passes, which may still be running on other streams.  The
  * call then starts at once: what needs no captured tensor (weight abs-max, candidate tables, the 100 candidate planes of every

@@ -184,7 +184,7 @@ def load():
     lib.p4v_launch_counters.restype = C.c_int
     lib.p4v_launch_counters.argtypes = [C.POINTER(C.c_int64), C.c_int]
     lib.p4v_calibrate_group.restype = C.c_int
-    lib.p4v_calibrate_group.argtypes = [C.POINTER(GroupJob), C.c_int32, vp]
+    lib.p4v_calibrate_group.argtypes = [C.POINTER(GroupJob), C.c_int32, vp, vp]
     _lib = lib
     return lib
 

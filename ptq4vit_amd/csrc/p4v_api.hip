@@ -1206,15 +1206,22 @@ int run_pass(Ctx& c, Pass& ps) {
             if (!c.dry && pc->done) CHK(q_fill(c, pc->done, 1, (size_t)ps.eq_n));
         }
         if (g_stat_on && ps.crange && !c.dry) {     // roofline step only: how many of this launch's candidates run
+            // From what the host knows WITHOUT another round trip wherever it does -- the timed calibration must make the same
+            // launches, in the same issue rounds, as an untimed one (inside a group an extra synchronisation regroups the members):
+            // the survivor range the pruned pass read back anyway (stages A2 / B2 under the pass memo), or "one candidate" (stage B1
+            // of a single score block: the range holds the slice winner).  Only a caller without either reads the range back here.
             int h[2] = {0, 0};
-            CHK(q_d2h(c, h, ps.crange, sizeof h));
-            CHK(q_sync(c));
+            const bool host_knows = ps.host_hi > ps.host_lo;
+            const bool one_cand = !host_knows && g_stage == 2 && ps.nj == 1;
+            if (host_knows) { h[0] = ps.host_lo; h[1] = ps.host_hi; }
+            else if (one_cand) { h[0] = c0; h[1] = c0 + 1; }
+            else { CHK(q_d2h(c, h, ps.crange, sizeof h)); CHK(q_sync(c)); }
             const int lo = std::max(h[0], c0), hi = std::min(h[1], c0 + nc);
             g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
-            if ((rblk || rblk_z) && ps.nj <= 64) {               // equal-sized score blocks, each on its own range
+            if ((rblk || rblk_z) && ps.nj <= 64 && !one_cand) {               // equal-sized score blocks, each on its own range
                 int hb[128];
-                CHK(q_d2h(c, hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj));
-                CHK(q_sync(c));
+                if (host_knows && ps.host_rblk && ps.nj <= 4) std::copy(ps.host_rblk, ps.host_rblk + 2 * ps.nj, hb);
+                else { CHK(q_d2h(c, hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj)); CHK(q_sync(c)); }
                 double sum = 0;
                 for (int j = 0; j < ps.nj; ++j) sum += std::max(0, std::min(std::min(hb[2 * j + 1], h[1]), c0 + nc) - std::max(std::max(hb[2 * j], h[0]), c0));
                 g_exec_frac = sum / ((double)nc * ps.nj);
@@ -1913,7 +1920,7 @@ template <int KS> int launch_sos_split_ks(Ctx& c, const SosSplitParams& kp, int 
 SelectParams sos_select_params(const SosSplitJob& j, const float* scores) {
     return SelectParams{scores, j.kp.C, 1, j.cands, 1, 0, 0, j.split, 0, 0, j.A_iv, j.aux_div, j.scores_out, j.scores_out_ld, j.best_out};
 }
-int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, float* scores) {
+int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, float* scores, int known_cands = -1) {
     const int slots = kp.halves * 4;
     float* part = c.ws.get<float>((size_t)kp.C * kp.Z * slots);
     if (!c.ws.ok()) return fail(P4V_ERR_WORKSPACE, "workspace too small: need >= %zu bytes", c.ws.off);
@@ -1922,7 +1929,8 @@ int sos_sweep(Ctx& c, SosSplitJob& j, SosSplitParams kp, const int* crange, floa
         CHK(q_fill(c, part, 0, sizeof(float) * (size_t)kp.C * kp.Z * slots));   // slots of all-padding waves
         const int KS = kp.K <= 64 ? 32 : kp.K <= 144 ? 72 : 100;
         double frac = 1.0;
-        if (g_stat_on && crange) {
+        if (g_stat_on && crange && known_cands >= 0) frac = (double)known_cands / kp.C;      // (no extra round trip: see run_pass)
+        else if (g_stat_on && crange) {
             int h[2] = {0, kp.C};
             CHK(q_d2h(c, h, crange, sizeof h));
             CHK(q_sync(c));
@@ -1992,21 +2000,23 @@ int run_sos_split_pruned_impl(Ctx& c, SosSplitJob& j) {
     { const int r_ = sos_sweep(c, j, a, nullptr, SA); g_stage = 0; if (r_) return r_; }
     CHK(enqueue(c, KERN(PruneParams, k_prune_pick), dim3(1), dim3(256), 0, pp));
     g_stage = 2;
-    { const int r_ = sos_sweep(c, j, kp, r1, SB); g_stage = 0; if (r_) return r_; }   // B1
+    { const int r_ = sos_sweep(c, j, kp, r1, SB, 1); g_stage = 0; if (r_) return r_; }   // B1 (the slice winner)
     pp.r_out = r2;                                // (+ the selection from its totals when nothing else survives)
     if (!c.dry) {
         SelectParams hsl = sos_select_params(j, SB);
         attach_mirror(hsl);
         CHK(enqueue(c, KERN(HullParams, k_prune_hull), dim3(1), dim3(256), 0, HullParams{pp, hsl}));
     }
+    int survivors = -1;
     if (j.host_sync_ok && !c.dry) {
         int h[2] = {0, 1};
         CHK(q_d2h(c, h, r2, sizeof h));
         CHK(q_sync(c));
         if (h[0] >= h[1]) { PRUNE_COUNT(1); c.ws.off = mark; return 0; }
+        survivors = std::max(0, std::min(h[1], kp.C) - std::max(h[0], 0));
     }
     g_stage = 3;
-    { const int r_ = sos_sweep(c, j, kp, r2, S2); g_stage = 0; if (r_) return r_; }   // B2
+    { const int r_ = sos_sweep(c, j, kp, r2, S2, survivors); g_stage = 0; if (r_) return r_; }   // B2
     if (!c.dry) {
         CHK(enqueue(c, KERN(MergeParams, k_merge_scores), dim3(1), dim3(256), 0, MergeParams{S2, SB, kp.C}));
     }

@@ -115,9 +115,12 @@ def run_job(job):
     return job
 
 
-def calibrate_group(jobs):
+def calibrate_group(jobs, inputs_ready=None):
     """calibration_step2 of all `jobs` in ONE p4v_calibrate_group call on the current stream: the members search in lock
-    step, every kernel launch of the same kind is issued once for all of them.  Results bit-identical to run_job on each."""
+    step, every kernel launch of the same kind is issued once for all of them.  Results bit-identical to run_job on each.
+    `inputs_ready`: a torch.cuda.Event recorded behind the capture passes that fill the jobs' captured tensors -- the call
+    starts at once with the work that needs none of them (weight abs-max, candidate tables, the candidate planes of the
+    weights) and makes its stream wait for the event where the first captured tensor is read.  None: the tensors are ready."""
     jobs = list(jobs)
     if not jobs:
         return jobs
@@ -143,7 +146,8 @@ def calibrate_group(jobs):
             g.out[k] = outs[k].data_ptr() if outs[k] is not None else None
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):
-        rc = lib.p4v_calibrate_group(arr, len(jobs), stream_ptr(dev))
+        ev = C.c_void_p(inputs_ready.cuda_event) if inputs_ready is not None else C.c_void_p(0)
+        rc = lib.p4v_calibrate_group(arr, len(jobs), stream_ptr(dev), ev)
     _lib.check(rc, "p4v_calibrate_group")
     del keep
     return jobs

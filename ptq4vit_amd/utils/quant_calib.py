@@ -743,12 +743,18 @@ class HessianQuantCalibrator(QuantCalibrator):
         if errors:
             raise errors[0]
 
-    def _search_grouped(self, names, n_calls):
+    def _search_grouped(self, names, n_calls, inputs_ready=None):
         """Independent modules (sequential=False) searched TOGETHER: `n_calls` p4v_calibrate_group calls (one host thread + HIP
         stream each), every call running the calibration_step2 of its modules in lock step with the kernel launches of the
         same kind issued once for all of them (csrc/p4v_api.hip, Group).  Replaces the loop of the reference's calibrator
         (utils/quant_calib.py:371-372).  Results do not depend on the partition: a grouped kernel runs every module's own
-        code on its own parameters and scratch."""
+        code on its own parameters and scratch.
+
+        `inputs_ready`: the event recorded behind the capture passes.  The group calls then start while the capture is still on
+        the GPU -- the library issues what needs no captured tensor first (weight abs-max, candidate tables, the 100 candidate
+        planes of every Linear's weights: 8.5 GB of k_pack output per ViT-B calibration) and waits for the event on its own
+        stream where the first captured tensor is read.  Only when preparing the calls launches no torch kernel on captured data
+        (every cached tensor dense fp32 on the device: no `.contiguous()` / `.to()` copy); otherwise the streams wait first."""
         import threading
         import time
         from .. import engine
@@ -759,8 +765,23 @@ class HessianQuantCalibrator(QuantCalibrator):
         streams = engine.side_streams(dev, n_calls)
         if not hasattr(self, "_module_ms"):
             self._module_ms = {}
-        for s in streams:
-            s.wait_stream(main)                       # the captured tensors were produced on the current stream
+        def dense(t):
+            return t is None or (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+
+        def prep_is_copy_free(m):
+            ri = m.raw_input
+            ins = list(ri) if isinstance(ri, (list, tuple)) else [ri]
+            if not isinstance(ri, (list, tuple)) and not dense(ri):          # (matmul operands are read through their strides)
+                return False
+            w = getattr(m, "weight", None)
+            return (all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in ins) and dense(m.raw_out)
+                    and dense(getattr(m, "raw_grad", None)) and (w is None or dense(w.data)) and _groupable(m))
+        early = (inputs_ready is not None and os.environ.get("P4V_EARLY_SEARCH", "1") != "0"
+                 and all(prep_is_copy_free(self.wrapped_modules[n]) for n in names))
+        if not early:
+            inputs_ready = None
+            for s in streams:
+                s.wait_stream(main)                   # the captured tensors were produced on the current stream
         keep = [(m.raw_input, m.raw_out, getattr(m, "raw_grad", None)) for m in (self.wrapped_modules[n] for n in names)]
         # modules of one kind are dealt over the calls, so that every call holds the same mixture (and its launches group)
         def kind(n):
@@ -805,7 +826,7 @@ class HessianQuantCalibrator(QuantCalibrator):
                             batch.append(n); jobs.append(job); acc += job.need
                         if not batch:
                             continue
-                        engine.calibrate_group(jobs)
+                        engine.calibrate_group(jobs, inputs_ready=inputs_ready)
                         for n, j in zip(batch, jobs):
                             m = self.wrapped_modules[n]
                             m.calibration_install(j)
@@ -985,7 +1006,7 @@ class HessianQuantCalibrator(QuantCalibrator):
             if concurrent:
                 if grouped:
                     calls = 1 if n_streams == 1 else (getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "3")))
-                    self._search_grouped(grp, calls)
+                    self._search_grouped(grp, calls, inputs_ready=cap_done)
                 else:
                     self._search_concurrent(grp, n_streams)
                 if cap_done is not None:            # (everything is synchronised now) when the capture really ended
