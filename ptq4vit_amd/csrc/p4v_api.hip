@@ -224,7 +224,10 @@ template <typename P, void (*K1)(P)> struct Kern1 {      // kernels off the grou
 #define KERN1_T(P, NAME, ...) (Kern1<P, NAME<__VA_ARGS__>>::desc())
 
 constexpr int MIR_SLOT = 2048, MIR_SLOTS = 3;
-constexpr size_t MIRROR_BYTES = 128 + sizeof(float) * MIR_SLOT * MIR_SLOTS;
+// header of a mirror block, in ints: [0,1] / [2,3] survivor ranges of the two tiers, [4] the slice's weight share, [16..79] /
+// [80..143] the per-score-block ranges of the two tiers (<= MIR_BLK blocks: the heads of an attention matmul), then the interval slots
+constexpr int MIR_HDR = 160, MIR_BLK = 32, MIR_RB1 = 16, MIR_RB2 = 80;
+constexpr size_t MIRROR_BYTES = sizeof(int) * MIR_HDR + sizeof(float) * MIR_SLOT * MIR_SLOTS;
 inline int* mirror_alloc() {
     void* p = nullptr;
     if (hipHostMalloc(&p, MIRROR_BYTES, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
@@ -958,7 +961,7 @@ struct Pass {
     const int* crange_blk;    // ... and per score block [2 * nj] (k_prune_hull's rblk): honoured where the sweep kernel's tiles lie inside
                               // one score block (run_pass decides; otherwise every block sweeps `crange`, a superset)
     int host_lo, host_hi;     // what the host read of `crange` (host_hi > host_lo: known) -- the launch geometry is planned for the
-    const int* host_rblk;     // candidates that will run -- and of `crange_blk` (nj <= 4; nullptr: unknown): closed blocks are not launched
+    const int* host_rblk;     // candidates that will run -- and of `crange_blk` (nj <= MIR_BLK; nullptr: unknown): closed blocks are not launched
     float* scores_keep;
     bool no_select;
     bool prunable;            // set by the *_impl callers for passes whose score is minus a sum of non-negative terms
@@ -1220,7 +1223,7 @@ int run_pass(Ctx& c, Pass& ps) {
             g_exec_frac = (double)std::max(0, hi - lo) / (double)nc;
             if ((rblk || rblk_z) && ps.nj <= 64 && !one_cand) {               // equal-sized score blocks, each on its own range
                 int hb[128];
-                if (host_knows && ps.host_rblk && ps.nj <= 4) std::copy(ps.host_rblk, ps.host_rblk + 2 * ps.nj, hb);
+                if (host_knows && ps.host_rblk && ps.nj <= MIR_BLK) std::copy(ps.host_rblk, ps.host_rblk + 2 * ps.nj, hb);
                 else { CHK(q_d2h(c, hb, rblk ? rblk : rblk_z, sizeof(int) * 2 * ps.nj)); CHK(q_sync(c)); }
                 double sum = 0;
                 for (int j = 0; j < ps.nj; ++j) sum += std::max(0, std::min(std::min(hb[2 * j + 1], h[1]), c0 + nc) - std::max(std::max(hb[2 * j], h[0]), c0));
@@ -1812,8 +1815,8 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
     // the survivors, and -- when there are none besides stage B1's candidates -- the pass's selection from its totals
     pp.r_out = r2; pp.rblk = rblk2;
     int* hm = (ps.host_sync_ok && !c.dry && tune(TUNE_B1_PATH) != 8) ? host_mirror(c) : nullptr;
-    pp.r_host = hm; pp.rblk_host = hm ? hm + 8 : nullptr;
-    int hblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // host copy of the per-block ranges stage A2 / B2 run on (nj <= 4)
+    pp.r_host = hm; pp.rblk_host = hm ? hm + MIR_RB1 : nullptr;
+    int hblk[2 * MIR_BLK] = {};                             // host copy of the per-block ranges stage A2 / B2 run on (nj <= MIR_BLK)
     int hlo = 0, hhi = 0;
     bool hblk_ok = false;
     const bool hull_selects = !ps.scores_out && ps.interval && (virt || ps.nj <= 32);   // (its non-virt selection is serial over the blocks)
@@ -1844,7 +1847,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         if (h[0] >= h[1]) return select_without_b2();
         nsurv = h[1] - h[0];
         hlo = h[0]; hhi = h[1];
-        if (hm && ps.nj <= 4) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[8 + i]; hblk_ok = true; }
+        if (hm && ps.nj <= MIR_BLK) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[MIR_RB1 + i]; hblk_ok = true; }
     }
     // second tier: many survivors of a slice that holds well under all of the weight -> sweep THEM over the larger slice first
     const int* rB = r2;
@@ -1859,15 +1862,15 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
         if (ps.twin) sliced2(a2.row2.pk);
         a2.cache = ps.col.expanded ? ps.cache : ps.cache ? &sc2->aplane : nullptr;
         a2.ecache = nullptr; a2.scores_keep = SA2; a2.no_select = true; a2.crange = r2; a2.crange_blk = rblk2;
-        int hblk_a2[8];                                   // (stage A2 runs on the first tier's ranges; the second hull overwrites hblk)
-        std::copy(hblk, hblk + 8, hblk_a2);
+        int hblk_a2[2 * MIR_BLK];                         // (stage A2 runs on the first tier's ranges; the second hull overwrites hblk)
+        std::copy(hblk, hblk + 2 * MIR_BLK, hblk_a2);
         a2.host_lo = hlo; a2.host_hi = hhi; a2.host_rblk = hblk_ok ? hblk_a2 : nullptr;
         a2.S1_pre = S1s; a2.S2_pre = S2s; a2.s_ready = true;
         g_stage = 4;
         { const int r_ = run_pass(c, a2); g_stage = 0; if (r_) return r_; }
         if (!c.dry) {
             PruneParams pp2 = pp;                 // same bound L* (stage B1's totals), the tighter partial sums, hull into r3
-            pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3; pp2.rblk_host = hm ? hm + 16 : nullptr;
+            pp2.SA = SA2; pp2.r_out = r3; pp2.r_host = hm ? hm + 2 : nullptr; pp2.rblk = rblk3; pp2.rblk_host = hm ? hm + MIR_RB2 : nullptr;
             CHK(enqueue(c, KERN(HullParams, k_prune_hull), dim3(1), dim3(256), 0, HullParams{pp2, hsl}));
             int h[2] = {0, 1};
             if (!hm) CHK(q_d2h(c, h, r3, sizeof h));
@@ -1877,7 +1880,7 @@ int run_pass_pruned_impl(Ctx& c, Pass& ps) {
             if (h[0] >= h[1]) return select_without_b2();
             rB = r3; rBblk = rblk3;
             hlo = h[0]; hhi = h[1];
-            if (hm && ps.nj <= 4) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[16 + i]; }
+            if (hm && ps.nj <= MIR_BLK) { for (int i = 0; i < 2 * ps.nj; ++i) hblk[i] = reinterpret_cast<volatile int*>(hm)[MIR_RB2 + i]; }
             else hblk_ok = false;
         }
     }
@@ -2066,7 +2069,7 @@ struct MirrorScope {
         float* base = (on && !c.dry && tune(TUNE_B1_PATH) != 8) ? reinterpret_cast<float*>(host_mirror(c)) : nullptr;
         const float* devs[MIR_SLOTS] = {a, b, d3};
         for (int i = 0; i < MIR_SLOTS; ++i)
-            g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + 32 + i * MIR_SLOT : nullptr, false, 0};
+            g_mir[i] = IvMirror{(base && devs[i]) ? devs[i] : nullptr, base ? base + MIR_HDR + i * MIR_SLOT : nullptr, false, 0};
     }
     ~MirrorScope() { for (auto& m : g_mir) m = IvMirror{}; }
     MirrorScope(const MirrorScope&) = delete;

@@ -3962,7 +3962,7 @@ struct PruneParams { const float* SA; const float* SB; int C, nj; float margin; 
                      int virt; int* best; const float* cands; int cand_cs, cand_js, cand_off; float* vrow;
                      int* r_host;         // optional mirror of r_out in mapped host memory (read by the host after its stream sync)
                      int* rblk;           // optional per-score-block survivor ranges [2 * nj] (see prune_hull)
-                     int* rblk_host; };   // optional mirror of rblk in mapped host memory, written when nj <= 4 (8 ints)
+                     int* rblk_host; };   // optional mirror of rblk in mapped host memory, written when nj <= 32 (64 ints)
 // (one workgroup of 256 threads; the score blocks one after the other, the candidates of a block across the threads)
 // r_out = hull over the blocks of stage A's first maxima
 #define PRUNE_WIDE_NJ 64        // from this many score blocks on: one THREAD per block (channel-wise weights: hundreds of blocks)
@@ -4104,7 +4104,7 @@ __device__ __forceinline__ bool prune_hull(const PruneParams& p, float* sv, int*
             for (int j = threadIdx.x; j < p.nj; j += 256) {
                 const int l = per_blk ? sblk[3 * j] : lo_s, h = per_blk ? sblk[3 * j + 1] : hi_s;
                 p.rblk[2 * j] = l; p.rblk[2 * j + 1] = h;
-                if (p.rblk_host && p.nj <= 4) { p.rblk_host[2 * j] = l; p.rblk_host[2 * j + 1] = h; }
+                if (p.rblk_host && p.nj <= 32) { p.rblk_host[2 * j] = l; p.rblk_host[2 * j + 1] = h; }
             }
         }
         else if (!per_blk) { for (int j = threadIdx.x; j < p.nj; j += 256) { p.rblk[2 * j] = lo_s; p.rblk[2 * j + 1] = hi_s; } }
