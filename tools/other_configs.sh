@@ -20,5 +20,5 @@ one "config 1: vit_small/224 PTQ4ViT W8A8 x32"          --model vit_small_patch1
 one "config 2a (headline): vit_base/224 PTQ4ViT W8A8 x32"  --steps 10 --warmup 3
 one "config 2b: vit_base/224 PTQ4ViT W6A6 x32"          --bits 6 --steps 10 --warmup 3
 one "vit_base/224 BasePTQ (cosine) W8A8 x32"            --config BasePTQ --steps 10 --warmup 3
-one "config 3: swin_base/384 PTQ4ViT W8A8 x128"         --model swin_base_patch4_window12_384 --calib 128 --steps 2 --warmup 1
-one "config 4: vit_base/384 PTQ4ViT W6A6 x128"          --model vit_base_patch16_384 --bits 6 --calib 128 --steps 2 --warmup 1
+one "config 3: swin_base/384 PTQ4ViT W8A8 x128"         --model swin_base_patch4_window12_384 --calib 128 --steps 2 --warmup 2
+one "config 4: vit_base/384 PTQ4ViT W6A6 x128"          --model vit_base_patch16_384 --bits 6 --calib 128 --steps 2 --warmup 2
