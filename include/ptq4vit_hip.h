@@ -21,8 +21,8 @@
  *     *_quant_forward, p4v_quantize_i8 and p4v_fake_quant never synchronise;
  *   - return value 0 = ok, <0 = error; p4v_last_error() returns a per-thread message;
  *   - safe to call concurrently on different devices / streams: the only state outside the call is per calling
- *     thread (error string, the optional launch timing of p4v_stats_*) and the two p4v_debug_* words, which exist
- *     for A/B measurements and are never written in production.
+ *     thread (error string, the optional launch timing of p4v_stats_*); the process-wide A/B words of
+ *     ptq4vit_hip_debug.h exist for measurements only and are never written in production.
  *
  * Data layout (all fp32, row-major, K contiguous unless strides are given):
  *   Linear  x[M][K], weight[N][K], bias[N], out/grad[M][N]        (M = batch*tokens)
@@ -430,21 +430,8 @@ int p4v_stats_get(p4v_kernel_stats* out);
  * desc.reserved bit 3).  Tests and bench.py use them to assert WHICH path produced a result.  `out4` may be NULL. */
 int p4v_prune_counters(int64_t* out4, int reset);
 
-/* A/B switches for measurements and kernel-vs-kernel agreement tests; never needed in production (default 0).
- * `variant` disables individual kernel paths (bit list in csrc/p4v_api.hip), `force_generic` routes every int8 sweep
- * through the generic kernel.  Process-wide, relaxed atomics: set them while no call is in flight. */
-int p4v_debug_set_variant(int variant, int force_generic);
-/* Overrides of launch heuristics: key 0 / 1 / 2 / 3 = candidate groups of k_sweep6 / k_sweep2 / k_sweep2g / k_sweep7
- * (0 = cost model), key 4 = print the launch plans to stderr, key 5 = workgroup order of k_sweep7 + 1, key 6 = k_sweep6 prologue
- * of the cost model (0.1 us), keys 9-14 = slice sizes / tiers of the pruned passes, key 12 = path switches for A/B runs (list in
- * csrc/p4v_api.hip: e.g. 8 read-backs by copy, 9 no per-score-block ranges, 11 the round-4 quantiser). */
-int p4v_debug_set_tuning(int key, int value);
-/* The row selection of the exact pruning alone (k_topk_rows; csrc/p4v_api.hip::slice_fill runs it on the per-sample metric
- * weight): for each of `segs` segments of `n` fp32 masses, d_mass [segs][n], the segment-local indices of the k heaviest
- * entries in ASCENDING index order, d_idx [segs][k]; among equal masses the lowest indices are taken; negative masses
- * count as the lightest.  Exposed for the tests: a repeated or missing row would make the slice's partial sums an
- * invalid bound.  1 <= k <= n. */
-int p4v_debug_topk_rows(const float* d_mass, int segs, int n, int k, int32_t* d_idx, void* stream);
+/* The A/B switches and test-only entry points (p4v_debug_*) are declared in ptq4vit_hip_debug.h: not part of the drop-in
+ * boundary, never called in production. */
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/ptq4vit_hip.h"
+#include "../../include/ptq4vit_hip_debug.h"
 #include "p4v_kernels.h"
 
 using namespace p4v;
@@ -107,6 +108,7 @@ std::atomic<long long> g_prune_cnt[4];
 //   64  no folding of the twin's negative plane in the activation search   128  old candidate-group heuristic
 //   256 no k_sweep2g (one candidate per pass at large K)            512  no pass memoisation
 //   1024 no candidate-plane cache (every pass re-packs its candidate-expanded operand)
+//   2048 cosine Linear searches on k_sweep2 (swapped operands, one GEMM per V block) instead of k_sweep6
 //   4096 quant_forward / folded-target GEMMs on the generic k_sweep instead of k_sweep2
 //   8192 no candidate groups for the generic k_sweep
 //   16384 k_sweep6 without the separate launch of the last, partial wave of workgroups
@@ -702,6 +704,11 @@ int launch_sweep4(Ctx& c, const Sweep3Params& p, int epi, int cgroups, bool pair
 
 template <int KT, int RB>
 int launch_sweep6_kt(Ctx& c, const Sweep3Params& p, int epi, dim3 grid, size_t lds, const StatInfo* si) {
+    if constexpr (RB == 2) {       // cosine (plain = activation search, transposed = weight search): one wave per SIMD only
+        if (epi == EPI_COS) return enqueue(c, KERN_T(Sweep3Params, k_sweep6, EPI_COS, KT, 2), grid, dim3(256), lds, p, si);
+        if (epi == EPI_COS_T) return enqueue(c, KERN_T(Sweep3Params, k_sweep6, EPI_COS_T, KT, 2), grid, dim3(256), lds, p, si);
+    }
+    if (epi == EPI_COS || epi == EPI_COS_T) return fail(P4V_ERR_UNSUPPORTED, "k_sweep6: the cosine epilogue has no 8-wave instance");
     P4V_EPI4(epi, return enqueue(c, KERN_T(Sweep3Params, k_sweep6, E, KT, RB), grid, dim3(512 / RB), lds, p, si))
 }
 
@@ -753,7 +760,7 @@ int launch_sweep6_part(Ctx& c, const Sweep3Params& p, int epi, int cgroups) {
     // 32-row blocks per wave: 2 = 4 waves, one per SIMD (default: bound by its own VALU + MFMA issue, LDS-light);
     // 1 = 8 waves, two per SIMD (A/B variant 32: hides the VALU work but doubles the fragment reads -> LDS-bound;
     // both measure 3.33 ms per fc1 search round on MI355X)
-    const int rb = (g_variant & 32) ? 1 : 2;
+    const int rb = ((g_variant & 32) && epi != EPI_COS && epi != EPI_COS_T) ? 1 : 2;
     const int nw = 8 / rb;
     const size_t lds = (size_t)3 * p.ktiles * 4096 + (size_t)(per + 1) * 2 * nw * sizeof(float) + (size_t)per * nw * sizeof(float) + 64 * sizeof(float) + 256;
     dim3 grid(p.ntile > 0 ? p.ntile : p.stiles * p.ttiles, 1, cgroups);
@@ -955,6 +962,7 @@ struct Pass {
     float* scores_out; int scores_out_ld;
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
+    bool cos6;                // cosine of a plain Linear layer on k_sweep6 (rows = samples, cols = features, Z = 1): set by linear_impl
     bool twin_disjoint;       // twin whose two ranges never overlap (post-GELU): k_sweep7 may stream them as one merged plane
     // exact candidate pruning (run_pass_pruned): device-side candidate range, scores kept for the next stage, no selection
     const int* crange;
@@ -1023,11 +1031,12 @@ int run_pass(Ctx& c, Pass& ps) {
                        (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0))) &&
                        (ps.sb_mode != 1 || ps.s_cs == 1 || ps.sb_div % 32 == 0) && (ps.eq_n == 1 || ps.crange);
     const bool b1_generic = bound || (g_stage == 2 && tune(TUNE_B1_PATH) == 1);    // (tuning 12=1: experiment, the bound pass on k_sweep2)
-    const bool stat_ok = !b1_generic && !ps.store_out && ps.i8 && !ps.twin && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
+    const bool stat_ok = !b1_generic && !ps.store_out && ps.i8 && !ps.twin && (ps.epi != EPI_COS || ps.cos6) && !g_force_v1 && !(g_variant & 4) && ps.Z == 1 &&
                          ps.sb_mode == 1 && blocks64 && (ps.row.expanded != ps.col.expanded) &&
                          rup(ps.K, 64) <= 768 && ps.o_bs == 0 && ps.o_nbs == 0;
     const bool b1_lds = g_stage == 2 && tune(TUNE_B1_PATH) == 2;        // experiment: the bound pass on k_sweep4 (stationary operand in LDS)
     const bool regs6 = stat_ok && sweep6_supported(Kp / SW_BKB) && !(g_variant & 16) && !b1_lds;   // k_sweep6: stationary operand in registers
+    if (ps.cos6 && !regs6) return fail(P4V_ERR_UNSUPPORTED, "cosine pass planned for k_sweep6 does not qualify for it");
     const bool pairs = stat_ok && !regs6 && !(g_variant & 8) && !b1_lds;                // k_sweep5: two candidates per pass
     // per-score-block candidate ranges: the weight search on k_sweep6 (a streaming 64-row tile lies in one scale block = one score
     // block: blocks64); tuning 12 = 9 switches them off (A/B)
@@ -1101,7 +1110,11 @@ int run_pass(Ctx& c, Pass& ps) {
     const int s3_slabs = (a_search ? Np : Mp) / 64, s3_groups = (a_search ? Mp : Np) / s3_gw;
     const int NpP = stat_ok ? s3_groups : fast ? Np / 32 : Np;          // columns of the partial-sum table
     const int MT7 = big7 ? (Mp / (ps.twin ? 128 : 256)) * 4 : 0;        // k_sweep7: one row per (sample tile, wave column)
-    const long p_zs = stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
+    // cosine on k_sweep6: k_finish_cos's table [64-feature slab][padded sample][3]; the samples are the streaming rows of the
+    // activation search (tiles of 64) and the stationary rows of the weight search (slabs of 256)
+    const int cos6_Sp = ps.cos6 ? (a_search ? (int)cdiv(ps.Mrows, 64) * 64 : Mp) : 0;
+    const int cos6_slabs = ps.cos6 ? (a_search ? Np / 64 : (int)cdiv(ps.Ncols, 64)) : 0;
+    const long p_zs = ps.cos6 ? (long)cos6_slabs * cos6_Sp * 3 : stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = !ps.use_s1 ? nullptr : ps.S1_pre ? ps.S1_pre : c.ws.get<float>((size_t)ps.eq_n * ps.s_cs);
@@ -1113,7 +1126,7 @@ int run_pass(Ctx& c, Pass& ps) {
     const int s6_stiles = (a_search ? Np : Mp) / 256, s6_ttiles = (int)cdiv(a_search ? ps.Mrows : ps.Ncols, 64);
     // (only where the in-place gather is uncoalesced: the activation search, whose tile is transposed; in the weight search the
     // lanes of a load already read consecutive features)
-    const bool epi6_on = regs6 && (a_search || tune(TUNE_EPI6W) == 1);
+    const bool epi6_on = regs6 && (a_search || ps.cos6 || tune(TUNE_EPI6W) == 1);
     const size_t epi6_bytes = epi6_on ? (size_t)s6_stiles * s6_ttiles * (256 * 64 * 8) : 0;
     EpiCache* ec = (epi6_on && ps.ecache && (long)epi6_bytes <= PLANE_CACHE_MAX && !(g_variant & 1024)) ? ps.ecache : nullptr;
     if (ec && !ec->assigned) {
@@ -1155,8 +1168,8 @@ int run_pass(Ctx& c, Pass& ps) {
         pe.O = ps.O; pe.Wt = ps.G ? ps.G : ps.O; pe.bias = ps.bias ? ps.bias : zero_bias;
         pe.o_ss = a_search ? ps.o_ns : ps.o_ms; pe.o_ts = a_search ? ps.o_ms : ps.o_ns;
         pe.SR = a_search ? ps.Ncols : ps.Mrows; pe.TR = a_search ? ps.Mrows : ps.Ncols;
-        pe.bias_on_t = a_search ? 0 : 1; pe.wt_mode = ps.wt_mode;
-        pe.stiles = s6_stiles; pe.ttiles = s6_ttiles; pe.E = epi6;
+        pe.bias_on_t = a_search ? 0 : 1; pe.wt_mode = ps.cos6 ? 4 : ps.wt_mode;
+        pe.stiles = s6_stiles; pe.ttiles = s6_ttiles; pe.E = epi6; pe.transposed = (ps.cos6 && !a_search) ? 1 : 0;
         if (zero_bias) CHK(q_fill(c, zero_bias, 0, sizeof(float) * (size_t)std::max(Mp, Np)));
         const long chunks = (long)(epi6_bytes / 16);
         CHK(enqueue(c, KERN(PrepEpi6Params, k_prep_epi6), dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 32)), dim3(256), 0, pe));
@@ -1249,6 +1262,8 @@ int run_pass(Ctx& c, Pass& ps) {
             if (regs6) {
                 // streaming tiles of 64 rows: only those holding valid rows (the plane is padded to 128)
                 q.stiles = s6_stiles; q.ttiles = s6_ttiles; q.E = epi6; q.crange_blk = rblk;
+                const int epi6k = ps.cos6 ? (a_search ? EPI_COS : EPI_COS_T) : ps.epi;
+                if (ps.cos6) q.NG = cos6_Sp;
                 // what the host knows of the device-side range: the launch geometry is planned for the candidates that will run
                 const bool known = ps.crange && ps.host_hi > ps.host_lo && tune(TUNE_B1_PATH) != 12;
                 const int nc_known = known ? std::max(1, std::min(ps.host_hi, c0 + nc) - std::max(ps.host_lo, c0)) : nc;
@@ -1275,7 +1290,7 @@ int run_pass(Ctx& c, Pass& ps) {
                         int cg6 = choose_cgroups((long)qq.ntile, ncr, q.ktiles, cu_slots(c, 256, 2), P6, 0.14);
                         if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(ncr, tune(TUNE_CG6)));
                         if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 open blocks [%d, %d): tiles %d x %d ktiles %d cand %d -> cgroups %d\n", j, j1, q.stiles, tt1 - tt0, q.ktiles, ncr, cg6);
-                        if (hi > lo && qq.ntile > 0) CHK(launch_sweep6(c, qq, ps.epi, cg6, ncr));
+                        if (hi > lo && qq.ntile > 0) CHK(launch_sweep6(c, qq, epi6k, cg6, ncr));
                         j = j1;
                     }
                     continue;
@@ -1283,7 +1298,7 @@ int run_pass(Ctx& c, Pass& ps) {
                 int cg6 = choose_cgroups((long)q.stiles * q.ttiles, nc_known, q.ktiles, cu_slots(c, 256, 2), P6, 0.14);
                 if (tune(TUNE_CG6) > 0) cg6 = std::max(1, std::min(nc, tune(TUNE_CG6)));
                 if (tune(TUNE_PRINT) > 0) fprintf(stderr, "[p4v] sweep6 tiles %d x %d ktiles %d cand %d (%d known) -> cgroups %d\n", q.stiles, q.ttiles, q.ktiles, nc, nc_known, cg6);
-                CHK(launch_sweep6(c, q, ps.epi, cg6, known ? nc_known : 0));
+                CHK(launch_sweep6(c, q, epi6k, cg6, known ? nc_known : 0));
                 continue;
             }
             const long wgs = (long)q.stiles * q.ttiles;
@@ -1396,7 +1411,11 @@ int run_pass(Ctx& c, Pass& ps) {
         CHK(launch_finish(c, fp));
     } else {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
-        FinishCosParams fp{part, p_cs, p_zs, Np, MT, ps.cos_ZB, ps.cos_ZV, ps.Ncols, ps.eq_n,
+        // (k_sweep6: Z = 1, the V blocks are consecutive runs of 64-feature slabs of the one table; samples = the rows)
+        // (a V block = sb_div features = sb_div / 64 whole slabs, whatever the padding behind the last block)
+        const int cos6_FS = !ps.cos6 ? 0 : ps.cos_ZV == 1 ? cos6_slabs : ps.sb_div / 64;
+        FinishCosParams fp{part, p_cs, ps.cos6 ? (long)cos6_FS * cos6_Sp * 3 : p_zs, ps.cos6 ? cos6_Sp : Np, ps.cos6 ? cos6_FS : MT,
+                           ps.cos_ZB, ps.cos_ZV, ps.cos6 ? ps.Mrows : ps.Ncols, ps.eq_n,
                            ps.cos_j_mode, std::max(1, ps.cos_j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish_cos(c, fp));
     }
@@ -2223,6 +2242,17 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     bool host_w_ok = false, host_a_ok = false;
     const int n_rounds = sg.full() ? d->search_round : 1;
     auto slot = [&](int round, int which) { return sg.full() ? round * 2 + which : 0; };   // granular call: one table
+    // Cosine on k_sweep6 (round 6): the layer as ONE GEMM in the orientation of the difference metrics (rows = samples, columns =
+    // features), the register-stationary sweep with the cosine epilogues EPI_COS / EPI_COS_T; the V blocks are runs of 64-feature
+    // slabs of k_finish_cos's table.  Otherwise (K > 768, blocks that are not whole slabs, variant 2048): k_sweep2 on the swapped
+    // operands, one GEMM per V block.
+    const bool cos6 = cosm && i8 && !twin && !general && nH == 1 && nA == 1 && (nV == 1 || crb_rows % 64 == 0) &&
+                      sweep6_supported((int)(rup(K, 64) / 64)) && !(g_variant & (4 | 16 | 2048)) && !g_force_v1;
+    auto cos6_pass = [&](Pass& ps, int j_mode) {
+        ps.cos6 = true; ps.G = nullptr; ps.wt_mode = 0; ps.prunable = false; ps.scache = nullptr; ps.scache2 = nullptr;
+        ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = j_mode;
+        ps.norm = 1.0 / (double)d->tokens;
+    };
     // the weight search pass of (round, column block h): reference linear.py:455-495
     auto w_search_pass = [&](int round, int h, const float* wc, int wc_cs, bool memo_w_on) -> Pass {
         Pass ps{};
@@ -2235,7 +2265,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         ps.scores_out_ld = nV;
         ps.best_out = best_out ? best_out + (long)slot(round, 0) * nV : nullptr;
         if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
-        if (!cosm) {
+        if (!cosm || cos6) {
             ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
             ps.row = x_operand(false, a_iv, 0);
             if (twin) { ps.row2 = xneg_operand(); ps.twin_disjoint = true; }    // linear.py:605-606: clamp(.,0,q-1) / clamp(.,-q,0)
@@ -2248,6 +2278,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             ps.j_mode = 1; ps.j_div = crb_rows;
             ps.norm = 1.0 / ((double)d->tokens * crb_rows);
             ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.scache2 = &slice2; ps.host_sync_ok = memo_w_on;
+            if (cos6) cos6_pass(ps, 1);
         } else {
             // swapped: rows = features of V block z, cols = samples
             ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -2331,7 +2362,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)slot(round, 1) * d->eq_n) * nV : nullptr;
             ps.scores_out_ld = nV;
             ps.best_out = (best_out && a == 0) ? best_out + (long)slot(round, 1) * nV : nullptr;
-            if (!cosm) {
+            if (!cosm || cos6) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
                 ps.row = x_operand(true, ac, nA);
                 if (twin) ps.row2 = xneg_operand();
@@ -2364,6 +2395,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     slice2.o_src = nullptr;         // (both tiers: the second one compares the same pointer and would otherwise keep
                                                     // the previous pass's target rows when two tier-2 activation passes follow each other)
                 }
+                if (cos6) cos6_pass(ps, 0);
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
                 ps.row = w_operand(false, w_iv, 0, true);

@@ -690,6 +690,7 @@ enum EpiMode {
     EPI_STORE = 5  // no metric: store raw_out - bias - scale*acc as an fp32 [M][N] tensor (candidate-invariant
                    // part of a twin operand folded into the target, see linear_impl)
     ,EPI_FWD = 6   // quant_forward: store scale*acc (+ scale2*acc2) + bias -- the quantised layer's output
+    ,EPI_COS_T = 7 // k_sweep6 only: cosine with the SAMPLES on the stationary side (weight search): transposed MFMA output
 };
 
 // Device-side candidate range of a pruned pass (exact branch-and-bound, p4v_api.hip::run_pass_pruned): when `crange` is set
@@ -2928,9 +2929,10 @@ __global__ __launch_bounds__(512, 2) void k_sweep5_g(GroupArgs<Sweep3Params> a) 
 // prologue took 10 % of the launch (profiles/r2_sweep6_ablation.txt).
 struct PrepEpi6Params {
     const float* O; const float* Wt; const float* bias;
-    long o_ss, o_ts; int SR, TR, bias_on_t, wt_mode;
+    long o_ss, o_ts; int SR, TR, bias_on_t, wt_mode;   // wt_mode 4 (cosine): k = 0 holds raw_out itself, k = 1 the bias of the element
     int stiles, ttiles;
     float* E;
+    int transposed;     // cosine weight search (EPI_COS_T): a lane's four values are four STREAMING rows of one stationary row
 };
 __device__ __forceinline__ void k_prep_epi6_body(const PrepEpi6Params& p, const uint3 blockIdx, const uint3 gridDim) {
     const long total = (long)p.stiles * p.ttiles * 8 * 2 * 4 * 2 * 64;
@@ -2939,19 +2941,20 @@ __device__ __forceinline__ void k_prep_epi6_body(const PrepEpi6Params& p, const 
         const long t = i >> 13;
         const int st = (int)(t % p.stiles), tt = (int)(t / p.stiles);
         const int g = lane >> 5, l31 = lane & 31;
-        const int tr = tt * 64 + cb * 32 + l31;
-        const int sr0 = st * 256 + b * 32 + 8 * q + 4 * g;
+        // plain: stationary rows st*256 + b*32 + 8q + 4g + e at streaming row tt*64 + cb*32 + l31;
+        // transposed: streaming rows tt*64 + cb*32 + 8q + 4g + e at stationary row st*256 + b*32 + l31
+        const int tr0 = tt * 64 + cb * 32 + (p.transposed ? 8 * q + 4 * g : l31);
+        const int sr0 = st * 256 + b * 32 + (p.transposed ? l31 : 8 * q + 4 * g);
         v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (tr < p.TR) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sr = sr0 + e;
-                if (sr < p.SR) {
-                    const long idx = (long)sr * p.o_ss + (long)tr * p.o_ts;
-                    const float o = p.O[idx];
-                    if (k == 0) v[e] = o - p.bias[p.bias_on_t ? tr : sr];
-                    else v[e] = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : 1.0f;
-                }
+        for (int e = 0; e < 4; ++e) {
+            const int sr = sr0 + (p.transposed ? 0 : e), tr = tr0 + (p.transposed ? e : 0);
+            if (sr < p.SR && tr < p.TR) {
+                const long idx = (long)sr * p.o_ss + (long)tr * p.o_ts;
+                const float o = p.O[idx];
+                const float bs = p.bias[p.bias_on_t ? tr : sr];
+                if (k == 0) v[e] = p.wt_mode == 4 ? o : o - bs;
+                else v[e] = p.wt_mode == 1 ? p.Wt[idx] : p.wt_mode == 2 ? o : p.wt_mode == 3 ? fabsf(o) : p.wt_mode == 4 ? bs : 1.0f;
             }
         }
         reinterpret_cast<v4f*>(p.E)[i] = v;
@@ -2969,6 +2972,15 @@ __global__ __launch_bounds__(256) void k_prep_epi6_g(GroupArgs<PrepEpi6Params> a
 template <int EPI, int KT, int RB>
 __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3 blockIdx, const uint3 gridDim) {
     constexpr int NW = 8 / RB;                           // waves per workgroup
+    // Cosine (round 6): a sample's dot(raw, sim) and |sim|^2 are sums over FEATURES, so the samples must sit on the lanes of the
+    // MFMA output (columns) and the features in a lane's 16 registers.  Activation search (EPI_COS): the stationary operand is
+    // the weights -- rows = features, as in every other epilogue.  Weight search (EPI_COS_T): the stationary operand is the
+    // samples, so the two MFMA operands swap places (both are 16 bytes of K per lane: D' = D^T) and a lane's registers run over
+    // the 64 streaming features of the tile.  Either way a wave writes (dot, |sim|^2, |raw|^2) per (candidate, 64-feature slab,
+    // sample) straight to k_finish_cos's table [slab][sample][3] (p.NG = padded samples): there is no LDS left for 100
+    // candidates x 256 samples, and the stores ride behind the ring barrier, a whole candidate before the next counted wait.
+    constexpr bool COS = EPI == EPI_COS || EPI == EPI_COS_T, TR = EPI == EPI_COS_T;
+    static_assert(!COS || RB == 2, "cosine epilogue: one wave per SIMD only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P4V_TRACE
     unsigned long long* trc = p.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
@@ -3037,12 +3049,43 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
                     if constexpr ((P4V_SW6_DBG & 32) != 0) sfr[kt][i][h] = v4i{lane, kt, i, h};     // ablation: no stationary loads
                     else sfr[kt][i][h] = gS[((kt * 2 + (RB == 2 ? i : ib)) * 2 + h) * 64];
                 }
+        // cosine instances: the fragments are pinned to the ACCUMULATION file (the MFMAs read them there).  Left alone the
+        // allocator spreads them over both files and shuffles them inside the candidate loop (112 v_accvgpr_mov + 3 scratch
+        // reloads per candidate at KT = 12; the difference-metric instances do not show it and stay as they were tuned).
+        if constexpr (COS && KT * RB * 2 * 4 > 128) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) asm volatile("" : "+a"(sfr[kt][i][h]));
+        }
     }
 
     // ---- candidate-invariant epilogue operands: 2 x 2 MFMA tiles of 32 x 32 (rows = stationary, cols = streaming), in
     // fragment order (k_prep_epi6: bias, padding and the choice of the metric weight are folded in) ---------------------
     float u[RB][2][16], w[RB][2][16];
-    if (p.E) {
+    if constexpr (COS) {
+        // cosine: u = raw_out itself, w = the bias of the element's FEATURE -- the same for both column blocks (plain: features
+        // on the rows) or both 32-row blocks (transposed: features on the columns), so only w[.][0][.] / w[0][.][.] is loaded and
+        // kept: the 256 architectural registers of the wave are full (64 accumulators, the fragment ring, 64 + 32 here)
+        const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f u4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 0) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[i][cb][q * 4 + e] = u4[e];
+                    if ((TR && i == 0) || (!TR && cb == 0)) {
+                        const v4f w4 = gE[(((i * 2 + cb) * 4 + q) * 2 + 1) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[i][cb][q * 4 + e] = w4[e];
+                    }
+                }
+    } else if (p.E) {
         const v4f* gE = reinterpret_cast<const v4f*>(p.E) + ((long)t * 8 + wid * RB) * (2 * 4 * 2 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -3103,6 +3146,42 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
     float* s1tab = res + (per + 1) * (2 * NW);
     for (int i = lane; i < ncand; i += 64) s1tab[i * NW + wid] = p.S1 ? p.S1[(c_lo + i) * p.s_cs + sb] : 1.0f;
 
+    // cosine: |raw|^2 of a lane's sample over the features this wave sees of it (plain: the wave's 64 stationary features, per
+    // column block; transposed: the tile's 64 streaming features, per 32-row block), in the order of the per-candidate sums
+    float oo_fix[2] = {0.0f, 0.0f};
+    auto half_sum = [](float x) __attribute__((always_inline)) {
+        // x(lane) + x(lane ^ 32): v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second
+        float y = x;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+        return x + y;
+    };
+    if constexpr (COS) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            float t2 = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = TR ? u[sg][o][r] : u[o][sg][r]; t2 = fmaf(v, v, t2); }
+            oo_fix[sg] = half_sum(t2);
+        }
+    }
+    float cd[2] = {0.0f, 0.0f}, cn[2] = {0.0f, 0.0f};    // cosine: running dot / |sim|^2 of the epilogue in flight
+    float sd[2] = {0.0f, 0.0f}, sn[2] = {0.0f, 0.0f};    // ... finished, waiting for their store slot behind the ring barrier
+    const int Sp = p.NG;
+    // table rows of this lane: plain -- slab = the wave's 64 features, samples t0 + cb * 32 + l31; transposed -- slab = the
+    // streaming tile, samples s0 + i * 32 + l31
+    // (one candidate's table is well below 4 GB: wave-uniform 64-bit base + per-lane 32-bit byte offset)
+    unsigned cos_row = 0;
+    if constexpr (COS) cos_row = (unsigned)((TR ? tt * Sp + s0 + l31 : (st * 4 + wid) * Sp + t0 + l31) * 12);
+    // Branch-free: both half waves hold the same sums behind half_sum and store them to the same address (a branch here -- or on
+    // "is there a previous candidate" below -- splits the basic block, and the pure arithmetic of the epilogue slices in front of
+    // it sinks across the split, out from between the MFMAs).
+    auto cos_store = [&](int cand, int sgrp, float d, float n2) __attribute__((always_inline)) {
+        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(p.part + (long)cand * p.p_cs) + (cos_row + sgrp * 384));
+        q[0] = d; q[1] = n2; q[2] = oo_fix[sgrp];
+    };
+
     // ---- main loop ----------------------------------------------------------------------------------------------
     // One candidate = 2 phases (column block cb = 0, then 1) of KT steps; a step = 2 fragment reads + 4 MFMAs.  With a
     // single wave per SIMD nothing hides behind another wave, so everything is interleaved by construction:
@@ -3152,6 +3231,43 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
             if constexpr (sl == 0) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i) asm volatile("" : "+v"(acc[i][cbE]));
+            }
+            return;
+        }
+        if constexpr (COS) {
+            // plain: block cbE holds samples cbE*32 + l31, summed over both 32-feature blocks i; transposed: block cbE holds
+            // features cbE*32 + .., sample group = i, summed over both column blocks (block 0 first, then block 1)
+            if constexpr (sl == 0 && (!TR || cbE == 0)) { cd[0] = cd[1] = cn[0] = cn[1] = 0.0f; }
+            if constexpr (sl < NSL) {
+#pragma unroll
+                for (int e = sl * EPS; e < (sl + 1) * EPS && e < NEL; ++e) {
+                    const int i = e >> 4, r = e & 15;
+                    const int sgi = TR ? i : 0;
+                    const float o = fmaf((float)acc[i][cbE][r], es1, TR ? w[0][cbE][r] : w[i][0][r]);
+                    cd[sgi] = fmaf(u[i][cbE][r], o, cd[sgi]);
+                    cn[sgi] = fmaf(o, o, cn[sgi]);
+                }
+                // (pins the slice between the MFMAs of its step: nothing else orders pure arithmetic against the asm statements)
+                if constexpr (TR) asm volatile("" : "+v"(cd[0]), "+v"(cd[1]), "+v"(cn[0]), "+v"(cn[1]));
+                else asm volatile("" : "+v"(cd[0]), "+v"(cn[0]));
+            } else if constexpr (!TR) {
+                const float d = half_sum(cd[0]), n2 = half_sum(cn[0]);
+                if constexpr (cbE == 1) { sd[0] = d; sn[0] = n2; }      // block 1 of candidate slot-1: stored with the next block 0
+                else {
+                    // behind the ring barrier of this candidate: block 0 of this candidate, block 1 of the previous one
+                    // (first candidate: the warm-up epilogue's sums go to the candidate's own block-1 entry, which the real ones
+                    // overwrite one candidate later -- same lane, same address, program order)
+                    cos_store(c_lo + slot - 1, 0, d, n2);
+                    cos_store(c_lo + max(slot - 2, 0), 1, sd[0], sn[0]);
+                }
+            } else {
+                if constexpr (cbE == 1) {                                // candidate slot-1 complete
+                    sd[0] = half_sum(cd[0]); sn[0] = half_sum(cn[0]); sd[1] = half_sum(cd[1]); sn[1] = half_sum(cn[1]);
+                } else {                                                 // the previous candidate, behind this one's ring barrier
+                    // (first candidate: warm-up sums into its own entries, overwritten one candidate later)
+                    cos_store(c_lo + max(slot - 2, 0), 0, sd[0], sn[0]);
+                    cos_store(c_lo + max(slot - 2, 0), 1, sd[1], sn[1]);
+                }
             }
             return;
         }
@@ -3205,8 +3321,10 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                if constexpr ((P4V_SW6_DBG & 2) == 0)
-                    acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+                if constexpr ((P4V_SW6_DBG & 2) == 0) {
+                    if constexpr (TR) acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.f[h], sfr[kt][i][h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+                    else acc[i][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sfr[kt][i][h], cur.f[h], (kt == 0 && h == 0) ? zero16 : acc[i][cb], 0, 0, 0);
+                }
                 if (h == 1 && i == 0) {
                     // the streamed tile of candidate ci+2 trickles in one 1 KB piece per wave and step (a burst right after
                     // the barrier stalls the fragment reads).  Issue point: after the third MFMA of the step, fenced so that
@@ -3268,7 +3386,13 @@ __device__ __forceinline__ void k_sweep6_body(const Sweep3Params& p, const uint3
 #ifdef P4V_TRACE
     if (threadIdx.x == 0) trc[2] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (COS) {
+        // the last candidate: plain -- its block 1 (block 0 went out behind its ring barrier); transposed -- both sample groups
+        if constexpr (!TR) cos_store(c_lo + ncand - 1, 1, sd[0], sn[0]);
+        else { cos_store(c_lo + ncand - 1, 0, sd[0], sn[0]); cos_store(c_lo + ncand - 1, 1, sd[1], sn[1]); }
+    }
     __syncthreads();   // also drains the over-issued (never consumed) ring pieces before the LDS is released
+    if constexpr (COS) return;
     // part[c][64-row slab][32-column group]; with RB = 1 two waves share a slab: fixed-order sum of their results
     for (int i = tid; i < ncand * 8; i += 64 * NW) {
         const int ci = i / 8, wv = (i % 8) >> 1, cb = i & 1;

@@ -1,4 +1,4 @@
-"""The C-ABI shared library loads on a CPU-only host and exports every symbol include/ptq4vit_hip.h declares.
+"""The C-ABI shared library loads on a CPU-only host and exports every symbol include/*.h declares.
 No compute call is made here (no GPU): only planning (workspace sizing) and argument validation."""
 import ctypes as C
 import os
@@ -19,7 +19,9 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "ptq4vit_hip.h")).read()
-    declared = set(re.findall(r"\b(p4v_[A-Za-z0-9_]+)\s*\(", hdr))
+    dbg = open(os.path.join(ROOT, "include", "ptq4vit_hip_debug.h")).read()
+    assert "p4v_debug_" not in hdr.split("#ifndef PTQ4VIT_HIP_H")[1].replace("p4v_debug_*", ""), "debug entry points belong in ptq4vit_hip_debug.h"
+    declared = set(re.findall(r"\b(p4v_[A-Za-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\b(p4v_[A-Za-z0-9_]+)\s*\(", dbg))
     assert {"p4v_linear_calibrate", "p4v_matmul_calibrate", "p4v_conv_calibrate", "p4v_version"} <= declared
     from ptq4vit_amd import _lib
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)

@@ -153,6 +153,8 @@ def _mk_linear(seed, b, T, K, N, postgelu=False, gscale=1e-3):
     dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=8, a_bit=8, metric="hessian", postgelu=True),
     dict(b=4, T=70, K=330, N=130, n_V=1, w_bit=6, a_bit=6, metric="hessian", postgelu=True),
     dict(b=5, T=61, K=200, N=390, n_V=3, w_bit=8, a_bit=8, metric="cosine", postgelu=False),
+    dict(b=3, T=50, K=192, N=192, n_V=3, w_bit=8, a_bit=8, metric="cosine", postgelu=False),    # cosine on k_sweep6 (plain + transposed)
+    dict(b=2, T=70, K=768, N=200, n_V=1, w_bit=6, a_bit=6, metric="cosine", postgelu=False),    # ... KT = 12, ragged N
     dict(b=3, T=50, K=96, N=160, n_V=2, w_bit=8, a_bit=8, metric="L2_norm", postgelu=False),
     # K = 192 / 384 / 768 bytes: register-stationary sweep (k_sweep6<KT = 3 / 6 / 12>), every epilogue flavour
     dict(b=3, T=50, K=192, N=128, n_V=2, w_bit=8, a_bit=8, metric="L1_norm", postgelu=False),
@@ -764,13 +766,59 @@ def test_cosine_on_the_fast_sweep_is_bit_identical_to_the_generic_kernel(eng, cf
             return res, {r["kernel"] for r in eng.stats_launches()}
         finally:
             eng.stats_enable(False)
-    fast, k_fast = kinds(run)
     try:
+        eng.debug_variant(2048)         # (Linear layers with K <= 768 take k_sweep6 by default: the test below)
+        fast, k_fast = kinds(run)
         eng.debug_tuning(12, 7)
         generic, k_gen = kinds(run)
     finally:
         eng.debug_tuning(12, 0)
+        eng.debug_variant(0)
     assert k_fast == {"k_sweep2"} and k_gen == {"k_sweep<int8>"}, (k_fast, k_gen)
     for a, g_ in zip(fast, generic):
         if a is not None:
             assert torch.equal(a, g_)
+
+
+# ------------------------------------------------------------------------------------------------
+# cosine on the register-stationary sweep (k_sweep6<EPI_COS / EPI_COS_T>, round 6) == cosine on k_sweep2
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(b=3, T=50, K=192, N=192, n_V=3, bit=8),         # DeiT-tiny qkv geometry in small: KT = 3, V blocks of one slab
+    dict(b=3, T=50, K=192, N=130, n_V=1, bit=8),         # ragged N: the last slab is partly padding
+    dict(b=3, T=49, K=256, N=128, n_V=2, bit=6),         # KT = 4
+    dict(b=2, T=70, K=384, N=200, n_V=1, bit=8),         # KT = 6
+    dict(b=2, T=70, K=512, N=192, n_V=3, bit=8),         # KT = 8
+    dict(b=2, T=197, K=768, N=2304, n_V=3, bit=8),       # ViT-B qkv at 2 images: KT = 12, 394 samples = 2 stationary slabs / 7 tiles
+    dict(b=2, T=197, K=768, N=3072, n_V=1, bit=8, eq_n=37),   # ViT-B fc1, odd candidate count
+    dict(b=1, T=10, K=192, N=64, n_V=1, bit=8, eq_n=1),  # one candidate, one tile
+], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_cosine_on_the_register_stationary_sweep_matches_the_swapped_sweep(eng, cfg):
+    """A cosine Linear search with K <= 768 runs as ONE GEMM on k_sweep6 (samples on the MFMA columns: plain in the activation
+    search, transposed operands in the weight search) instead of one k_sweep2 GEMM per V block on swapped operands.  Both write
+    (dot, |sim|^2, |raw|^2) per (candidate, 64-feature slab, sample) with the same per-lane order of additions and share
+    k_finish_cos: the score tables of every pass and the selected intervals must be IDENTICAL (reference linear.py:406-407,
+    483-487)."""
+    hp = dict(metric="cosine", eq_alpha=0.01, eq_beta=1.2, eq_n=cfg.get("eq_n", 100), search_round=2)
+    w, bias, x, out, grad = _mk_linear(13, cfg["b"], cfg["T"], cfg["K"], cfg["N"])
+    run = lambda: eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), postgelu=False, n_H=1, n_a=1,
+                                       n_V=cfg["n_V"], w_bit=cfg["bit"], a_bit=cfg["bit"], want_scores=True, **hp)
+    def kinds(fn):
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+            return res, {r["kernel"] for r in eng.stats_launches()}
+        finally:
+            eng.stats_enable(False)
+    six, k_six = kinds(run)
+    try:
+        eng.debug_variant(2048)
+        two, k_two = kinds(run)
+    finally:
+        eng.debug_variant(0)
+    assert k_six == {"k_sweep6"} and k_two == {"k_sweep2"}, (k_six, k_two)
+    for a, b_ in zip(six, two):
+        if a is not None:
+            assert torch.equal(a, b_), float((a.double() - b_.double()).abs().max())
