@@ -835,6 +835,8 @@ template <bool ROWS_FIXED> int launch_sweep8_epi(Ctx& c, const SweepParams& p, i
 
 // k_sweep7: large-K int8 sweep (both operands streaming, 256 x 256 workgroup tile)
 template <int TWIN> int launch_sweep7_epi(Ctx& c, const Sweep7Params& p, int epi, dim3 grid, size_t lds, const StatInfo* si) {
+    if constexpr (TWIN == 0) { if (epi == EPI_COS) return enqueue(c, KERN_T(Sweep7Params, k_sweep7, 0, EPI_COS), grid, dim3(512), lds, p, si); }
+    if (epi == EPI_COS) return fail(P4V_ERR_UNSUPPORTED, "k_sweep7: the cosine epilogue has no twin instance");
     P4V_EPI4(epi, return enqueue(c, KERN_T(Sweep7Params, k_sweep7, TWIN, E), grid, dim3(512), lds, p, si))
 }
 
@@ -963,6 +965,7 @@ struct Pass {
     int32_t* best_out;
     float* store_out;         // EPI_STORE pass: one "candidate", writes raw_out - bias - scale*acc, no finish/select
     bool cos6;                // cosine of a plain Linear layer on k_sweep6 (rows = samples, cols = features, Z = 1): set by linear_impl
+    bool cos7;                // ... on k_sweep7 (K >= 1024)
     bool twin_disjoint;       // twin whose two ranges never overlap (post-GELU): k_sweep7 may stream them as one merged plane
     // exact candidate pruning (run_pass_pruned): device-side candidate range, scores kept for the next stage, no selection
     const int* crange;
@@ -1050,7 +1053,7 @@ int run_pass(Ctx& c, Pass& ps) {
     // k_sweep7 (large K): rows = samples, columns = output features of a plain [M][N] layer; features contiguous in
     // raw_out / raw_grad and a multiple of 32 (dwordx4 epilogue loads, whole 32-feature blocks), every 32-feature block
     // inside one scale / score block, exactly one operand candidate-expanded, the twin's second plane not expanded
-    const bool big7 = !b1_generic && !stat_ok && !ps.store_out && ps.i8 && ps.epi != EPI_COS && !g_force_v1 && !(g_variant & 32768) && ps.Z == 1 &&
+    const bool big7 = !b1_generic && !stat_ok && !ps.store_out && ps.i8 && (ps.epi != EPI_COS || ps.cos7) && !g_force_v1 && !(g_variant & 32768) && ps.Z == 1 &&
                       rup(ps.K, 64) >= 1024 && rup(ps.K, 64) % 256 == 0 && (long)ps.Mrows * ps.o_ms * 4 < (1L << 32) && ps.sb_mode == 1 && (ps.s_cs == 1 || ps.sb_div % 32 == 0) &&
                       (ps.j_mode == 0 || (ps.j_mode == 1 && (ps.nj == 1 || ps.j_div % 32 == 0))) &&
                       ps.row.expanded != ps.col.expanded && !(ps.twin && (ps.row.expanded || ps.row2.expanded)) &&
@@ -1059,6 +1062,7 @@ int run_pass(Ctx& c, Pass& ps) {
     // post-GELU twin on k_sweep7: ONE merged int8 plane k_pos + k_neg (disjoint supports), split in registers (variant
     // 2097152 keeps the two-plane kernel for A/B runs)
     const bool merged7 = big7 && ps.twin && ps.twin_disjoint && !(g_variant & 2097152);
+    if (ps.cos7 && (!big7 || ps.twin)) return fail(P4V_ERR_UNSUPPORTED, "cosine pass planned for k_sweep7 does not qualify for it");
     // k_sweep6 tiles the stationary operand (the one that is NOT candidate-expanded) in 256-row slabs
     const int Mp = (int)rup(ps.Mrows, big7 ? (ps.twin ? 128 : 256) : (regs6 && !ps.row.expanded) ? 256 : PADR);
     const int Np = (int)rup(ps.Ncols, big7 ? 256 : (regs6 && !ps.col.expanded) ? 256 : PADR);
@@ -1112,9 +1116,11 @@ int run_pass(Ctx& c, Pass& ps) {
     const int MT7 = big7 ? (Mp / (ps.twin ? 128 : 256)) * 4 : 0;        // k_sweep7: one row per (sample tile, wave column)
     // cosine on k_sweep6: k_finish_cos's table [64-feature slab][padded sample][3]; the samples are the streaming rows of the
     // activation search (tiles of 64) and the stationary rows of the weight search (slabs of 256)
-    const int cos6_Sp = ps.cos6 ? (a_search ? (int)cdiv(ps.Mrows, 64) * 64 : Mp) : 0;
-    const int cos6_slabs = ps.cos6 ? (a_search ? Np / 64 : (int)cdiv(ps.Ncols, 64)) : 0;
-    const long p_zs = ps.cos6 ? (long)cos6_slabs * cos6_Sp * 3 : stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
+    // ... on k_sweep7: slabs of 128 features (a wave's rows), the samples are the tile-padded rows
+    const int cos_slab = ps.cos7 ? 128 : 64;
+    const int cos6_Sp = ps.cos7 ? Mp : ps.cos6 ? (a_search ? (int)cdiv(ps.Mrows, 64) * 64 : Mp) : 0;
+    const int cos6_slabs = ps.cos7 ? Np / 128 : ps.cos6 ? (a_search ? Np / 64 : (int)cdiv(ps.Ncols, 64)) : 0;
+    const long p_zs = (ps.cos6 || ps.cos7) ? (long)cos6_slabs * cos6_Sp * 3 : stat_ok ? (long)s3_slabs * s3_groups : big7 ? (long)MT7 * NpP : (long)MT * NpP * (cosm ? 3 : 1);
     const long p_cs = p_zs * ps.Z;
     float* part = c.ws.get<float>((size_t)p_cs * ps.eq_n);
     float* S1 = !ps.use_s1 ? nullptr : ps.S1_pre ? ps.S1_pre : c.ws.get<float>((size_t)ps.eq_n * ps.s_cs);
@@ -1176,7 +1182,7 @@ int run_pass(Ctx& c, Pass& ps) {
     }
     if (ec) ec->valid = true;
     if (big7 && !c.dry) {
-        PrepEpiParams pe{ps.O, ps.G ? ps.G : ps.O, ps.bias, ps.o_ms, ps.Mrows, ps.Ncols, ps.wt_mode,
+        PrepEpiParams pe{ps.O, ps.G ? ps.G : ps.O, ps.bias, ps.o_ms, ps.Mrows, ps.Ncols, ps.cos7 ? 4 : ps.wt_mode,
                          Np / 256, Mp / (ps.twin ? 128 : 256), ps.twin ? 1 : 0, epi7};
         const long chunks = (long)Mp * Np * 2 / 4;
         CHK(enqueue(c, KERN(PrepEpiParams, k_prep_epi), dim3((unsigned)std::min<long>(cdiv(chunks, 256), 256L * 16)), dim3(256), 0, pe));
@@ -1317,7 +1323,7 @@ int run_pass(Ctx& c, Pass& ps) {
             q.S1 = S1; q.S2 = S2; q.s_cs = ps.s_cs; q.sb_div = ps.s_cs > 1 ? std::max(1, ps.sb_div) : (1 << 30);
             q.E = epi7;
             q.c0 = c0; q.c1 = c0 + nc; q.crange = ps.crange;
-            q.part = part; q.p_cs = p_cs; q.NG = NpP;
+            q.part = part; q.p_cs = p_cs; q.NG = ps.cos7 ? cos6_Sp : NpP;
             q.rtiles = Np / 256; q.ctiles = Mp / (ps.twin ? 128 : 256);
             // one workgroup per CU; per k-tile ~0.62 us (16 MFMAs per wave, two waves per SIMD), ~3 k-tiles' worth of
             // epilogue per candidate, a prologue of a few us (scale tables, first tiles)
@@ -1413,9 +1419,10 @@ int run_pass(Ctx& c, Pass& ps) {
         // part layout [C][ZB][ZV][FS][Sp][3] with z = zb*ZV + zv
         // (k_sweep6: Z = 1, the V blocks are consecutive runs of 64-feature slabs of the one table; samples = the rows)
         // (a V block = sb_div features = sb_div / 64 whole slabs, whatever the padding behind the last block)
-        const int cos6_FS = !ps.cos6 ? 0 : ps.cos_ZV == 1 ? cos6_slabs : ps.sb_div / 64;
-        FinishCosParams fp{part, p_cs, ps.cos6 ? (long)cos6_FS * cos6_Sp * 3 : p_zs, ps.cos6 ? cos6_Sp : Np, ps.cos6 ? cos6_FS : MT,
-                           ps.cos_ZB, ps.cos_ZV, ps.cos6 ? ps.Mrows : ps.Ncols, ps.eq_n,
+        const bool cosp = ps.cos6 || ps.cos7;
+        const int cos6_FS = !cosp ? 0 : ps.cos_ZV == 1 ? cos6_slabs : ps.sb_div / cos_slab;
+        FinishCosParams fp{part, p_cs, cosp ? (long)cos6_FS * cos6_Sp * 3 : p_zs, cosp ? cos6_Sp : Np, cosp ? cos6_FS : MT,
+                           ps.cos_ZB, ps.cos_ZV, cosp ? ps.Mrows : ps.Ncols, ps.eq_n,
                            ps.cos_j_mode, std::max(1, ps.cos_j_div), ps.nj, ps.norm, scores};
         CHK(launch_finish_cos(c, fp));
     }
@@ -2248,8 +2255,12 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
     // operands, one GEMM per V block.
     const bool cos6 = cosm && i8 && !twin && !general && nH == 1 && nA == 1 && (nV == 1 || crb_rows % 64 == 0) &&
                       sweep6_supported((int)(rup(K, 64) / 64)) && !(g_variant & (4 | 16 | 2048)) && !g_force_v1;
+    // ... and on k_sweep7 for K >= 1024 (fc2): 128-feature slabs; the conditions are run_pass's for that kernel
+    const bool cos7 = cosm && i8 && !twin && !general && nH == 1 && nA == 1 && (nV == 1 || crb_rows % 128 == 0) && !cos6 &&
+                      rup(K, 64) >= 1024 && rup(K, 64) % 256 == 0 && N % 32 == 0 && (long)M * N * 4 < (1L << 32) &&
+                      (c.dry || (((unsigned long long)O) & 15) == 0) && !(g_variant & (2048 | 32768)) && !g_force_v1;
     auto cos6_pass = [&](Pass& ps, int j_mode) {
-        ps.cos6 = true; ps.G = nullptr; ps.wt_mode = 0; ps.prunable = false; ps.scache = nullptr; ps.scache2 = nullptr;
+        ps.cos6 = cos6; ps.cos7 = cos7; ps.G = nullptr; ps.wt_mode = 0; ps.prunable = false; ps.scache = nullptr; ps.scache2 = nullptr;
         ps.cos_ZB = 1; ps.cos_ZV = nV; ps.cos_j_mode = j_mode;
         ps.norm = 1.0 / (double)d->tokens;
     };
@@ -2265,7 +2276,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
         ps.scores_out_ld = nV;
         ps.best_out = best_out ? best_out + (long)slot(round, 0) * nV : nullptr;
         if (h > 0) { ps.scores_out = nullptr; ps.best_out = nullptr; }  // tables of the first column block only
-        if (!cosm || cos6) {
+        if (!cosm || cos6 || cos7) {
             ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
             ps.row = x_operand(false, a_iv, 0);
             if (twin) { ps.row2 = xneg_operand(); ps.twin_disjoint = true; }    // linear.py:605-606: clamp(.,0,q-1) / clamp(.,-q,0)
@@ -2278,7 +2289,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             ps.j_mode = 1; ps.j_div = crb_rows;
             ps.norm = 1.0 / ((double)d->tokens * crb_rows);
             ps.prunable = !(d->reserved & 8); ps.scache = &slice; ps.scache2 = &slice2; ps.host_sync_ok = memo_w_on;
-            if (cos6) cos6_pass(ps, 1);
+            if (cos6 || cos7) cos6_pass(ps, 1);
         } else {
             // swapped: rows = features of V block z, cols = samples
             ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
@@ -2362,7 +2373,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
             ps.scores_out = (scores_out && a == 0) ? scores_out + ((long)slot(round, 1) * d->eq_n) * nV : nullptr;
             ps.scores_out_ld = nV;
             ps.best_out = (best_out && a == 0) ? best_out + (long)slot(round, 1) * nV : nullptr;
-            if (!cosm || cos6) {
+            if (!cosm || cos6 || cos7) {
                 ps.Z = 1; ps.Mrows = M; ps.Ncols = N;
                 ps.row = x_operand(true, ac, nA);
                 if (twin) ps.row2 = xneg_operand();
@@ -2395,7 +2406,7 @@ int linear_impl(const p4v_linear_desc* d, const float* W, const float* bias, con
                     slice2.o_src = nullptr;         // (both tiers: the second one compares the same pointer and would otherwise keep
                                                     // the previous pass's target rows when two tier-2 activation passes follow each other)
                 }
-                if (cos6) cos6_pass(ps, 0);
+                if (cos6 || cos7) cos6_pass(ps, 0);
             } else {
                 ps.Z = nV; ps.Mrows = crb_rows; ps.Ncols = M;
                 ps.row = w_operand(false, w_iv, 0, true);

@@ -3494,7 +3494,9 @@ __device__ __forceinline__ void k_prep_epi_body(const PrepEpiParams& p, const ui
             const v4f o = *reinterpret_cast<const v4f*>(p.O + (long)m * p.ldo + n);
             if (!(k & 1)) {
                 v = o;
-                if (p.bias) { const v4f b = *reinterpret_cast<const v4f*>(p.bias + n); v = o - b; }
+                if (p.bias && p.wt_mode != 4) { const v4f b = *reinterpret_cast<const v4f*>(p.bias + n); v = o - b; }
+            } else if (p.wt_mode == 4) {       // cosine: raw_out itself above, the bias of the simulated output here
+                if (p.bias) v = *reinterpret_cast<const v4f*>(p.bias + n);
             } else if (p.wt_mode == 1) v = *reinterpret_cast<const v4f*>(p.G + (long)m * p.ldo + n);
             else if (p.wt_mode == 2) v = o;
             else if (p.wt_mode == 3) v = v4f{fabsf(o[0]), fabsf(o[1]), fabsf(o[2]), fabsf(o[3])};
@@ -3697,7 +3699,9 @@ __device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3
     // of three register sets; wave-uniform base (SGPR pair) + per-lane 32-bit offset: no vector address arithmetic.
     constexpr int NQ = TWIN ? 1 : 2;
     constexpr int NSB = 8 * NQ;
-    constexpr bool NEEDW = (EPI == EPI_SQ_W || EPI == EPI_W_SQ);
+    constexpr bool COS = EPI == EPI_COS;
+    static_assert(!COS || TW == 0, "cosine epilogue: one sample-side plane");
+    constexpr bool NEEDW = (EPI == EPI_SQ_W || EPI == EPI_W_SQ || COS);
     struct Hb { v4f u[2], w[2]; };
     const unsigned e_voff = (unsigned)lane * 16u;
     const float* e_wave = p.E + ((long)(ct * p.rtiles + rt) * 8 + wid) * (NSB * 4 * 256);   // 256 floats per 1 KB chunk
@@ -3716,6 +3720,10 @@ __device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3
         v4f s2v = {0.f, 0.f, 0.f, 0.f};
         if (TWIN) s2v = *reinterpret_cast<const v4f*>(s2tab + ci * 8 + wr * 4);
         float sumj[4] = {0.f, 0.f, 0.f, 0.f};
+        // cosine (round 6): the MFMA columns are samples, so a lane owns ONE sample per sample block q and sums dot(raw, sim),
+        // |sim|^2, |raw|^2 over the wave's 128 features (j-major, the order of the sub-blocks); the two half waves are added and
+        // the triple goes straight to k_finish_cos's table [128-feature slab][sample][3] (p.NG = padded samples)
+        float dq[2] = {0.f, 0.f}, nq[2] = {0.f, 0.f}, oq[2] = {0.f, 0.f};
         // ring of RD register sets, loads RD - 1 sub-blocks ahead of the arithmetic: the 48 fragment registers are dead during
         // the epilogue, so six sets (96 VGPRs) fit next to the 128 accumulators; the operands come from L2 / Infinity Cache
         // at ~1-2 us per access and only the depth of this ring hides that
@@ -3734,6 +3742,22 @@ __device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3
             if constexpr (NEEDW) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur.u[0]), "+v"(cur.u[1]), "+v"(cur.w[0]), "+v"(cur.w[1]) : "n"(younger) : "memory");
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur.u[0]), "+v"(cur.u[1]) : "n"(younger) : "memory");
             const float s1 = s1v[j], s2 = s2v[j];
+            if constexpr (COS) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = (2 * h2 + rr) * 4 + e;
+                        const float uu = cur.u[rr][e];
+                        const float o = fmaf((float)acc[j][q][r], s1, cur.w[rr][e]);
+                        dq[q] = fmaf(uu, o, dq[q]);
+                        nq[q] = fmaf(o, o, nq[q]);
+                        oq[q] = fmaf(uu, uu, oq[q]);
+                    }
+                asm volatile("" : "+v"(dq[q]), "+v"(nq[q]), "+v"(oq[q]));     // (pinned here, as `sum` below)
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             float sum = sumj[j];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
@@ -3757,10 +3781,25 @@ __device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3
         [&]<int... SB>(std::integer_sequence<int, SB...>) __attribute__((always_inline)) {
             (do_sb(std::integral_constant<int, SB>{}), ...);
         }(std::make_integer_sequence<int, NSB>{});
+        if constexpr (COS) {
+            auto half_sum = [](float x) __attribute__((always_inline)) {     // x(lane) + x(lane ^ 32), as in k_sweep6
+                float y = x;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+                return x + y;
+            };
+            // both half waves store the same triple to the same address (no exec-mask branch in the k-tile pipeline)
+            char* row = reinterpret_cast<char*>(p.part + (long)(c_lo + ci) * p.p_cs) +
+                        (unsigned)(((rt * 2 + wr) * p.NG + m0 + wc * 64 + l31) * 12);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float* dst = reinterpret_cast<float*>(row + q * 384);
+                dst[0] = half_sum(dq[q]); dst[1] = half_sum(nq[q]); dst[2] = half_sum(oq[q]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float s = wave_sum_dpp(sumj[j]);       // fixed order: deterministic
-            if (lane == 63) res[(ci * 8 + wid) * 4 + j] = s;
+            const float s = COS ? 0.0f : wave_sum_dpp(sumj[j]);       // fixed order: deterministic
+            if (!COS && lane == 63) res[(ci * 8 + wid) * 4 + j] = s;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -3861,6 +3900,7 @@ __device__ __forceinline__ void k_sweep7_body(const Sweep7Params& p, const uint3
 #undef P4V_DSR
 #undef P4V_GLD
     __syncthreads();
+    if constexpr (COS) return;
     // ---- one coalesced write of this workgroup's results ---------------------------------------------------------------
     for (int i = tid; i < ncand * 32; i += 512) {
         const int cc = c_lo + (i >> 5), wv = (i >> 2) & 7, j = i & 3;

@@ -822,3 +822,45 @@ def test_cosine_on_the_register_stationary_sweep_matches_the_swapped_sweep(eng, 
     for a, b_ in zip(six, two):
         if a is not None:
             assert torch.equal(a, b_), float((a.double() - b_.double()).abs().max())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, T=197, K=3072, N=768, n_V=1, bit=8),       # ViT-B fc2 geometry (BasePTQ: plain Linear, no twin)
+    dict(b=2, T=70, K=1024, N=384, n_V=3, bit=6),        # V blocks of one 128-feature slab each
+    dict(b=1, T=50, K=1280, N=160, n_V=1, bit=8, eq_n=7),    # ragged N (a partly padded slab), few candidates
+], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_cosine_on_the_large_k_sweep_matches_the_swapped_sweep(eng, cfg):
+    """K >= 1024 (fc2): the cosine search as one GEMM on k_sweep7<0, EPI_COS> (128-feature slabs) against one k_sweep2 GEMM per
+    V block on swapped operands (64-feature slabs).  Same integers, another order of the fp32 additions: score tables within
+    SCORE_RTOL of each other, a differing selection only at a tie of the tables (reference linear.py:406-407)."""
+    from tests.helpers import SCORE_RTOL, TIE_RTOL
+    hp = dict(metric="cosine", eq_alpha=0.01, eq_beta=1.2, eq_n=cfg.get("eq_n", 100), search_round=2)
+    w, bias, x, out, grad = _mk_linear(17, cfg["b"], cfg["T"], cfg["K"], cfg["N"])
+    run = lambda: eng.linear_calibrate(weight=_t(w), bias=_t(bias), x=_t(x), out=_t(out), grad=_t(grad), postgelu=False, n_H=1, n_a=1,
+                                       n_V=cfg["n_V"], w_bit=cfg["bit"], a_bit=cfg["bit"], want_scores=True, **hp)
+    def kinds(fn):
+        eng.stats_reset()
+        eng.stats_enable(True)
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+            return res, {r["kernel"] for r in eng.stats_launches()}
+        finally:
+            eng.stats_enable(False)
+    seven, k_seven = kinds(run)
+    try:
+        eng.debug_variant(2048)
+        two, k_two = kinds(run)
+    finally:
+        eng.debug_variant(0)
+    assert k_seven == {"k_sweep7"} and k_two == {"k_sweep2"}, (k_seven, k_two)
+    w7, a7, s7 = seven[0], seven[1], seven[2]
+    w2, a2, s2 = two[0], two[1], two[2]
+    # first pass (weight search of round 0) sees the same inputs on both paths: its table must agree to rounding
+    t7, t2 = s7.reshape(-1, s7.shape[-2], s7.shape[-1])[0], s2.reshape(-1, s2.shape[-2], s2.shape[-1])[0]
+    scale = t2.abs().max().item()
+    assert (t7 - t2).abs().max().item() <= SCORE_RTOL * scale, ((t7 - t2).abs().max().item(), scale)
+    if not (torch.equal(w7, w2) and torch.equal(a7, a2)):
+        # a different selection must be a tie of the FIRST differing table, to TIE_RTOL
+        gap = (t2.max(dim=0).values - t2.gather(0, t7.argmax(dim=0, keepdim=True))[0]).abs().max().item()
+        assert gap <= TIE_RTOL * scale, (gap, scale)
