@@ -34,12 +34,15 @@ def test_no_kernel_uses_scratch(resources):
 
 def test_register_stationary_sweep_fits_one_wave_per_simd(resources):
     k6 = {k: v for k, v in resources.items() if "k_sweep6<" in k and k.rstrip(")").split("<")[1].split(">")[0].endswith(", 2")}
-    assert len(k6) == 20                                     # 4 epilogues x KT in {3, 4, 6, 8, 12}
+    assert len(k6) == 30                                     # (4 difference epilogues + the 2 cosine ones) x KT in {3, 4, 6, 8, 12}
     for k, v in k6.items():
         assert v["NumVgprs"] + v["NumAgprs"] <= 512, (k, v)
     # K = 768: the 192 stationary registers are the AGPR file, accumulators and the raw_out / raw_grad tile are VGPRs
     big = [v for k, v in k6.items() if ", 12, 2>" in k and ("<0," in k or "<3," in k)]
     assert big and all(v["NumAgprs"] >= 160 for v in big), big   # (hipcc keeps some of the 192 in VGPRs)
+    # the cosine instances pin all 192 to the accumulation file (left alone the allocator shuffles them inside the candidate loop)
+    cos = [v for k, v in k6.items() if ", 12, 2>" in k and ("<4," in k or "<7," in k)]
+    assert len(cos) == 2 and all(v["NumAgprs"] == 192 for v in cos), cos
 
 
 def test_streaming_sweeps_keep_two_waves_per_simd(resources):
