@@ -40,14 +40,26 @@ def workspace(dev, nbytes, slot=0):
     ws = _workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspace.pop(key, None)
-        ws = None
-        ws = torch.empty(int(nbytes * 1.05) + (1 << 20), dtype=torch.uint8, device=dev)
+        ws = None           # (the old buffer goes back to torch's pool BEFORE the new one is taken from it)
+        pad = (1 << 20) if slot == "arena" else int(nbytes * 0.05) + (1 << 20)    # an arena is sized by its caller's budget
+        ws = torch.empty(int(nbytes) + pad, dtype=torch.uint8, device=dev)
         _workspace[key] = ws
     return ws
 
 
 def release_workspace():
     _workspace.clear()
+
+
+def workspace_bytes(dev=None):
+    """Bytes of scratch buffers the engine keeps alive between calls (per device, stream and group member)."""
+    return sum(ws.numel() for (d, _s, _slot), ws in _workspace.items() if dev is None or d == dev)
+
+
+def workspace_held(dev, slot=0):
+    """Size of the scratch buffer already kept for (current stream of `dev`, `slot`); 0 if none."""
+    ws = _workspace.get((dev, torch.cuda.current_stream(dev).cuda_stream, slot))
+    return 0 if ws is None else ws.numel()
 
 
 _side_streams = {}
@@ -127,14 +139,21 @@ def calibrate_group(jobs, inputs_ready=None):
     lib = _lib.load()
     dev = jobs[0].dev
     arr = (_lib.GroupJob * len(jobs))()
-    keep = []
+    # ONE arena per (device, stream) for the scratch of all members, carved by offset: the call's scratch is exactly the sum of
+    # the members' needs whatever mixture the previous calls on this stream held (a buffer per member slot, each grown to the
+    # largest member it ever saw, added up to more than the budget of a 128-image configuration and fragmented torch's pool).
+    offs, total = [], 0
+    for job in jobs:
+        offs.append(total)
+        total += (int(job.need) + 4095) & ~4095
+    arena = workspace(dev, total, slot="arena")
+    base = arena.data_ptr()
+    keep = [arena]
     for i, job in enumerate(jobs):
         if job.dev != dev:
             raise ValueError("calibrate_group: every member must live on the same device")
         if job.scores is not None:
             raise ValueError("calibrate_group: score tables are only returned by the single-module calls")
-        ws = workspace(dev, job.need, slot=i)
-        keep.append(ws)
         g = arr[i]
         g.kind, g.status, g.desc = job.kind, 0, C.cast(C.pointer(job.desc), C.c_void_p)
         ins = list(job.inputs) + [None] * (5 - len(job.inputs))
@@ -144,7 +163,7 @@ def calibrate_group(jobs, inputs_ready=None):
         outs = list(job.outputs) + [None] * (3 - len(job.outputs))
         for k in range(3):
             g.out[k] = outs[k].data_ptr() if outs[k] is not None else None
-        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
+        g.workspace, g.workspace_bytes = base + offs[i], int(job.need)
     with torch.cuda.device(dev):
         ev = C.c_void_p(inputs_ready.cuda_event) if inputs_ready is not None else C.c_void_p(0)
         rc = lib.p4v_calibrate_group(arr, len(jobs), stream_ptr(dev), ev)

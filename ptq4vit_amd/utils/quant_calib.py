@@ -268,6 +268,14 @@ class HessianQuantCalibrator(QuantCalibrator):
         dev = _dev_of(self.net)
         if dev.type != "cuda":
             return 96 << 30
+        # The engine's scratch buffers persist between calibrations (keyed by stream and group member).  A grouped search of a
+        # 128-image configuration leaves > 100 GiB of them behind (Swin-B/384 x 128: 184 GiB): the next network's caches then do
+        # not fit next to them, the capture is split into groups and every group repeats the whole capture pass (round 6: 10-36 s
+        # per calibration instead of 6).  Buffers of that size go back to torch's pool here; the search takes what it needs
+        # from the same pool again (`_search_grouped` sizes its scratch to what is free once the caches are resident).
+        from .. import engine
+        if engine.workspace_bytes(dev) > (16 << 30):
+            engine.release_workspace()
         free, _total = torch.cuda.mem_get_info(dev)
         pooled = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)    # cached by torch's allocator: reusable
         budget = max(8 << 30, int(free + pooled) - self.SEARCH_HEADROOM_BYTES)
@@ -791,7 +799,20 @@ class HessianQuantCalibrator(QuantCalibrator):
             return (type(m).__name__, shp, tuple(m.raw_out.shape))
         order = sorted(names, key=lambda n: (str(kind(n)), names.index(n)))
         parts = [order[i::n_calls] for i in range(n_calls)]
-        budget = int(float(os.environ.get("P4V_GROUP_GIB", "150")) * (1 << 30)) // n_calls
+        # Scratch of all concurrent group calls together: P4V_GROUP_GIB at most, and never more than what is free NOW -- the
+        # captured tensors of this group are resident (their allocation is host-side and behind us) -- plus what torch's pool and
+        # the engine's own kept buffers can be re-used for, minus a margin for the allocator's rounding and torch temporaries.
+        # (Round 6 sized it to a constant 150 GiB: next to the 207 GB of captured tensors of Swin-B/384 x 128 the first call ran
+        # out of memory three times, and the buffers it left behind starved the next calibration's caches.)
+        budget_all = int(float(os.environ.get("P4V_GROUP_GIB", "150")) * (1 << 30))
+        if dev.type == "cuda":
+            free, _tot = torch.cuda.mem_get_info(dev)
+            pooled = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            avail = int(free + pooled) + engine.workspace_bytes(dev) - (6 << 30)
+            if avail < budget_all:
+                engine.release_workspace()      # (buffers sized for another mixture of members would be stranded next to the new ones)
+                budget_all = max(4 << 30, avail)
+        budget = budget_all // n_calls
         errors = []
 
         def cost(n, sizes):
@@ -820,10 +841,11 @@ class HessianQuantCalibrator(QuantCalibrator):
                             ri = m.raw_input
                             sizes[n] = 4 * (sum(t.numel() for t in ri) if isinstance(ri, (list, tuple)) else ri.numel()) + 8 * m.raw_out.numel()
                             job = m.calibration_job()
-                            if batch and acc + job.need > budget:          # scratch of the members so far fills the budget: next call
+                            held = (int(job.need) + 4095) & ~4095          # (its share of the call's arena, engine.calibrate_group)
+                            if batch and acc + held > budget:              # scratch of the members so far fills the budget: next call
                                 break
                             todo.pop(0)
-                            batch.append(n); jobs.append(job); acc += job.need
+                            batch.append(n); jobs.append(job); acc += held
                         if not batch:
                             continue
                         engine.calibrate_group(jobs, inputs_ready=inputs_ready)
@@ -1045,7 +1067,11 @@ class HessianQuantCalibrator(QuantCalibrator):
             grp = groups.pop(0)
             try:
                 dc, ds = run_group(grp)
-            except torch.cuda.OutOfMemoryError:
+            except torch.cuda.OutOfMemoryError as oom:
+                if os.environ.get("P4V_CAPTURE_TRACE", "0") == "1":
+                    import traceback
+                    tb = traceback.extract_tb(oom.__traceback__)
+                    print("[ptq4vit_amd] OOM at " + " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}({f.name})" for f in tb[-4:]) + ": " + str(oom).split("\n")[0][:200], flush=True)
                 # the budget was an estimate (allocator fragmentation, another tenant on the GPU): drop this group's caches
                 # and scratch, halve the budget and re-plan what is not calibrated yet.  (Not possible mid-collective.)
                 if shard_cap or len(grp) <= 1:      # a single module that does not fit cannot be split any further
