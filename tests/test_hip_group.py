@@ -196,3 +196,53 @@ def test_whole_network_grouped_search_equals_the_per_module_search(eng, model, c
     assert c_one["groups"] == 1 and c_one["issued"] * 3 < c_per["issued"], (c_one, c_per)
     print(f"[group] {model} x {calib}: {n} interval scalars bit-identical; kernel launches per calibration: per module {c_per['issued']}, "
           f"one group {c_one['issued']} ({c_one['rounds']} rounds), two groups {c_two['issued']}")
+
+
+def test_group_scratch_is_one_arena_within_its_budget(eng, monkeypatch):
+    """The scratch of a group call is ONE arena per stream, carved by offset, and `_search_grouped` sizes the concurrent calls' arenas to
+    a budget (P4V_GROUP_GIB, never more than what is free next to the resident caches): with a budget that holds only a few members a
+    call runs as several p4v_calibrate_group batches REUSING the arena -- same intervals as the default, and the engine keeps no more
+    scratch than the budget.  (Round 6: a buffer per member slot, each grown to the largest member it ever saw, ran Swin-B/384 x 128 out
+    of memory next to its 193 GiB of captured tensors; reference utils/quant_calib.py:371-372 is the loop this replaces.)"""
+    from ptq4vit_amd.configs import PTQ4ViT
+    from ptq4vit_amd.utils import models, net_wrap
+    from ptq4vit_amd.utils.quant_calib import HessianQuantCalibrator
+    torch.cuda.empty_cache()
+    eng.release_workspace()
+    net = models.get_net("deit_tiny_patch16_224", seed=0, device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    images = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+
+    class Loader:
+        batch_size = 8
+
+        def __iter__(self):
+            yield images, None
+
+    def calibrate():
+        for m in wrapped.values():
+            m.mode = "raw"
+        eng.launch_counters(reset=True)
+        cal = HessianQuantCalibrator(net, wrapped, Loader(), sequential=False, batch_size=4)
+        cal.search_grouped, cal.group_calls = True, 2
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            cal.batching_quant_calib()
+        torch.cuda.synchronize()
+        return _intervals(wrapped), eng.launch_counters(reset=True)
+
+    ref, c_ref = calibrate()
+    big = eng.workspace_bytes()
+    assert c_ref["groups"] == 2, c_ref
+    eng.release_workspace()
+    budget = max(big // 8, 48 << 20)
+    monkeypatch.setenv("P4V_GROUP_GIB", repr(budget / 2**30))
+    small, c_small = calibrate()
+    assert c_small["groups"] > c_ref["groups"], (c_small, c_ref)          # the calls ran as several batches
+    for name in ref:
+        for a, b in zip(ref[name], small[name]):
+            assert torch.equal(a, b), name
+    # two arenas (one per concurrent call), each within its half of the budget unless a single member needs more
+    assert eng.workspace_bytes() < big, (eng.workspace_bytes(), big)
+    print(f"[group] scratch kept by the engine: {big >> 20} MiB at the default budget, {eng.workspace_bytes() >> 20} MiB at {budget >> 20} MiB "
+          f"({c_small['groups']} group calls instead of {c_ref['groups']})")
