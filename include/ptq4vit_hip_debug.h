@@ -20,7 +20,7 @@ extern "C" {
 int p4v_debug_set_variant(int variant, int force_generic);
 /* Overrides of launch heuristics: key 0 / 1 / 2 / 3 = candidate groups of k_sweep6 / k_sweep2 / k_sweep2g / k_sweep7
  * (0 = cost model), key 4 = print the launch plans to stderr, key 5 = workgroup order of k_sweep7 + 1, key 6 = k_sweep6 prologue
- * of the cost model (0.1 us), keys 9-14 = slice sizes / tiers of the pruned passes, key 12 = path switches for A/B runs (list in
+ * of the cost model (0.1 us), keys 9-15 = slice sizes / tiers / thresholds of the pruned passes, key 12 = path switches for A/B runs (list in
  * csrc/p4v_api.hip: e.g. 8 read-backs by copy, 9 no per-score-block ranges, 11 the round-4 quantiser). */
 int p4v_debug_set_tuning(int key, int value);
 /* The row selection of the exact pruning alone (k_topk_rows; csrc/p4v_api.hip::slice_fill runs it on the per-sample metric

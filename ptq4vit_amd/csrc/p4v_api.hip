@@ -127,7 +127,7 @@ std::atomic<int> g_variant_word{0};
 // tuning overrides of the launch heuristics (p4v_debug_set_tuning; <= 0: use the cost model)
 std::atomic<int> g_tune[16];
 enum { TUNE_CG6 = 0, TUNE_CG2 = 1, TUNE_CG2G = 2, TUNE_CG7 = 3, TUNE_PRINT = 4, TUNE_ORDER7 = 5, TUNE_P6 = 6, TUNE_PLANE_GIB = 7, TUNE_EPI6W = 8,
-       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11, TUNE_B1_PATH = 12, TUNE_TIER2 = 13, TUNE_TIER2_DIV = 14 };   // TIER2: 1 = no second slice tier; >= 2: minimum survivor count that triggers it   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
+       TUNE_LOOSE_PCT = 9, TUNE_SLICE_DIV = 10, TUNE_SLICE_SMALL = 11, TUNE_B1_PATH = 12, TUNE_TIER2 = 13, TUNE_TIER2_DIV = 14, TUNE_LOOSE_ROWS = 15 };   // LOOSE_ROWS: sample rows from which a module prunes on a 5 % slice share   // TIER2: 1 = no second slice tier; >= 2: minimum survivor count that triggers it   // SLICE_SMALL: rows of the slice a Linear tries first   // pruning: weight share below which a module keeps full sweeps (%); Linear slice = M / div   // EPI6W: 1 = fragment-order epilogue image also in the weight search   // P6: k_sweep6 prologue, 0.1 us; PLANE_GIB: plane budget per chunk (cache limit = half)
 // TUNE_B1_PATH (key 12) doubles as the A/B switch of the round-4 / round-5 paths: 1 / 2 the bound pass on k_sweep2 / k_sweep4,
 // 3 the bound pass on the sweep kernels, 5 padded 64-column planes, 6 no slice kernels, 7 cosine on the generic kernel,
 // 8 read-backs by copy (no mapped host memory), 9 no per-score-block candidate ranges, 10 k_slice_b instead of k_slice_b2,
@@ -1491,8 +1491,12 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
             // once per module: is the slice worth it?  The bounds are as tight as the share of the metric weight the slice
             // holds (ViT class-token rows: > 0.99; the qkv layers, whose keys and values of every token feed the class token:
             // 0.72 -- still worth it, measured: 187 -> 168 ms per ViT-B calibration); below 0.5 most candidates survive and
-            // the three stages cost more than the full sweep they replace (Swin: 0.2) -- such a module keeps the full sweep
-            // (variant 8388608: always prune)
+            // the three stages cost more than the full sweep they replace -- such a module keeps the full sweep (variant
+            // 8388608: always prune).  Round 6: that was measured on 6 304-row layers.  On the 128-image configurations a pass
+            // is 10-200 x larger while the stages' fixed costs are the same, and Swin (no class token: the slice holds 0.1-0.25
+            // of the weight) still loses a fifth of its search time to candidates the slice already rules out: from 65 536
+            // sample rows on a module prunes when its slice holds 5 % (Swin-B/384 x 128: search 4.75 -> 3.83 s; 25 %: no change,
+            // 1 %: 3.81 s).  What survives is re-evaluated exactly as before: the selection does not depend on the threshold.
             float f = 1.0f;
             int* hm = tune(TUNE_B1_PATH) == 8 ? nullptr : host_mirror(c);
             CHK(enqueue(c, KERN(MassFracParams, k_mass_fraction), dim3(1), dim3(1024), 0,
@@ -1508,7 +1512,8 @@ int slice_fill(Ctx& c, SliceCache* sc, const SliceGeo& g, bool host_sync_ok) {
                 sc->idx_src = nullptr;
                 return slice_fill(c, sc, g2, host_sync_ok);
             }
-            if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : 0.5f))) { sc->loose = true; return 0; }
+            const bool big_pass = zrows >= (tune(TUNE_LOOSE_ROWS) > 0 ? (long)tune(TUNE_LOOSE_ROWS) : 65536L);
+            if (!(f >= (tune(TUNE_LOOSE_PCT) > 0 ? 0.01f * tune(TUNE_LOOSE_PCT) : big_pass ? 0.05f : 0.5f))) { sc->loose = true; return 0; }
         }
         sc->k_eff = g.k;
     }

@@ -117,8 +117,9 @@ def _intervals(wrapped):
 
 
 @pytest.mark.parametrize("model,bits,calib,min_staged", [("vit_base_patch16_224", 8, 32, 250), ("vit_small_patch16_224", 8, 32, 150),
-                                                         ("vit_base_patch16_224", 6, 32, 150), ("deit_tiny_patch16_224", 8, 16, 50)],
-                         ids=["vit-b-w8a8-x32", "vit-s-w8a8-x32", "vit-b-w6a6-x32", "deit-tiny-w8a8-x16"])
+                                                         ("vit_base_patch16_224", 6, 32, 150), ("deit_tiny_patch16_224", 8, 16, 50),
+                                                         ("swin_tiny_patch4_window7_224", 8, 16, 40)],
+                         ids=["vit-b-w8a8-x32", "vit-s-w8a8-x32", "vit-b-w6a6-x32", "deit-tiny-w8a8-x16", "swin-tiny-w8a8-x16-loose-slices"])
 def test_whole_network_calibration_is_bit_identical_with_and_without_pruning(eng, model, bits, calib, min_staged):
     """A whole network (the BASELINE headline ViT-B/224 W8A8 PTQ4ViT x 32 images, 74 modules, and three neighbours): the
     calibration bench.py times; the same calibration again (run-to-run determinism of the four search streams); the same with the
@@ -161,15 +162,21 @@ def test_whole_network_calibration_is_bit_identical_with_and_without_pruning(eng
         torch.cuda.synchronize()
         return _intervals(wrapped), eng.prune_counters(reset=True)
 
-    pruned, c_on = calibrate()
-    again, _ = calibrate()
+    # Swin has no class token: a slice holds 0.1-0.25 of the metric weight, and only the 128-image configurations are large
+    # enough (>= 65 536 sample rows) for the engine to prune on such a slice (round 6).  Tuning key 15 lowers that size limit, so
+    # that the LOOSE-slice passes run here -- exactness must not depend on how much of the weight the slice holds.
+    if "swin" in model:
+        eng.debug_tuning(15, 1024)
     try:
+        pruned, c_on = calibrate()
+        again, _ = calibrate()
         eng.debug_variant(4194304)
         full, c_off = calibrate()
         eng.debug_variant(134217728)
         checked, c_chk = calibrate()
     finally:
         eng.debug_variant(0)
+        eng.debug_tuning(15, 0)
     assert c_chk["staged"] == c_on["staged"], (c_chk, c_on)
     # ViT-B: every executed pass but the `head` Linear's (one row per image: its slice would be the whole layer); the smaller
     # networks keep the passes whose full sweep is cheaper than three staged launches
