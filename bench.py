@@ -377,7 +377,9 @@ def main():
         for tab in (PTQ4ViT.w_bit, PTQ4ViT.a_bit, PTQ4ViT.A_bit, PTQ4ViT.B_bit):
             for k in tab:
                 tab[k] = args.bits
-    wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
+    import contextlib as _ctx, io as _io
+    with _ctx.redirect_stdout(_io.StringIO()):       # (stdout carries the ONE JSON line and nothing else)
+        wrapped = net_wrap.wrap_modules_in_net(net, PTQ4ViT)
     img = models.input_size(args.model)
     g = torch.Generator(device="cpu").manual_seed(0)
     images = torch.randn(args.calib, 3, img, img, generator=g).to(dev)
