@@ -1045,7 +1045,14 @@ class HessianQuantCalibrator(QuantCalibrator):
             t2 = time.time()
             if concurrent:
                 if grouped:
-                    calls = 1 if n_streams == 1 else (getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "3")))
+                    calls = 1 if n_streams == 1 else (getattr(self, "group_calls", None) or int(os.environ.get("P4V_GROUP_CALLS", "0")))
+                    if calls <= 0:
+                        # three concurrent calls overlap each other's small kernels and round trips (ViT-B/224 x 32: 127 ms with one
+                        # call, 112 with three; ViT-S x 32: 68.7 / 62.7; DeiT-tiny x 32: 44.3 / 41.2); a calibration whose captured
+                        # tensors are a few hundred MB is issue-bound and pays for every extra round instead (DeiT-tiny BasePTQ x 4,
+                        # BASELINE config 0: 5 rounds / 27.7 ms with one call, 15 rounds / 29.4 ms with three)
+                        small = sum(self._estimate_cache_bytes(grp).values()) < (512 << 20)
+                        calls = 1 if small else 3
                     self._search_grouped(grp, calls, inputs_ready=cap_done)
                 else:
                     self._search_concurrent(grp, n_streams)
